@@ -1,0 +1,25 @@
+"""CPU oracle for the UNet-2D training hot path.
+
+TEST INFRASTRUCTURE ONLY.  This package is a PyTorch-CPU / numpy restatement of
+the reference algorithm (trnKhanh/medical-image-analysis, `src/models/unet`,
+`src/losses`, `src/transforms`, `src/scheduler`, `ALTrainer.train_step`).  It is
+the checker for the HIP path and the CPU baseline that `bench.py` times.  Only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import it; the product package (`medical-image-analysis_amd/`) never does.
+
+Pinning status
+--------------
+* model / losses / poly-LR / train step / pure-torch transforms (gamma, noise,
+  low-res, rot90, mirror, z-score, combinators): PINNED.  `oracle/gen_golden.py`
+  imports the reference's own `blocks.py`, `unet.py`, `losses/*.py`,
+  `scheduler/lr_scheduler.py` and `transforms/*.py` in the dev container and
+  writes `tests/golden/*.npz`; `tests/test_oracle_golden.py` checks this
+  restatement against those vectors.
+* transforms whose arithmetic lives in torchvision (RandomAffine,
+  RandomRotation, RandomCrop2D, JointResize, RandomGaussianBlur,
+  RandomContrast, RandomBrightness): PARITY UNPINNED.  torchvision is a
+  third-party dependency, un-versioned in the reference's `pyproject.toml:19`,
+  absent from /root/reference and not installed here.  They are restated from
+  torchvision's published algorithm and pinned by analytic known-answer tests
+  only (see `tests/test_oracle_transforms.py`).
+"""

@@ -1,0 +1,158 @@
+"""The oracle (CPU restatement) against vectors produced by the imported reference
+(oracle/gen_golden.py).  Runs on CPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses_ref, train_ref, transforms_ref as T, unet_ref
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name), allow_pickle=False))
+
+
+def params_from(d, prefix="init/"):
+    return {k[len(prefix):]: torch.from_numpy(v.copy()) for k, v in d.items() if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("tag,norm,k1", [("instance", "instance", 3), ("batch", "batch", 3), ("instance_odd", "instance", 4)])
+def test_unet_train_step(tag, norm, k1):
+    d = load(f"unet_{tag}.npz")
+    p = params_from(d)
+    x, y = torch.from_numpy(d["x"]), torch.from_numpy(d["labels"])
+    with torch.no_grad():
+        pe = {k: v.clone() for k, v in p.items()}
+        lo = unet_ref.unet_forward(pe, x, norm, training=False)
+        np.testing.assert_allclose(lo.numpy(), d["eval/logits"], atol=1e-6)
+        assert (lo.softmax(1).argmax(1).numpy() == d["eval/argmax"]).all()
+        np.testing.assert_allclose(unet_ref.enc_feature(pe, x, norm).numpy(), d["eval/enc_feature"], atol=1e-6)
+        np.testing.assert_allclose(unet_ref.pixel_feature(pe, x, norm)[1].numpy(), d["eval/pixel_feature"], atol=1e-6)
+    opt = train_ref.make_optimizer(p, "adamw", weight_decay=5e-4)
+    lr = train_ref.poly_lr(0, 1e-3, 4000, 250)
+    assert lr == float(d["train/lr"])
+    r = train_ref.train_step(p, opt, x, y, k1 - 1, norm, lr=lr)
+    np.testing.assert_allclose(r["logits"].numpy(), d["train/logits"], atol=1e-6)
+    np.testing.assert_allclose(r["loss"].numpy(), d["train/loss"], atol=1e-6)
+    np.testing.assert_allclose(r["grad_norm"].numpy(), d["train/grad_norm"], rtol=1e-5)
+    for k, v in d.items():
+        if k.startswith("post/"):
+            got = p[k[5:]].detach().numpy()
+            # Adam's first step is lr*g/(|g|+eps): where the reference gradient is rounding
+            # noise (conv bias in front of a norm layer: analytically 0) only |delta| <= lr holds.
+            np.testing.assert_allclose(got, v, atol=2.5 * lr, err_msg=k)
+            g = d.get("grad/" + k[5:])
+            if g is not None and v.dtype.kind == "f":
+                m = np.abs(g) > 1e-5
+                np.testing.assert_allclose(got[m], v[m], atol=2e-7, err_msg=k)
+
+
+def test_unet_grads_match():
+    d = load("unet_instance.npz")
+    p = params_from(d)
+    for v in train_ref.trainable(p).values():
+        v.requires_grad_(True)
+    x, y = torch.from_numpy(d["x"]), torch.from_numpy(d["labels"])
+    out = unet_ref.unet_forward(p, x, "instance", True)
+    np.testing.assert_allclose(losses_ref.ce_loss(out, y).item(), d["train/ce"], atol=1e-6)
+    np.testing.assert_allclose(losses_ref.dice_loss(out, y, 2, do_bg=True).item(), d["train/dice"], atol=1e-6)
+    losses_ref.dice_and_ce(out, y, 2).backward()
+    for k, v in d.items():
+        if k.startswith("grad/"):
+            np.testing.assert_allclose(p[k[5:]].grad.numpy(), v, atol=2e-6, err_msg=k)
+
+
+def test_deep_supervision_and_res():
+    d = load("unet_ds.npz")
+    p = params_from(d)
+    x = torch.from_numpy(d["x"])
+    with torch.no_grad():
+        outs = unet_ref.unet_forward(p, x, "instance", False, deep_supervision=True, ds_layer=3, return_ds=True)
+    assert len(outs) == 3
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.numpy(), d[f"eval/ds{i}"], atol=1e-6)
+    d = load("unet_res.npz")
+    p = params_from(d)
+    x = torch.from_numpy(d["x"])
+    with torch.no_grad():
+        lo = unet_ref.unet_forward(p, x, "instance", False, block_type="res")
+    np.testing.assert_allclose(lo.numpy(), d["eval/logits"], atol=1e-6)
+
+
+def test_init_matches_reference_rng_stream():
+    d = load("unet_instance.npz")
+    # gen_golden perturbs norm affine params after init; conv weights are untouched
+    p = unet_ref.init_params(1, 3, [4, 8, 16], "instance", seed=1337)
+    for k in ("encoder.levels.0.0.all.0.weight", "encoder.levels.2.1.all.0.bias",
+              "decoder.upsamples.0.weight", "decoder.upsamples.1.bias", "decoder.seg_output.weight"):
+        np.testing.assert_array_equal(p[k].numpy(), d["init/" + k], err_msg=k)
+    assert set(p) == {k[5:] for k in d if k.startswith("init/")}
+
+
+def test_losses():
+    d = load("losses.npz")
+    logits, labels = torch.from_numpy(d["logits"]), torch.from_numpy(d["labels"])
+    for do_bg in (False, True):
+        for batch in (False, True):
+            for squared in (False, True):
+                key = f"dice_bg{int(do_bg)}_b{int(batch)}_s{int(squared)}"
+                li = logits.clone().requires_grad_(True)
+                v = losses_ref.dice_loss(li, labels, 3, do_bg=do_bg, batch=batch, squared=squared)
+                v.backward()
+                np.testing.assert_allclose(v.item(), d[key], atol=1e-6)
+                np.testing.assert_allclose(li.grad.numpy(), d[key + "_grad"], atol=1e-7)
+    np.testing.assert_allclose(losses_ref.ce_loss(logits, labels[:, None]).item(), d["ce"], atol=1e-6)
+    np.testing.assert_allclose(losses_ref.dice_and_ce(logits, labels, 3, 0.7, 0.3).item(), d["dice_ce_w"], atol=1e-6)
+    np.testing.assert_allclose(losses_ref.dice_and_ce(logits, labels, 3, 0.0, None).item(),
+                               d["dice_ce_zero_weight_quirk"], atol=1e-6)
+    # known answers
+    lab = torch.tensor([[[0, 1], [2, 2]]])
+    assert abs(losses_ref.dice_loss(torch.zeros(1, 3, 2, 2), lab, 2, do_bg=True).item() - 0.6761878354) < 1e-6
+    assert abs(float(d["kat_uniform_dice"]) - 0.6761878354) < 1e-6
+    assert abs(float(d["kat_perfect_dice"])) < 1e-6
+    assert abs(float(d["kat_uniform_ce"]) - np.log(3)) < 1e-6
+
+
+def test_poly_lr():
+    for lr0, n, w, interval, it, want in load("poly_lr.npz")["table"]:
+        got = train_ref.poly_lr(int(it), lr0, int(n), int(w), interval=int(interval))
+        assert got == pytest.approx(want, rel=1e-12, abs=0)
+
+
+def test_transforms_pinned():
+    d = load("transforms.npz")
+    img, lab = torch.from_numpy(d["image"]), torch.from_numpy(d["label"])
+    np.testing.assert_array_equal(T.apply_gamma(img, torch.from_numpy(d["gamma/gamma"])).numpy(), d["gamma/image"])
+    np.testing.assert_array_equal(T.apply_noise(img, torch.from_numpy(d["noise/noise"])).numpy(), d["noise/image"])
+    np.testing.assert_array_equal(T.apply_lowres(img, d["lowres/scales"].tolist()).numpy(), d["lowres/image"])
+    k = int(d["rot90/k"])
+    np.testing.assert_array_equal(T.apply_rot90(img, k).numpy(), d["rot90/image"])
+    np.testing.assert_array_equal(T.apply_rot90(lab, k).numpy(), d["rot90/label"])
+    np.testing.assert_array_equal(T.apply_mirror(img, (-1,)).numpy(), d["mirror_w/image"])
+    np.testing.assert_array_equal(T.apply_mirror(lab, (-2, -1)).numpy(), d["mirror_hw/label"])
+    np.testing.assert_array_equal(T.apply_zscore(img).numpy(), d["zscore/image"])
+    for s, k in d["blur_ksize_table"]:
+        assert T.blur_kernel_size(float(s)) == int(k)
+
+
+def test_transform_draw_order():
+    """RandomTransform draws its uniform before the inner transform's draws (common.py:27)."""
+    d = load("transforms.npz")
+    img, lab = torch.from_numpy(d["image"]), torch.from_numpy(d["label"])
+    for seed in (100, 101, 102, 103):
+        torch.manual_seed(seed)
+        im, lb = img.clone(), lab.clone()
+        if T.draw_apply(0.5):
+            im = T.apply_gamma(im, T.draw_gamma(0.7, 1.5))
+        if T.draw_apply(0.5):
+            im = T.apply_lowres(im, T.draw_lowres_scales(2, 0.5, 1.0))
+        if T.draw_apply(0.5):
+            k = int(torch.randint(0, 4, (1,)).item())
+            im, lb = T.apply_rot90(im, k), T.apply_rot90(lb, k)
+        if T.draw_apply(0.5):
+            im = T.apply_gamma(im, T.draw_gamma(0.7, 1.5))
+        np.testing.assert_array_equal(im.numpy(), d[f"compose_{seed}/image"])
+        np.testing.assert_array_equal(lb.numpy(), d[f"compose_{seed}/label"])
