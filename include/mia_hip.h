@@ -1,0 +1,133 @@
+/* libmia_hip.so -- C ABI of the MI355X (gfx950) UNet-2D training hot path.
+ *
+ * The reference (trnKhanh/medical-image-analysis) is pure Python on top of torch / torchvision library
+ * kernels: it has NO FFI layer of its own for this path.  Each entry point below therefore cites the
+ * reference call site whose library kernel(s) it replaces; the Python classes that bind them
+ * (medical-image-analysis_amd/{models,losses,transforms,...}) keep the reference's class / argument
+ * surface, and INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *   - every pointer is a raw DEVICE pointer unless named host_*; the caller owns all memory
+ *     (inputs, outputs, saved statistics, workspaces); the library never allocates or frees
+ *   - `stream` is a hipStream_t (0 = null stream); all work is enqueued, nothing synchronises
+ *   - activations are NHWC; `dtype` is MIA_F32 or MIA_BF16 and applies to activations and packed
+ *     weights; statistics, parameters, gradients of parameters and logits are always fp32
+ *   - return 0 on success, negative for argument errors (MIA_EARG / MIA_EUNSUPPORTED), positive =
+ *     hipError_t; mia_last_error() returns a thread-local message
+ */
+#ifndef MIA_HIP_H
+#define MIA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIA_F32 0
+#define MIA_BF16 1
+
+int mia_version(void);
+const char* mia_last_error(void);
+
+/* ------------------------------------------------------------------ weights / layout */
+/* fp32 parameter [D0][D1][taps] -> packed [taps][npad][kpad] (zero padded) in `dtype`.
+ * Replaces the cuDNN/MIOpen filter transform behind nn.Conv2d / nn.ConvTranspose2d
+ * (src/models/unet/blocks.py:83-90, unet.py:142).  n_from_d0: n indexes D0 (else D1). */
+int mia_pack_weight(const float* src, void* dst, int dtype, int d0, int d1, int taps, int npad, int kpad,
+                    int n_from_d0, void* stream);
+/* generic strided (n, c, p) copy with dtype conversion: NCHW <-> NHWC, fp32 <-> bf16
+ * (replaces .to(dtype)/.contiguous() at al_trainer.py:1366-1368). */
+int mia_relayout(const void* src, int src_dtype, void* dst, int dst_dtype, int n, int c, int64_t hw,
+                 int64_t ssn, int64_t ssc, int64_t ssp, int64_t dsn, int64_t dsc, int64_t dsp, void* stream);
+/* out[c] (+)= sum over p rows of x[p][c]: bias gradients of Conv2d / ConvTranspose2d. */
+int mia_colsum_workspace(int64_t p, int c); /* floats */
+int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, float* out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ dense conv products (MFMA) */
+#define MIA_CONV_G3S1 0 /* gather 3x3 s1 p1: Conv2d fwd (blocks.py:83-90) and its input gradient (flip_taps=1) */
+#define MIA_CONV_G3S2 1 /* gather 3x3 s2 p1: strided Conv2d fwd (unet.py:58-66, first block of each level) */
+#define MIA_CONV_G2S2 2 /* gather 2x2 s2 p0: ConvTranspose2d input gradient (unet.py:142) */
+#define MIA_CONV_T3S2 3 /* transposed 3x3 s2: strided Conv2d input gradient */
+#define MIA_CONV_T2S2 4 /* transposed 2x2 s2: ConvTranspose2d fwd (unet.py:142, :212) */
+#define MIA_CONV_G1 5   /* 1x1: ResidualBlock skip conv (blocks.py:147-153) */
+/* out[p][n] = bias[n] + sum_taps sum_k in[p*s + tap - pad][k] * wpack[tap][n][k].
+ * in1|in2 are concatenated along channels (c1 + c2) -- this is how torch.cat([skip, up], 1)
+ * (unet.py:213) is eliminated; out1|out2 are split along channels (o1 + o2) for its gradient.
+ * stat_partials (optional): [N][tiles][o1+o2][2] per-tile sum / sum-of-squares of the output
+ * (feeds mia_norm_finalize; replaces the statistics pass of InstanceNorm2d/BatchNorm2d, blocks.py:98).
+ * tiles = tiles_y * tiles_x from mia_conv_mma_tiles(). */
+int mia_conv_mma_tiles(int mode, int hout, int wout, int* tiles_y, int* tiles_x, int* tile_h);
+int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const void* in2, int c2, const void* wpack, int npad,
+                 int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2, int o2,
+                 float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream);
+
+#define MIA_WGRAD_3S1 0
+#define MIA_WGRAD_3S2 1
+#define MIA_WGRAD_2S2 2 /* ConvTranspose2d: x := grad_output (fine grid), dy := layer input (coarse grid) */
+/* slabs[z][tap][npad][kpad] = sum over the z-th share of output pixels of dy[p][n] * x[p*s+tap-pad][k]
+ * (autograd weight gradient of the layers above); mia_wgrad_reduce sums the ksplit slabs in a fixed
+ * order into grad[nn][kk][taps] (= OIHW for Conv2d, [Cin][Cout][2][2] for ConvTranspose2d). */
+int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x);
+int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const void* x2, int c2, const void* dy, int cdy,
+                   float* slabs, int ksplit, int npad, int kpad, int n, int hx, int wx, int hy, int wy, void* stream);
+int mia_wgrad_reduce(const float* slabs, int ksplit, int taps, int npad, int kpad, float* grad, int nn, int kk,
+                     int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ Dropout2d + norm + LeakyReLU */
+#define MIA_NORM_INSTANCE 0
+#define MIA_NORM_BATCH 1
+/* per-(n,c) coefficients from conv-epilogue partials: xhat = xa*y + xb, z = lrelu(scale*y + shift).
+ * drop_scale [N][C] (0 or 1/(1-p)) folds nn.Dropout2d (blocks.py:92-96); batch mode updates
+ * running_mean/var (momentum, unbiased var) and num_batches_tracked like nn.BatchNorm2d. */
+int mia_norm_finalize(const float* partials, int n, int tiles, int c, int64_t hw, int mode, int training,
+                      const float* drop_scale, const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, long long* num_batches, float* xa, float* xb,
+                      float* scale, float* shift, void* stream);
+/* stand-alone statistics partials [N][slabs][C][2] when no conv epilogue produced them */
+int mia_norm_stats(const void* y, int dtype, int n, int64_t hw, int c, int slabs, float* partials, void* stream);
+int mia_norm_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift, int n, int64_t hw, int c,
+                     float slope, void* stream);
+/* backward of (dropout . norm . lrelu): dy, dgamma, dbeta.  partials: [N][slabs][C][2]; c1, c2: [N][C]. */
+int mia_norm_act_bwd(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
+                     const float* xa, const float* xb, int n, int64_t hw, int c, int mode, int fixed_stats, float slope,
+                     int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta, int accumulate,
+                     void* stream);
+
+/* ------------------------------------------------------------------ 1x1 head + Dice/CE loss */
+/* seg_output = Conv2d(c0, K1, 1) (unet.py:176), K1 <= 8.  Logits are fp32 with element strides (osn, osk, osp). */
+int mia_head_fwd(const void* x, int dtype, const float* w, const float* b, float* logits, int n, int64_t hw, int c0, int k1,
+                 int64_t osn, int64_t osk, int64_t osp, void* stream);
+int mia_head_bwd_workspace(int c0, int k1); /* floats */
+int mia_head_bwd(const float* dlogits, const void* x, int dtype, const float* w, void* dx, float* dw, float* db,
+                 float* workspace, int n, int64_t hw, int c0, int k1, int64_t gsn, int64_t gsk, int64_t gsp, int accumulate,
+                 void* stream);
+#define MIA_LOSS_SOFTMAX 1
+#define MIA_LOSS_DO_BG 2
+#define MIA_LOSS_BATCH 4
+#define MIA_LOSS_SQUARED 8
+/* out[0] = ce_w*CE + dice_w*Dice, out[1] = CE (mean over pixels), out[2] = Dice
+ * (DiceLoss.forward dice_loss.py:32-76, DiceAndCELoss.forward compound_losses.py:33-49).
+ * sums [B][K1][3] = (I, sum p, sum t); coef [B][K1][2] feeds the backward; *bad_label set on label outside [0,K1). */
+int mia_dice_ce_workspace(int nb, int k1, int slabs); /* floats */
+int mia_dice_ce_fwd(const float* logits, const long long* labels, int nb, int64_t hw, int k1, int64_t sn, int64_t sk,
+                    int64_t sp, int flags, float smooth, float dice_w, float ce_w, int slabs, float* workspace, float* sums,
+                    float* coef, float* out, int* bad_label, void* stream);
+int mia_dice_ce_bwd(const float* logits, const long long* labels, const float* coef, const float* grad_out, float* dlogits,
+                    int nb, int64_t hw, int k1, int64_t sn, int64_t sk, int64_t sp, int64_t gsn, int64_t gsk, int64_t gsp,
+                    int flags, float dice_w, float ce_w, void* stream);
+
+/* ------------------------------------------------------------------ optimizer (al_trainer.py:1374-1379) */
+#define MIA_OPT_ADAM 0
+#define MIA_OPT_ADAMW 1
+#define MIA_OPT_SGD 2
+int mia_grad_norm_workspace(void); /* floats */
+/* out[0] = global L2 norm, out[1] = min(1, max_norm/(norm+1e-6)) (torch.nn.utils.clip_grad_norm_) */
+int mia_grad_norm(const float* grad, int64_t n, float max_norm, float* workspace, float* out, void* stream);
+int mia_scale_by_clip(float* x, int64_t n, const float* clip, void* stream);
+int mia_optim_step(float* param, const float* grad, float* m, float* v, int64_t n, int kind, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, int first_step,
+                   const float* clip, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

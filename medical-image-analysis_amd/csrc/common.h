@@ -1,0 +1,87 @@
+// Shared helpers for libmia_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define MIA_F32 0
+#define MIA_BF16 1
+
+#define MIA_OK 0
+#define MIA_EARG (-1)
+#define MIA_EUNSUPPORTED (-2)
+
+extern "C" const char* mia_last_error(void);
+void mia_set_error(const char* fmt, ...);
+
+#define MIA_CHECK_ARG(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      mia_set_error(__VA_ARGS__);           \
+      return MIA_EARG;                      \
+    }                                       \
+  } while (0)
+
+// Returns positive hipError_t on launch failure (C-ABI convention, include/mia_hip.h).
+#define MIA_LAUNCH_CHECK()                                                  \
+  do {                                                                      \
+    hipError_t _e = hipGetLastError();                                      \
+    if (_e != hipSuccess) {                                                 \
+      mia_set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+      return (int)_e;                                                       \
+    }                                                                       \
+  } while (0)
+
+typedef unsigned short bf16_t;  // raw storage
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __builtin_bit_cast(float, ((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int EPU = 4;  // elements per 16-byte unit
+  static constexpr int DT = MIA_F32;
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  __device__ static __forceinline__ float cvt(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int EPU = 8;
+  static constexpr int DT = MIA_BF16;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+  __device__ static __forceinline__ bf16_t cvt(float v) { return f2bf(v); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64); result valid in thread 0.
+__device__ __forceinline__ float block_sum(float v, float* red /*>= 16 floats LDS*/) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x < 64) {
+    r = (l < nw) ? red[l] : 0.f;
+    r = wave_sum(r);
+  }
+  return r;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

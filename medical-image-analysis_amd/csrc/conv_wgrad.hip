@@ -1,0 +1,357 @@
+// Weight-gradient kernels on MFMA for gfx950 (NHWC activations).
+//
+//   dW[tap][n][k] = sum over output pixels p of  dy[p][n] * x[p*stride + tap - pad][k]
+//
+// (reference: autograd of nn.Conv2d at src/models/unet/blocks.py:83-90 and of
+// nn.ConvTranspose2d at unet.py:142).  The contraction index is the PIXEL, which is the slow
+// dimension of both NHWC operands, so:
+//   * bf16: tiles are staged to LDS in their natural [pixel][channel] order (XOR-swizzled 8-row x
+//     32-column subtiles) and both MFMA operands are fetched with ds_read_b64_tr_b16 (hardware
+//     transposing read) -> v_mfma_f32_16x16x32_bf16, K = 32 pixels per instruction.
+//   * fp32: v_mfma_f32_16x16x4_f32 takes one scalar per lane; [pixel][channel] LDS rows padded to
+//     80 dwords make the b32 fragment reads conflict free.
+// A workgroup (4 waves) owns a 64(n) x 64(k) block of dW for ALL taps; wave w owns k-tile w and keeps
+// taps x 4 accumulators in registers while it walks its share of the pixel tiles (split-K over
+// gridDim.y).  Partials go to per-split slabs; mia_wgrad_reduce sums the slabs in a fixed order
+// (bitwise reproducible, no float atomics) straight into the parameter's native OIHW / IOHW layout.
+//   MODE_W3S1: 3x3 stride 1 pad 1;  MODE_W3S2: 3x3 stride 2 pad 1;  MODE_W2S2: 2x2 stride 2 pad 0
+//   (MODE_W2S2 is ConvTranspose2d's wgrad with x := grad_output (fine grid), dy := input (coarse)).
+#include "common.h"
+
+enum { MODE_W3S1 = 0, MODE_W3S2 = 1, MODE_W2S2 = 2 };
+
+struct WgArgs {
+  const void* x1; const void* x2; int c1; int c2;
+  const void* dy; int cdy;
+  float* slabs;
+  int N, Hx, Wx, Hy, Wy;
+  int npad, kpad, ksplit;
+  int tiles_x, tiles_y;
+  int vec_x, vec_dy;
+};
+
+template <int MODE> struct WGeo {
+  static constexpr int KS = MODE == MODE_W2S2 ? 2 : 3;
+  static constexpr int S = MODE == MODE_W3S1 ? 1 : 2;
+  static constexpr int PAD = MODE == MODE_W2S2 ? 0 : 1;
+  static constexpr int TAPS = KS * KS;
+};
+
+// ---------------------------------------------------------------- bf16 (tr16 reads)
+__device__ __forceinline__ int swz_off(int row, int ch) {
+  // byte offset of 16-byte chunk `ch` (0..7) of pixel-row `row` in a [rows][64 x bf16] tile, stored as
+  // 8-row x 32-column subtiles of 512 B with the chunk index XOR-swizzled by (row>>2)&3
+  return 512 * ((row >> 3) * 2 + (ch >> 2)) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ s16x4 tr_read(const unsigned char* base, int off) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgs a) {
+  using G = WGeo<MODE>;
+  constexpr int KS = G::KS, S = G::S, PAD = G::PAD, TAPS = G::TAPS;
+  constexpr int TH = (S == 1) ? 8 : 4;
+  constexpr int XH = (TH - 1) * S + KS, XW = 15 * S + KS;
+  constexpr int XROWS = ((XH * XW + 7) / 8) * 8;
+  constexpr int X_BYTES = XROWS * 128, D_BYTES = TH * 16 * 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[X_BYTES + D_BYTES];
+  unsigned char* xs = smem;
+  unsigned char* ds = smem + X_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, i16 = lane & 15, qp = i16 >> 2, pp = i16 & 3;
+  const int nkb = a.kpad / 64;
+  const int kblk = blockIdx.x % nkb, nblk = blockIdx.x / nkb;
+  const int n0 = nblk * 64, k0 = kblk * 64;
+  const int kin = a.c1 + a.c2;
+  const bf16_t* x1 = static_cast<const bf16_t*>(a.x1);
+  const bf16_t* x2 = static_cast<const bf16_t*>(a.x2);
+  const bf16_t* dy = static_cast<const bf16_t*>(a.dy);
+
+  f32x4 acc[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool wave_active = (k0 + wave * 16) < kin;
+
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  for (int tile = blockIdx.y; tile < ntiles; tile += a.ksplit) {
+    int tt = tile;
+    const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+    const int ty = tt % a.tiles_y; tt /= a.tiles_y;
+    const int img = tt;
+    const int oy0 = ty * TH, ox0 = tx * 16;
+    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    __syncthreads();  // previous tile's reads done
+    for (int u = tid; u < XH * XW * 8; u += 256) {
+      const int ch = u & 7, pix = u >> 3;
+      const int iy = pix / XW, ix = pix - iy * XW;
+      const int gy = iy0 + iy, gx = ix0 + ix, c = k0 + ch * 8;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (gy >= 0 && gy < a.Hx && gx >= 0 && gx < a.Wx && c < kin) {
+        const size_t p = ((size_t)img * a.Hx + gy) * a.Wx + gx;
+        if (a.vec_x) {
+          const bf16_t* src = (c < a.c1) ? x1 + p * a.c1 + c : x2 + p * a.c2 + (c - a.c1);
+          v = *reinterpret_cast<const u32x4*>(src);
+        } else {
+          alignas(16) bf16_t tmp[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int ce = c + e;
+            tmp[e] = ce < a.c1 ? x1[p * a.c1 + ce] : (ce < kin ? x2[p * a.c2 + (ce - a.c1)] : (bf16_t)0);
+          }
+          v = *reinterpret_cast<const u32x4*>(tmp);
+        }
+      }
+      *reinterpret_cast<u32x4*>(xs + swz_off(pix, ch)) = v;
+    }
+    for (int u = tid; u < TH * 16 * 8; u += 256) {
+      const int ch = u & 7, pix = u >> 3;
+      const int y = pix >> 4, xx = pix & 15;
+      const int gy = oy0 + y, gx = ox0 + xx, c = n0 + ch * 8;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (gy < a.Hy && gx < a.Wy && c < a.cdy) {
+        const size_t p = ((size_t)img * a.Hy + gy) * a.Wy + gx;
+        if (a.vec_dy) {
+          v = *reinterpret_cast<const u32x4*>(dy + p * a.cdy + c);
+        } else {
+          alignas(16) bf16_t tmp[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) tmp[e] = (c + e < a.cdy) ? dy[p * a.cdy + c + e] : (bf16_t)0;
+          v = *reinterpret_cast<const u32x4*>(tmp);
+        }
+      }
+      *reinterpret_cast<u32x4*>(ds + swz_off(pix, ch)) = v;
+    }
+    __syncthreads();
+    if (wave_active) {
+#pragma unroll
+      for (int kb = 0; kb < TH / 2; ++kb) {
+        // lane group `grp` covers k = 8*grp .. 8*grp+7 of this 32-pixel block; two 4-row tr reads each
+        const int yy = 2 * kb + (grp >> 1), xb = 8 * (grp & 1) + qp;
+        u32x4 af[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int ch = 2 * c + (pp >> 1);
+          const int r0 = yy * 16 + xb;
+          const s16x4 lo = tr_read(ds, swz_off(r0, ch) + 8 * (pp & 1));
+          const s16x4 hi = tr_read(ds, swz_off(r0 + 4, ch) + 8 * (pp & 1));
+          af[c] = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh) {
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) {
+            const int ch = 2 * wave + (pp >> 1);
+            const int r0 = (yy * S + kh) * XW + xb * S + kw;
+            const s16x4 lo = tr_read(xs, swz_off(r0, ch) + 8 * (pp & 1));
+            const s16x4 hi = tr_read(xs, swz_off(r0 + 4 * S, ch) + 8 * (pp & 1));
+            const bf16x8 b = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              acc[kh * KS + kw][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[c]), b,
+                                                                               acc[kh * KS + kw][c], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // slab[z][tap][n][k]: C rows = n (A side), cols = k (B side)
+  float* slab = a.slabs + (size_t)blockIdx.y * TAPS * a.npad * a.kpad;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + c * 16 + 4 * grp + r, k = k0 + wave * 16 + i16;
+        slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+      }
+}
+
+// ---------------------------------------------------------------- fp32
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgArgs a) {
+  using G = WGeo<MODE>;
+  constexpr int KS = G::KS, S = G::S, PAD = G::PAD, TAPS = G::TAPS;
+  constexpr int TH = (S == 1) ? 4 : 2;
+  constexpr int XH = (TH - 1) * S + KS, XW = 15 * S + KS;
+  constexpr int PS = 80;  // LDS pixel stride in dwords (64 channels + 16 pad)
+  __shared__ __attribute__((aligned(16))) float smem[(XH * XW + TH * 16) * PS];
+  float* xs = smem;
+  float* ds = smem + XH * XW * PS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, i16 = lane & 15;
+  const int nkb = a.kpad / 64;
+  const int kblk = blockIdx.x % nkb, nblk = blockIdx.x / nkb;
+  const int n0 = nblk * 64, k0 = kblk * 64;
+  const int kin = a.c1 + a.c2;
+  const float* x1 = static_cast<const float*>(a.x1);
+  const float* x2 = static_cast<const float*>(a.x2);
+  const float* dy = static_cast<const float*>(a.dy);
+
+  f32x4 acc[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool wave_active = (k0 + wave * 16) < kin;
+
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  for (int tile = blockIdx.y; tile < ntiles; tile += a.ksplit) {
+    int tt = tile;
+    const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+    const int ty = tt % a.tiles_y; tt /= a.tiles_y;
+    const int img = tt;
+    const int oy0 = ty * TH, ox0 = tx * 16;
+    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    __syncthreads();
+    for (int u = tid; u < XH * XW * 16; u += 256) {
+      const int ch = u & 15, pix = u >> 4;
+      const int iy = pix / XW, ix = pix - iy * XW;
+      const int gy = iy0 + iy, gx = ix0 + ix, c = k0 + ch * 4;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < a.Hx && gx >= 0 && gx < a.Wx && c < kin) {
+        const size_t p = ((size_t)img * a.Hx + gy) * a.Wx + gx;
+        if (a.vec_x) {
+          const float* src = (c < a.c1) ? x1 + p * a.c1 + c : x2 + p * a.c2 + (c - a.c1);
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ce = c + e;
+            v[e] = ce < a.c1 ? x1[p * a.c1 + ce] : (ce < kin ? x2[p * a.c2 + (ce - a.c1)] : 0.f);
+          }
+        }
+      }
+      *reinterpret_cast<f32x4*>(xs + pix * PS + ch * 4) = v;
+    }
+    for (int u = tid; u < TH * 16 * 16; u += 256) {
+      const int ch = u & 15, pix = u >> 4;
+      const int y = pix >> 4, xx = pix & 15;
+      const int gy = oy0 + y, gx = ox0 + xx, c = n0 + ch * 4;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (gy < a.Hy && gx < a.Wy && c < a.cdy) {
+        const size_t p = ((size_t)img * a.Hy + gy) * a.Wy + gx;
+        if (a.vec_dy) {
+          v = *reinterpret_cast<const f32x4*>(dy + p * a.cdy + c);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (c + e < a.cdy) ? dy[p * a.cdy + c + e] : 0.f;
+        }
+      }
+      *reinterpret_cast<f32x4*>(ds + pix * PS + ch * 4) = v;
+    }
+    __syncthreads();
+    if (wave_active) {
+      for (int y = 0; y < TH; ++y) {
+#pragma unroll
+        for (int xq = 0; xq < 4; ++xq) {
+          const int xx = xq * 4 + q;  // this lane's pixel (k index) within the row
+          float af[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) af[c] = ds[(y * 16 + xx) * PS + c * 16 + i16];
+#pragma unroll
+          for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+              const float b = xs[((y * S + kh) * XW + xx * S + kw) * PS + wave * 16 + i16];
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                acc[kh * KS + kw][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], b, acc[kh * KS + kw][c], 0, 0, 0);
+            }
+        }
+      }
+    }
+  }
+  float* slab = a.slabs + (size_t)blockIdx.y * TAPS * a.npad * a.kpad;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + c * 16 + 4 * q + r, k = k0 + wave * 16 + i16;
+        slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+      }
+}
+
+// ---------------------------------------------------------------- slab reduce -> native parameter layout
+// layout 0: conv   grad[n][k][kh][kw]  (OIHW, n = Cout, k = Cin)
+// layout 1: convT  grad[n][k][kh][kw] where the parameter is [Cin_T][Cout_T][2][2] and the GEMM ran with
+//           n := Cin_T (coarse-side channels, "dy" operand) and k := Cout_T (fine-side channels, "x" operand)
+__global__ void wgrad_reduce_kernel(const float* slabs, int ksplit, int taps, int npad, int kpad, float* grad, int nn,
+                                    int kk, int accumulate) {
+  const int64_t total = (int64_t)nn * kk * taps;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % taps);
+    const int k = (int)((i / taps) % kk);
+    const int n = (int)(i / ((int64_t)taps * kk));
+    const size_t off = ((size_t)t * npad + n) * kpad + k;
+    const size_t sstride = (size_t)taps * npad * kpad;
+    float s = 0.f;
+    for (int z = 0; z < ksplit; ++z) s += slabs[z * sstride + off];
+    grad[i] = accumulate ? grad[i] + s : s;
+  }
+}
+
+extern "C" int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x) {
+  const int s = mode == MODE_W3S1 ? 1 : 2;
+  const int th = dtype == MIA_BF16 ? (s == 1 ? 8 : 4) : (s == 1 ? 4 : 2);
+  if (tiles_y) *tiles_y = ceil_div(hy, th);
+  if (tiles_x) *tiles_x = ceil_div(wy, 16);
+  return MIA_OK;
+}
+
+extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const void* x2, int c2, const void* dy,
+                              int cdy, float* slabs, int ksplit, int npad, int kpad, int n, int hx, int wx, int hy,
+                              int wy, void* stream) {
+  MIA_CHECK_ARG(mode >= 0 && mode <= MODE_W2S2, "mia_conv_wgrad: bad mode %d", mode);
+  MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_conv_wgrad: bad dtype");
+  MIA_CHECK_ARG(x1 && dy && slabs && c1 > 0 && c2 >= 0 && cdy > 0, "mia_conv_wgrad: null/empty operand");
+  MIA_CHECK_ARG((c2 == 0) == (x2 == nullptr), "mia_conv_wgrad: split operand mismatch");
+  MIA_CHECK_ARG(npad % 64 == 0 && kpad % 64 == 0 && npad >= cdy && kpad >= c1 + c2, "mia_conv_wgrad: bad padding");
+  MIA_CHECK_ARG(ksplit >= 1 && ksplit <= 65535, "mia_conv_wgrad: bad ksplit %d", ksplit);
+  bool ok = mode == MODE_W3S1 ? (hx == hy && wx == wy)
+          : mode == MODE_W3S2 ? (hy == (hx + 1) / 2 && wy == (wx + 1) / 2) : (hx == 2 * hy && wx == 2 * wy);
+  MIA_CHECK_ARG(ok, "mia_conv_wgrad: mode %d shape mismatch x %dx%d dy %dx%d", mode, hx, wx, hy, wy);
+  WgArgs a;
+  a.x1 = x1; a.x2 = x2; a.c1 = c1; a.c2 = c2; a.dy = dy; a.cdy = cdy; a.slabs = slabs;
+  a.N = n; a.Hx = hx; a.Wx = wx; a.Hy = hy; a.Wy = wy; a.npad = npad; a.kpad = kpad; a.ksplit = ksplit;
+  mia_wgrad_geometry(mode, dtype, hy, wy, &a.tiles_y, &a.tiles_x);
+  const int epu = dtype == MIA_BF16 ? 8 : 4;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  a.vec_x = (c1 % epu == 0) && (c2 % epu == 0) && al16(x1) && (x2 == nullptr || al16(x2));
+  a.vec_dy = (cdy % epu == 0) && al16(dy);
+  dim3 grid((npad / 64) * (kpad / 64), ksplit);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == MIA_BF16) {
+    if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W3S1>, grid, dim3(256), 0, st, a);
+    else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W3S2>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W2S2>, grid, dim3(256), 0, st, a);
+  } else {
+    if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_f32_kernel<MODE_W3S1>, grid, dim3(256), 0, st, a);
+    else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_f32_kernel<MODE_W3S2>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_f32_kernel<MODE_W2S2>, grid, dim3(256), 0, st, a);
+  }
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+extern "C" int mia_wgrad_reduce(const float* slabs, int ksplit, int taps, int npad, int kpad, float* grad, int nn,
+                                int kk, int accumulate, void* stream) {
+  MIA_CHECK_ARG(slabs && grad && ksplit >= 1 && taps >= 1 && nn >= 1 && kk >= 1 && nn <= npad && kk <= kpad,
+                "mia_wgrad_reduce: bad arguments");
+  const int64_t total = (int64_t)nn * kk * taps;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs, ksplit,
+                     taps, npad, kpad, grad, nn, kk, accumulate);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}

@@ -1,0 +1,368 @@
+// 1x1 segmentation head (C0 -> K1 <= 8 logits) and the fused Dice + cross-entropy loss, gfx950.
+//
+// Reference: seg_output = Conv2d(c0, K1, 1) (src/models/unet/unet.py:176); DiceLoss.forward
+// (src/losses/dice_loss.py:32-76); DiceAndCELoss.forward (src/losses/compound_losses.py:33-49) with
+// torch.nn.CrossEntropyLoss (mean over all pixels).  These are pure bandwidth: the head reads C0
+// values and writes K1 per pixel; the loss reads K1 logits + one label per pixel ONCE (the reference
+// materialises softmax, a long one-hot, a float one-hot and a product) and reduces I = sum p*t,
+// sum p (or p^2), sum t per (image, class) plus the CE sum with wave shuffles, no float atomics.
+#include "common.h"
+
+#define MAXK 8
+
+// ---------------------------------------------------------------- head forward
+// 8 lanes per pixel, each lane strides over the pixel's 16-byte units; K1 accumulators; xor-shuffle reduce.
+template <typename T>
+__global__ void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                float* __restrict__ out, int64_t npix, int c0, int k1, int64_t osp, int64_t osk,
+                                int64_t osn, int64_t hw) {
+  extern __shared__ float wsh[];  // [k1][c0]
+  for (int i = threadIdx.x; i < k1 * c0; i += blockDim.x) wsh[i] = w[i];
+  __syncthreads();
+  constexpr int EPU = Elem<T>::EPU;
+  const int sub = threadIdx.x & 7;
+  const bool vec = (c0 % EPU) == 0;
+  for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; p < npix; p += ((int64_t)gridDim.x * blockDim.x) >> 3) {
+    float acc[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) acc[k] = 0.f;
+    const T* row = x + p * c0;
+    if (vec) {
+      for (int u = sub; u < c0 / EPU; u += 8) {
+        alignas(16) T v[EPU];
+        *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(row + u * EPU);
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) {
+          const float xv = Elem<T>::ld(v + e);
+#pragma unroll
+          for (int k = 0; k < MAXK; ++k)
+            if (k < k1) acc[k] += xv * wsh[k * c0 + u * EPU + e];
+        }
+      }
+    } else {
+      for (int ch = sub; ch < c0; ch += 8) {
+        const float xv = Elem<T>::ld(row + ch);
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+          if (k < k1) acc[k] += xv * wsh[k * c0 + ch];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      if (k < k1) {
+        float v = acc[k];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        if (sub == 0) out[(p / hw) * osn + (p % hw) * osp + k * osk] = v + b[k];
+      }
+    }
+  }
+}
+
+extern "C" int mia_head_fwd(const void* x, int dtype, const float* w, const float* b, float* logits, int n, int64_t hw,
+                            int c0, int k1, int64_t osn, int64_t osk, int64_t osp, void* stream) {
+  MIA_CHECK_ARG(x && w && b && logits && n > 0 && hw > 0 && c0 > 0, "mia_head_fwd: bad arguments");
+  MIA_CHECK_ARG(k1 >= 1 && k1 <= MAXK, "mia_head_fwd: k1=%d not in [1,%d]", k1, MAXK);
+  MIA_CHECK_ARG((size_t)k1 * c0 * 4 <= 60000, "mia_head_fwd: weight tile too large for LDS");
+  const int64_t npix = (int64_t)n * hw;
+  const int blocks = (int)((npix * 8 + 255) / 256 < 8192 ? (npix * 8 + 255) / 256 : 8192);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == MIA_BF16)
+    hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), k1 * c0 * 4, st, static_cast<const bf16_t*>(x), w, b, logits, npix, c0, k1, osp, osk, osn, hw);
+  else if (dtype == MIA_F32)
+    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(blocks), dim3(256), k1 * c0 * 4, st, static_cast<const float*>(x), w, b, logits, npix, c0, k1, osp, osk, osn, hw);
+  else { mia_set_error("mia_head_fwd: bad dtype"); return MIA_EARG; }
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------- head backward (input gradient)
+template <typename T>
+__global__ void head_bwd_input_kernel(const float* __restrict__ dl, const float* __restrict__ w, T* __restrict__ dx,
+                                      int64_t npix, int c0, int k1, int64_t gsp, int64_t gsk, int64_t gsn, int64_t hw) {
+  extern __shared__ float wsh[];
+  for (int i = threadIdx.x; i < k1 * c0; i += blockDim.x) wsh[i] = w[i];
+  __syncthreads();
+  const int64_t total = npix * c0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / c0;
+    const int ch = (int)(i - p * c0);
+    const float* g = dl + (p / hw) * gsn + (p % hw) * gsp;
+    float s = 0.f;
+    for (int k = 0; k < k1; ++k) s += g[k * gsk] * wsh[k * c0 + ch];
+    Elem<T>::st(dx + i, s);
+  }
+}
+
+// weight / bias gradient partials: block handles a pixel slab; thread -> channel, loops pixels
+template <typename T>
+__global__ void head_bwd_weight_kernel(const float* __restrict__ dl, const T* __restrict__ x, float* __restrict__ part,
+                                       int64_t npix, int c0, int k1, int64_t gsp, int64_t gsk, int64_t gsn, int64_t hw) {
+  // part: [gridDim.x][k1][c0 + 1]  (last column = bias partial)
+  extern __shared__ float sh[];  // [rows_par][cw] per k
+  const int cw = blockDim.x >= c0 ? c0 : blockDim.x, rows_par = blockDim.x / cw;
+  const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+  const int64_t per = (npix + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = r0 + per < npix ? r0 + per : npix;
+  for (int cb = 0; cb < c0; cb += cw) {
+    const int ch = cb + tc;
+    float acc[MAXK], bacc[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) { acc[k] = 0.f; bacc[k] = 0.f; }
+    if (ch < c0 && tr < rows_par)
+      for (int64_t p = r0 + tr; p < r1; p += rows_par) {
+        const float xv = Elem<T>::ld(x + p * c0 + ch);
+        const float* g = dl + (p / hw) * gsn + (p % hw) * gsp;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+          if (k < k1) { const float gv = g[k * gsk]; acc[k] += gv * xv; bacc[k] += gv; }
+      }
+    for (int k = 0; k < k1; ++k) {
+      __syncthreads();
+      sh[threadIdx.x] = acc[k];
+      sh[blockDim.x + threadIdx.x] = bacc[k];
+      __syncthreads();
+      if (tr == 0 && ch < c0) {
+        float t = 0.f;
+        for (int j = 0; j < rows_par; ++j) t += sh[j * cw + tc];
+        part[((size_t)blockIdx.x * k1 + k) * (c0 + 1) + ch] = t;
+        if (ch == 0) {
+          float tb = 0.f;
+          for (int j = 0; j < rows_par; ++j) tb += sh[blockDim.x + j * cw];
+          part[((size_t)blockIdx.x * k1 + k) * (c0 + 1) + c0] = tb;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void head_bwd_final_kernel(const float* __restrict__ part, int nblk, int k1, int c0, float* __restrict__ dw,
+                                      float* __restrict__ db, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k1 * (c0 + 1)) return;
+  const int k = i / (c0 + 1), ch = i % (c0 + 1);
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[((size_t)b * k1 + k) * (c0 + 1) + ch];
+  if (ch < c0) dw[k * c0 + ch] = accumulate ? dw[k * c0 + ch] + s : s;
+  else db[k] = accumulate ? db[k] + s : s;
+}
+
+#define HEAD_BWD_BLOCKS 512
+extern "C" int mia_head_bwd_workspace(int c0, int k1) { return HEAD_BWD_BLOCKS * k1 * (c0 + 1); }
+
+extern "C" int mia_head_bwd(const float* dlogits, const void* x, int dtype, const float* w, void* dx, float* dw, float* db,
+                            float* workspace, int n, int64_t hw, int c0, int k1, int64_t gsn, int64_t gsk, int64_t gsp,
+                            int accumulate, void* stream) {
+  MIA_CHECK_ARG(dlogits && x && w && dw && db && workspace && n > 0 && hw > 0 && c0 > 0, "mia_head_bwd: bad arguments");
+  MIA_CHECK_ARG(k1 >= 1 && k1 <= MAXK, "mia_head_bwd: k1=%d not in [1,%d]", k1, MAXK);
+  const int64_t npix = (int64_t)n * hw;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t total = npix * c0;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  const int wblocks = (int)(npix / 64 < 1 ? 1 : (npix / 64 > HEAD_BWD_BLOCKS ? HEAD_BWD_BLOCKS : npix / 64));
+  if (dtype == MIA_BF16) {
+    if (dx) hipLaunchKernelGGL(head_bwd_input_kernel<bf16_t>, dim3(blocks), dim3(256), k1 * c0 * 4, st, dlogits, w, static_cast<bf16_t*>(dx), npix, c0, k1, gsp, gsk, gsn, hw);
+    hipLaunchKernelGGL(head_bwd_weight_kernel<bf16_t>, dim3(wblocks), dim3(256), 512 * 4, st, dlogits, static_cast<const bf16_t*>(x), workspace, npix, c0, k1, gsp, gsk, gsn, hw);
+  } else if (dtype == MIA_F32) {
+    if (dx) hipLaunchKernelGGL(head_bwd_input_kernel<float>, dim3(blocks), dim3(256), k1 * c0 * 4, st, dlogits, w, static_cast<float*>(dx), npix, c0, k1, gsp, gsk, gsn, hw);
+    hipLaunchKernelGGL(head_bwd_weight_kernel<float>, dim3(wblocks), dim3(256), 512 * 4, st, dlogits, static_cast<const float*>(x), workspace, npix, c0, k1, gsp, gsk, gsn, hw);
+  } else { mia_set_error("mia_head_bwd: bad dtype"); return MIA_EARG; }
+  hipLaunchKernelGGL(head_bwd_final_kernel, dim3(ceil_div(k1 * (c0 + 1), 128)), dim3(128), 0, st, workspace, wblocks, k1, c0, dw, db, accumulate);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------- fused Dice + CE
+// flags
+#define LF_SOFTMAX 1
+#define LF_DO_BG 2
+#define LF_BATCH 4
+#define LF_SQUARED 8
+
+struct LossGeom { int64_t sn, sk, sp; };  // element strides of the logits tensor: image, class, pixel
+
+// forward partials: part[b][slab][k][3] (I, sum_p, sum_t) and cepart[b][slab]
+__global__ void dice_ce_fwd_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, int64_t hw, int k1,
+                                   LossGeom g, int flags, int slabs, float* __restrict__ part, float* __restrict__ cepart,
+                                   int* __restrict__ bad_label) {
+  __shared__ float red[16];
+  const int b = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  const int64_t per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  float si[MAXK], sp[MAXK], st[MAXK], ce = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) { si[k] = 0.f; sp[k] = 0.f; st[k] = 0.f; }
+  const float* base = logits + b * g.sn;
+  for (int64_t p = r0 + threadIdx.x; p < r1; p += blockDim.x) {
+    float v[MAXK];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+      if (k < k1) { v[k] = base[p * g.sp + k * g.sk]; mx = fmaxf(mx, v[k]); }
+    const long long lab = labels[(int64_t)b * hw + p];
+    if (lab < 0 || lab >= k1) { *bad_label = 1; continue; }
+    float pr[MAXK];
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+      if (k < k1) { pr[k] = __expf(v[k] - mx); se += pr[k]; }
+    const float inv = 1.f / se;
+    const float lse = mx + __logf(se);
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+      if (k < k1) {
+        const float pk = (flags & LF_SOFTMAX) ? pr[k] * inv : v[k];
+        const float t = (k == (int)lab) ? 1.f : 0.f;
+        si[k] += pk * t;
+        sp[k] += (flags & LF_SQUARED) ? pk * pk : pk;
+        st[k] += t;
+        if (k == (int)lab) ce += lse - v[k];
+      }
+  }
+  for (int k = 0; k < k1; ++k) {
+    float* dst = part + (((size_t)b * slabs + s) * k1 + k) * 3;
+    float r;
+    r = block_sum(si[k], red); if (threadIdx.x == 0) dst[0] = r;
+    r = block_sum(sp[k], red); if (threadIdx.x == 0) dst[1] = r;
+    r = block_sum(st[k], red); if (threadIdx.x == 0) dst[2] = r;
+  }
+  const float r = block_sum(ce, red);
+  if (threadIdx.x == 0) cepart[(size_t)b * slabs + s] = r;
+}
+
+// finalize: sums[b][k][3]; coef[b][k][2] = (alpha, beta) with dDice/dp_k(pixel) = alpha*t (+2p*... if squared) + beta
+// out[0] = total loss, out[1] = ce, out[2] = dice
+__global__ void dice_ce_finalize_kernel(const float* __restrict__ part, const float* __restrict__ cepart, int nb, int slabs,
+                                        int k1, int64_t hw, int flags, float smooth, float dice_w, float ce_w,
+                                        float* __restrict__ sums, float* __restrict__ coef, float* __restrict__ out) {
+  // single block; thread -> (b,k)
+  __shared__ double dsum[256];
+  __shared__ double cesum[256];
+  const int kb = (flags & LF_DO_BG) ? 0 : 1;
+  const int nk = k1 - kb;
+  const int total = nb * k1;
+  double mydice = 0.0, myce = 0.0;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int b = i / k1, k = i % k1;
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int s = 0; s < slabs; ++s) {
+      const float* p = part + (((size_t)b * slabs + s) * k1 + k) * 3;
+      a0 += p[0]; a1 += p[1]; a2 += p[2];
+    }
+    sums[i * 3 + 0] = (float)a0; sums[i * 3 + 1] = (float)a1; sums[i * 3 + 2] = (float)a2;
+  }
+  for (int i = threadIdx.x; i < nb * slabs; i += blockDim.x) myce += cepart[i];
+  __syncthreads();
+  // dice terms (thread per (b,k) for !batch, per k for batch)
+  if (flags & LF_BATCH) {
+    for (int k = kb + threadIdx.x; k < k1; k += blockDim.x) {
+      double I = 0, P = 0, Tt = 0;
+      for (int b = 0; b < nb; ++b) { I += sums[(b * k1 + k) * 3]; P += sums[(b * k1 + k) * 3 + 1]; Tt += sums[(b * k1 + k) * 3 + 2]; }
+      I /= nb; P /= nb; Tt /= nb;
+      const double num = 2 * I + smooth, den = P + Tt + smooth;
+      mydice += (1.0 - num / den) / nk;
+      // d(dice_k)/dI_b = -(2/den)/nb ; d/dP_b = (num/den^2)/nb ; loss = mean_k
+      for (int b = 0; b < nb; ++b) {
+        coef[(b * k1 + k) * 2 + 0] = (float)(-(2.0 / den) / nb / nk);
+        coef[(b * k1 + k) * 2 + 1] = (float)((num / (den * den)) / nb / nk);
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int k = i % k1;
+      if (k < kb) continue;
+      const double I = sums[i * 3], P = sums[i * 3 + 1], Tt = sums[i * 3 + 2];
+      const double num = 2 * I + smooth, den = P + Tt + smooth;
+      mydice += (1.0 - num / den) / ((double)nb * nk);
+      coef[i * 2 + 0] = (float)(-(2.0 / den) / ((double)nb * nk));
+      coef[i * 2 + 1] = (float)((num / (den * den)) / ((double)nb * nk));
+    }
+  }
+  if (!(flags & LF_DO_BG))
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) { coef[(b * k1) * 2] = 0.f; coef[(b * k1) * 2 + 1] = 0.f; }
+  dsum[threadIdx.x] = mydice; cesum[threadIdx.x] = myce;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double d = 0, c = 0;
+    for (int i = 0; i < blockDim.x; ++i) { d += dsum[i]; c += cesum[i]; }
+    c /= ((double)nb * (double)hw);
+    out[1] = (float)c; out[2] = (float)d;
+    out[0] = (float)(ce_w * c + dice_w * d);
+  }
+}
+
+// backward: dlogits[b,p,k] = gout * ( ce_w/(B*HW) * (softmax_k - t_k) + dice_w * dDice/dlogit_k )
+__global__ void dice_ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                   const float* __restrict__ coef, const float* __restrict__ gout, float* __restrict__ dl,
+                                   int nb, int64_t hw, int k1, LossGeom g, LossGeom go, int flags, float dice_w, float ce_w) {
+  const int64_t total = (int64_t)nb * hw;
+  const float go_s = gout ? gout[0] : 1.f;
+  const float cew = ce_w / (float)((double)nb * (double)hw);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / hw);
+    const int64_t p = i - (int64_t)b * hw;
+    const float* src = logits + b * g.sn + p * g.sp;
+    float v[MAXK], pr[MAXK];
+    float mx = -INFINITY, se = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+      if (k < k1) { v[k] = src[k * g.sk]; mx = fmaxf(mx, v[k]); }
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+      if (k < k1) { pr[k] = __expf(v[k] - mx); se += pr[k]; }
+    const float inv = 1.f / se;
+    const int lab = (int)labels[i];
+    // dL/dp_k for the dice part
+    float gk[MAXK], dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+      if (k < k1) {
+        const float sm = pr[k] * inv;
+        const float pk = (flags & LF_SOFTMAX) ? sm : v[k];
+        const float al = coef[((size_t)b * k1 + k) * 2], be = coef[((size_t)b * k1 + k) * 2 + 1];
+        float gg = al * (k == lab ? 1.f : 0.f) + be * ((flags & LF_SQUARED) ? 2.f * pk : 1.f);
+        gk[k] = gg * dice_w;
+        pr[k] = sm;
+        dot += gk[k] * sm;
+      }
+    float* dst = dl + b * go.sn + p * go.sp;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+      if (k < k1) {
+        const float dd = (flags & LF_SOFTMAX) ? pr[k] * (gk[k] - dot) : gk[k];
+        const float dc = cew * (pr[k] - (k == lab ? 1.f : 0.f));
+        dst[k * go.sk] = go_s * (dd + dc);
+      }
+  }
+}
+
+extern "C" int mia_dice_ce_workspace(int nb, int k1, int slabs) { return nb * slabs * (k1 * 3 + 1); }
+
+// sums: [B][K1][3], coef: [B][K1][2], out: [3] (loss, ce, dice), bad_label: int flag (device)
+extern "C" int mia_dice_ce_fwd(const float* logits, const long long* labels, int nb, int64_t hw, int k1, int64_t sn, int64_t sk,
+                               int64_t sp, int flags, float smooth, float dice_w, float ce_w, int slabs, float* workspace,
+                               float* sums, float* coef, float* out, int* bad_label, void* stream) {
+  MIA_CHECK_ARG(logits && labels && workspace && sums && coef && out && bad_label, "mia_dice_ce_fwd: null pointer");
+  MIA_CHECK_ARG(nb > 0 && hw > 0 && slabs > 0, "mia_dice_ce_fwd: bad shape");
+  MIA_CHECK_ARG(k1 >= 1 && k1 <= MAXK, "mia_dice_ce_fwd: k1=%d not in [1,%d]", k1, MAXK);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  LossGeom g{sn, sk, sp};
+  float* part = workspace;
+  float* cepart = workspace + (size_t)nb * slabs * k1 * 3;
+  hipLaunchKernelGGL(dice_ce_fwd_kernel, dim3(nb * slabs), dim3(256), 0, st, logits, labels, hw, k1, g, flags, slabs, part, cepart, bad_label);
+  hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(256), 0, st, part, cepart, nb, slabs, k1, hw, flags, smooth, dice_w, ce_w, sums, coef, out);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+extern "C" int mia_dice_ce_bwd(const float* logits, const long long* labels, const float* coef, const float* grad_out,
+                               float* dlogits, int nb, int64_t hw, int k1, int64_t sn, int64_t sk, int64_t sp, int64_t gsn,
+                               int64_t gsk, int64_t gsp, int flags, float dice_w, float ce_w, void* stream) {
+  MIA_CHECK_ARG(logits && labels && coef && dlogits && nb > 0 && hw > 0, "mia_dice_ce_bwd: bad arguments");
+  MIA_CHECK_ARG(k1 >= 1 && k1 <= MAXK, "mia_dice_ce_bwd: k1=%d not in [1,%d]", k1, MAXK);
+  const int64_t total = (int64_t)nb * hw;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  LossGeom g{sn, sk, sp}, go{gsn, gsk, gsp};
+  hipLaunchKernelGGL(dice_ce_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), logits, labels, coef,
+                     grad_out, dlogits, nb, hw, k1, g, go, flags, dice_w, ce_w);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}

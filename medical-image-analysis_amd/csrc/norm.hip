@@ -1,0 +1,311 @@
+// Instance / batch normalisation + channel dropout + LeakyReLU(0.01), NHWC, gfx950.
+//
+// Reference block: conv -> Dropout2d -> InstanceNorm2d|BatchNorm2d(eps=1e-5, affine) -> LeakyReLU
+// (src/models/unet/blocks.py:92-102).  All three collapse to per-(image, channel) coefficients:
+//     y' = m*y                      (m = 0 or 1/(1-p), Dropout2d channel mask)
+//     xhat = (y' - mean')*rstd' = xa*y + xb
+//     z = lrelu(gamma*xhat + beta) = lrelu(scale*y + shift)
+// The conv epilogue (conv_mma.hip) already produced per-tile sum / sum-of-squares partials, so the
+// statistics cost no extra pass over the activation; the apply passes are pure HBM streams with
+// 16-byte accesses, reductions use wave shuffles + one LDS hop, and no float atomics are used.
+#include "common.h"
+
+#define NORM_INSTANCE 0
+#define NORM_BATCH 1
+
+// ---------------------------------------------------------------- forward statistics finalize
+// partials: [N][T][C][2] (sum, sumsq) of the raw conv output.  One thread per (n, c) for instance,
+// per c for batch (loops n).  Accumulates in double: var = E[y^2] - mean^2 must not cancel in fp32.
+__global__ void norm_finalize_kernel(const float* __restrict__ part, int n_img, int tiles, int c, int64_t hw, int mode,
+                                     int training, const float* __restrict__ drop, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+                                     float* running_var, long long* num_batches, float* __restrict__ xa,
+                                     float* __restrict__ xb, float* __restrict__ scale, float* __restrict__ shift) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mode == NORM_INSTANCE) {
+    if (idx >= n_img * c) return;
+    const int n = idx / c, ch = idx % c;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < tiles; ++t) {
+      const float* p = part + (((size_t)n * tiles + t) * c + ch) * 2;
+      s1 += p[0]; s2 += p[1];
+    }
+    const double m = drop ? (double)drop[idx] : 1.0;
+    const double mean = s1 / (double)hw;
+    double var = s2 / (double)hw - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(m * m * var + (double)eps);
+    const float a = (float)(m * rstd), b = (float)(-m * mean * rstd);
+    xa[idx] = a; xb[idx] = b;
+    scale[idx] = gamma[ch] * a; shift[idx] = gamma[ch] * b + beta[ch];
+    return;
+  }
+  // batch
+  if (idx >= c) return;
+  const int ch = idx;
+  double rstd, meanp;
+  if (training) {
+    double e1 = 0.0, e2 = 0.0;
+    for (int n = 0; n < n_img; ++n) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int t = 0; t < tiles; ++t) {
+        const float* p = part + (((size_t)n * tiles + t) * c + ch) * 2;
+        s1 += p[0]; s2 += p[1];
+      }
+      const double m = drop ? (double)drop[n * c + ch] : 1.0;
+      e1 += m * s1; e2 += m * m * s2;
+    }
+    const double cnt = (double)n_img * (double)hw;
+    meanp = e1 / cnt;
+    double var = e2 / cnt - meanp * meanp;
+    if (var < 0.0) var = 0.0;
+    rstd = 1.0 / sqrt(var + (double)eps);
+    if (running_mean) {
+      const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+      running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * meanp);
+      running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+      if (ch == 0 && num_batches) *num_batches += 1;
+    }
+  } else {
+    meanp = running_mean[ch];
+    rstd = 1.0 / sqrt((double)running_var[ch] + (double)eps);
+  }
+  for (int n = 0; n < n_img; ++n) {
+    const double m = (training && drop) ? (double)drop[n * c + ch] : 1.0;
+    const float a = (float)(m * rstd), b = (float)(-meanp * rstd);
+    xa[n * c + ch] = a; xb[n * c + ch] = b;
+    scale[n * c + ch] = gamma[ch] * a; shift[n * c + ch] = gamma[ch] * b + beta[ch];
+  }
+}
+
+extern "C" int mia_norm_finalize(const float* partials, int n, int tiles, int c, int64_t hw, int mode, int training,
+                                 const float* drop_scale, const float* gamma, const float* beta, float eps, float momentum,
+                                 float* running_mean, float* running_var, long long* num_batches, float* xa, float* xb,
+                                 float* scale, float* shift, void* stream) {
+  MIA_CHECK_ARG(mode == NORM_INSTANCE || mode == NORM_BATCH, "mia_norm_finalize: bad mode %d", mode);
+  MIA_CHECK_ARG(gamma && beta && xa && xb && scale && shift && n > 0 && c > 0 && hw > 0, "mia_norm_finalize: bad arguments");
+  MIA_CHECK_ARG(partials || (mode == NORM_BATCH && !training), "mia_norm_finalize: partials required");
+  MIA_CHECK_ARG(mode == NORM_INSTANCE || training || (running_mean && running_var), "mia_norm_finalize: eval batch norm needs running stats");
+  const int work = mode == NORM_INSTANCE ? n * c : c;
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(ceil_div(work, 128)), dim3(128), 0, static_cast<hipStream_t>(stream), partials,
+                     n, tiles, c, hw, mode, training, drop_scale, gamma, beta, eps, momentum, running_mean, running_var,
+                     num_batches, xa, xb, scale, shift);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------- stand-alone statistics (no conv epilogue available)
+// partial sums over a pixel slab for every channel: part[n][s][c][2]
+template <typename T>
+__global__ void norm_stats_kernel(const T* __restrict__ y, int64_t hw, int c, int slabs, float* __restrict__ part) {
+  extern __shared__ float sh[];
+  const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  const int cw = blockDim.x >= c ? c : blockDim.x, rows_par = blockDim.x / cw;
+  const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+  const int64_t per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  const T* base = y + (size_t)n * hw * c;
+  for (int cb = blockIdx.y * cw; cb < c; cb += gridDim.y * cw) {
+    const int ch = cb + tc;
+    float s1 = 0.f, s2 = 0.f;
+    if (ch < c && tr < rows_par)
+      for (int64_t r = r0 + tr; r < r1; r += rows_par) { const float v = Elem<T>::ld(base + r * c + ch); s1 += v; s2 += v * v; }
+    sh[threadIdx.x] = s1; sh[blockDim.x + threadIdx.x] = s2;
+    __syncthreads();
+    if (tr == 0 && ch < c) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int j = 0; j < rows_par; ++j) { t1 += sh[j * cw + tc]; t2 += sh[blockDim.x + j * cw + tc]; }
+      float* dst = part + (((size_t)n * slabs + s) * c + ch) * 2;
+      dst[0] = t1; dst[1] = t2;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int mia_norm_stats(const void* y, int dtype, int n, int64_t hw, int c, int slabs, float* partials, void* stream) {
+  MIA_CHECK_ARG(y && partials && n > 0 && hw > 0 && c > 0 && slabs > 0, "mia_norm_stats: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == MIA_BF16)
+    hipLaunchKernelGGL(norm_stats_kernel<bf16_t>, dim3(n * slabs, ceil_div(c, 256)), dim3(256), 512 * sizeof(float), st, static_cast<const bf16_t*>(y), hw, c, slabs, partials);
+  else if (dtype == MIA_F32)
+    hipLaunchKernelGGL(norm_stats_kernel<float>, dim3(n * slabs, ceil_div(c, 256)), dim3(256), 512 * sizeof(float), st, static_cast<const float*>(y), hw, c, slabs, partials);
+  else { mia_set_error("mia_norm_stats: bad dtype"); return MIA_EARG; }
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------- forward apply: z = lrelu(scale*y + shift)
+template <typename T, bool VEC>
+__global__ void norm_act_fwd_kernel(const T* __restrict__ y, T* __restrict__ z, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, int64_t hw, int c, int64_t total_units, float slope) {
+  constexpr int EPU = VEC ? Elem<T>::EPU : 1;
+  const int upp = c / EPU;  // units per pixel
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < total_units; u += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = u / upp;
+    const int ch = (int)(u - pix * upp) * EPU;
+    const int n = (int)(pix / hw);
+    const float* sc = scale + (size_t)n * c + ch;
+    const float* sf = shift + (size_t)n * c + ch;
+    if constexpr (VEC) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(y + u * EPU);
+      alignas(16) T in[EPU]; alignas(16) T out[EPU];
+      *reinterpret_cast<u32x4*>(in) = raw;
+#pragma unroll
+      for (int e = 0; e < EPU; ++e) {
+        const float v = sc[e] * Elem<T>::ld(in + e) + sf[e];
+        out[e] = Elem<T>::cvt(v > 0.f ? v : v * slope);
+      }
+      *reinterpret_cast<u32x4*>(z + u * EPU) = *reinterpret_cast<const u32x4*>(out);
+    } else {
+      const float v = sc[0] * Elem<T>::ld(y + u) + sf[0];
+      Elem<T>::st(z + u, v > 0.f ? v : v * slope);
+    }
+  }
+}
+
+extern "C" int mia_norm_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift, int n, int64_t hw,
+                                int c, float slope, void* stream) {
+  MIA_CHECK_ARG(y && z && scale && shift && n > 0 && hw > 0 && c > 0, "mia_norm_act_fwd: bad arguments");
+  const int epu = dtype == MIA_BF16 ? 8 : 4;
+  const bool vec = (c % epu == 0) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(z)) & 15) == 0;
+  const int64_t units = (int64_t)n * hw * (vec ? c / epu : c);
+  const int blocks = (int)((units + 255) / 256 < 16384 ? (units + 255) / 256 : 16384);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define NA(T, V) hipLaunchKernelGGL((norm_act_fwd_kernel<T, V>), dim3(blocks), dim3(256), 0, st, static_cast<const T*>(y), \
+                                    static_cast<T*>(z), scale, shift, hw, c, units, slope)
+  if (dtype == MIA_BF16) { if (vec) NA(bf16_t, true); else NA(bf16_t, false); }
+  else if (dtype == MIA_F32) { if (vec) NA(float, true); else NA(float, false); }
+  else { mia_set_error("mia_norm_act_fwd: bad dtype"); return MIA_EARG; }
+#undef NA
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------- backward pass 1: per-(n, slab, c) sums of g and g*xhat
+template <typename T>
+__global__ void norm_act_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, const float* __restrict__ xa,
+                                           const float* __restrict__ xb, int64_t hw, int c, int slabs, float slope,
+                                           float* __restrict__ part) {
+  extern __shared__ float sh[];
+  const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  const int cw = blockDim.x >= c ? c : blockDim.x, rows_par = blockDim.x / cw;
+  const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+  const int64_t per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  const size_t base = (size_t)n * hw * c;
+  for (int cb = blockIdx.y * cw; cb < c; cb += gridDim.y * cw) {
+    const int ch = cb + tc;
+    float s1 = 0.f, s2 = 0.f;
+    if (ch < c && tr < rows_par) {
+      const float sc = scale[(size_t)n * c + ch], sf = shift[(size_t)n * c + ch];
+      const float a = xa[(size_t)n * c + ch], b = xb[(size_t)n * c + ch];
+      for (int64_t r = r0 + tr; r < r1; r += rows_par) {
+        const float yv = Elem<T>::ld(y + base + r * c + ch);
+        float g = Elem<T>::ld(dz + base + r * c + ch);
+        if (!(sc * yv + sf > 0.f)) g *= slope;
+        s1 += g; s2 += g * (a * yv + b);
+      }
+    }
+    sh[threadIdx.x] = s1; sh[blockDim.x + threadIdx.x] = s2;
+    __syncthreads();
+    if (tr == 0 && ch < c) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int j = 0; j < rows_par; ++j) { t1 += sh[j * cw + tc]; t2 += sh[blockDim.x + j * cw + tc]; }
+      float* dst = part + (((size_t)n * slabs + s) * c + ch) * 2;
+      dst[0] = t1; dst[1] = t2;
+    }
+    __syncthreads();
+  }
+}
+
+// pass 1b: combine partials -> per-(n,c) group means c1 = mean(g), c2 = mean(g*xhat); dgamma, dbeta
+__global__ void norm_bwd_finalize_kernel(const float* __restrict__ part, int n_img, int slabs, int c, int64_t hw, int mode,
+                                         int fixed_stats, float* __restrict__ c1, float* __restrict__ c2,
+                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double tg = 0.0, tgx = 0.0;
+  for (int n = 0; n < n_img; ++n) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < slabs; ++s) {
+      const float* p = part + (((size_t)n * slabs + s) * c + ch) * 2;
+      s1 += p[0]; s2 += p[1];
+    }
+    tg += s1; tgx += s2;
+    if (mode == NORM_INSTANCE) {
+      c1[n * c + ch] = fixed_stats ? 0.f : (float)(s1 / (double)hw);
+      c2[n * c + ch] = fixed_stats ? 0.f : (float)(s2 / (double)hw);
+    }
+  }
+  if (mode == NORM_BATCH) {
+    const double cnt = (double)n_img * (double)hw;
+    for (int n = 0; n < n_img; ++n) {
+      c1[n * c + ch] = fixed_stats ? 0.f : (float)(tg / cnt);
+      c2[n * c + ch] = fixed_stats ? 0.f : (float)(tgx / cnt);
+    }
+  }
+  dgamma[ch] = accumulate ? dgamma[ch] + (float)tgx : (float)tgx;
+  dbeta[ch] = accumulate ? dbeta[ch] + (float)tg : (float)tg;
+}
+
+// pass 2: dy = xa*gamma*(g - c1 - xhat*c2)
+template <typename T, bool VEC>
+__global__ void norm_act_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, T* __restrict__ dy,
+                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                          const float* __restrict__ xa, const float* __restrict__ xb,
+                                          const float* __restrict__ c1, const float* __restrict__ c2, int64_t hw, int c,
+                                          int64_t total_units, float slope) {
+  constexpr int EPU = VEC ? Elem<T>::EPU : 1;
+  const int upp = c / EPU;
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < total_units; u += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = u / upp;
+    const int ch = (int)(u - pix * upp) * EPU;
+    const size_t o = (size_t)(pix / hw) * c + ch;
+    alignas(16) T gin[EPU]; alignas(16) T yin[EPU]; alignas(16) T out[EPU];
+    if constexpr (VEC) {
+      *reinterpret_cast<u32x4*>(gin) = *reinterpret_cast<const u32x4*>(dz + u * EPU);
+      *reinterpret_cast<u32x4*>(yin) = *reinterpret_cast<const u32x4*>(y + u * EPU);
+    } else { gin[0] = dz[u]; yin[0] = y[u]; }
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) {
+      const float yv = Elem<T>::ld(yin + e);
+      float g = Elem<T>::ld(gin + e);
+      if (!(scale[o + e] * yv + shift[o + e] > 0.f)) g *= slope;
+      const float xh = xa[o + e] * yv + xb[o + e];
+      // scale = gamma*xa
+      out[e] = Elem<T>::cvt(scale[o + e] * (g - c1[o + e] - xh * c2[o + e]));
+    }
+    if constexpr (VEC) *reinterpret_cast<u32x4*>(dy + u * EPU) = *reinterpret_cast<const u32x4*>(out);
+    else dy[u] = out[0];
+  }
+}
+
+extern "C" int mia_norm_act_bwd(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
+                                const float* xa, const float* xb, int n, int64_t hw, int c, int mode, int fixed_stats,
+                                float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta,
+                                int accumulate, void* stream) {
+  MIA_CHECK_ARG(dz && y && dy && scale && shift && xa && xb && partials && c1 && c2 && dgamma && dbeta,
+                "mia_norm_act_bwd: null pointer");
+  MIA_CHECK_ARG(n > 0 && hw > 0 && c > 0 && slabs > 0, "mia_norm_act_bwd: bad shape");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int epu = dtype == MIA_BF16 ? 8 : 4;
+  const bool vec = (c % epu == 0) &&
+                   ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+  const int64_t units = (int64_t)n * hw * (vec ? c / epu : c);
+  const int blocks = (int)((units + 255) / 256 < 16384 ? (units + 255) / 256 : 16384);
+#define RD(T) hipLaunchKernelGGL(norm_act_bwd_reduce_kernel<T>, dim3(n * slabs, ceil_div(c, 256)), dim3(256), 512 * sizeof(float), st,   \
+                                 static_cast<const T*>(dz), static_cast<const T*>(y), scale, shift, xa, xb, hw, c, slabs, \
+                                 slope, partials)
+#define AP(T, V) hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, V>), dim3(blocks), dim3(256), 0, st,                   \
+                                    static_cast<const T*>(dz), static_cast<const T*>(y), static_cast<T*>(dy), scale, shift, \
+                                    xa, xb, c1, c2, hw, c, units, slope)
+  if (dtype == MIA_BF16) RD(bf16_t); else if (dtype == MIA_F32) RD(float);
+  else { mia_set_error("mia_norm_act_bwd: bad dtype"); return MIA_EARG; }
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, st, partials, n, slabs, c, hw, mode,
+                     fixed_stats, c1, c2, dgamma, dbeta, accumulate);
+  if (dtype == MIA_BF16) { if (vec) AP(bf16_t, true); else AP(bf16_t, false); }
+  else { if (vec) AP(float, true); else AP(float, false); }
+#undef RD
+#undef AP
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}

@@ -1,0 +1,26 @@
+"""Cross-entropy on the fused HIP Dice/CE kernel (reference `src/losses/ce_loss.py:6-16`)."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from mia_hip import ops
+
+
+class RobustCrossEntropyLoss(nn.CrossEntropyLoss):
+    """Accepts a [B,1,H,W] (possibly float) target like the reference; mean over all pixels.
+    Class weights / ignore_index / label smoothing are not on the al_train path and are rejected."""
+
+    def forward(self, input: Tensor, target: Tensor) -> Tensor:
+        if target.ndim == input.ndim:
+            assert target.shape[1] == 1
+            target = target[:, 0]
+        return hip_cross_entropy(self, input, target.long())
+
+
+def hip_cross_entropy(module, input: Tensor, target: Tensor) -> Tensor:
+    if getattr(module, "weight", None) is not None or getattr(module, "label_smoothing", 0.0) != 0.0 or \
+            getattr(module, "reduction", "mean") != "mean":
+        raise NotImplementedError("HIP cross-entropy implements the al_train configuration: no class weights, "
+                                  "no label smoothing, reduction='mean'")
+    return ops.DiceCEFn.apply(input, target, ops.loss_flags(True, True, False, False), 1e-5, 0.0, 1.0, 0)

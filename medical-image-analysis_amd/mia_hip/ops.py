@@ -1,0 +1,436 @@
+"""Tensor-level wrappers + autograd glue over libmia_hip.so.
+
+PyTorch-ROCm is used only as a container (device memory, streams, autograd graph); every FLOP and
+every byte moved on the hot path goes through the HIP kernels behind ``include/mia_hip.h``.
+Activations are plain contiguous NHWC tensors ``[N, H, W, C]`` in fp32 or bf16.  There is no CPU
+fallback: tensors must live on a HIP device and the shared object must be built.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import (BF16, CONV_G1, CONV_G2S2, CONV_G3S1, CONV_G3S2, CONV_T2S2, CONV_T3S2, F32, LOSS_BATCH, LOSS_DO_BG,
+               LOSS_SOFTMAX, LOSS_SQUARED, NORM_BATCH, NORM_INSTANCE, WGRAD_2S2, WGRAD_3S1, WGRAD_3S2, MiaError, call, lib)
+
+LRELU_SLOPE = 0.01
+_c_int, _c_float, _c_i64 = ctypes.c_int, ctypes.c_float, ctypes.c_int64
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if d == torch.float32:
+        return F32
+    if d == torch.bfloat16:
+        return BF16
+    raise MiaError(f"unsupported activation dtype {d} (fp32 or bf16)")
+
+
+def _need_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise MiaError("libmia_hip operates on HIP device tensors only (no CPU fallback); got a CPU tensor")
+
+
+def _pad(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def _kb(dtype: int) -> int:
+    return 32 if dtype == BF16 else 16
+
+
+# ------------------------------------------------------------------ weight packing (cached per parameter version)
+class PackCache:
+    """Packed copies of one fp32 parameter, invalidated by the tensor's version counter."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, w: torch.Tensor, dtype: int, n_from_d0: bool, kpad_mult: Optional[int] = None) -> Tuple[torch.Tensor, int, int]:
+        key = (dtype, n_from_d0)
+        ver = (w._version, w.data_ptr())
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1], hit[2], hit[3]
+        d0, d1 = w.shape[0], w.shape[1]
+        taps = w.shape[2] * w.shape[3]
+        nn, kk = (d0, d1) if n_from_d0 else (d1, d0)
+        npad, kpad = _pad(nn, 64), _pad(kk, _kb(dtype))
+        buf = torch.empty((taps, npad, kpad), device=w.device, dtype=torch.bfloat16 if dtype == BF16 else torch.float32)
+        wc = w.detach()
+        if not wc.is_contiguous():
+            wc = wc.contiguous()
+        call("mia_pack_weight", _p(wc), _p(buf), dtype, d0, d1, taps, npad, kpad, int(n_from_d0), _stream())
+        self._store[key] = (ver, buf, npad, kpad)
+        return buf, npad, kpad
+
+
+_caches = {}
+
+
+def pack_cache(w: torch.Tensor) -> PackCache:
+    c = _caches.get(id(w))
+    if c is None or c[0]() is not w:
+        import weakref
+        pc = PackCache()
+        _caches[id(w)] = (weakref.ref(w, lambda _r, k=id(w): _caches.pop(k, None)), pc)
+        return pc
+    return c[1]
+
+
+# ------------------------------------------------------------------ layout helpers
+def to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Logical NCHW tensor (any dense strides) -> contiguous NHWC tensor in `dtype` (HIP relayout kernel)."""
+    _need_dev(x)
+    n, c, h, w = x.shape
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    sn, sc, sh, sw = x.stride()
+    if x.dtype == dtype:
+        if c == 1 and sw == 1 and (h == 1 or sh == w) and (n == 1 or sn == h * w):
+            return x.reshape(n, h, w, 1)  # NCHW with C=1 is already NHWC
+        if sc == 1 and sw == c and (h == 1 or sh == w * c) and (n == 1 or sn == h * w * c):
+            return x.permute(0, 2, 3, 1)  # channels_last storage: zero-copy
+    if h > 1 and sh != w * sw:
+        x = x.contiguous()
+        sn, sc, sh, sw = x.stride()
+    out = torch.empty((n, h, w, c), device=x.device, dtype=dtype)
+    call("mia_relayout", _p(x), _dt(x), _p(out), _dt(out), n, c, _c_i64(h * w), _c_i64(sn), _c_i64(sc), _c_i64(sw),
+         _c_i64(h * w * c), _c_i64(1), _c_i64(c), _stream())
+    return out
+
+
+def nhwc_as_nchw(x: torch.Tensor) -> torch.Tensor:
+    """Zero-copy logical-NCHW view (channels_last strides) of a contiguous NHWC tensor."""
+    return x.permute(0, 3, 1, 2)
+
+
+def cast_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if x.dtype == dtype:
+        return x
+    n, h, w, c = x.shape
+    out = torch.empty_like(x, dtype=dtype)
+    call("mia_relayout", _p(x), _dt(x), _p(out), _dt(out), n, c, _c_i64(h * w), _c_i64(h * w * c), _c_i64(1), _c_i64(c),
+         _c_i64(h * w * c), _c_i64(1), _c_i64(c), _stream())
+    return out
+
+
+# ------------------------------------------------------------------ raw op wrappers
+def conv_tiles(mode: int, hout: int, wout: int) -> int:
+    ty, tx, th = _c_int(), _c_int(), _c_int()
+    call("mia_conv_mma_tiles", mode, hout, wout, ctypes.byref(ty), ctypes.byref(tx), ctypes.byref(th))
+    return ty.value * tx.value
+
+
+def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: torch.Tensor, npad: int, kpad: int,
+             flip: bool, bias: Optional[torch.Tensor], nout: int, out_hw: Tuple[int, int], want_stats: bool = False,
+             out_split: Optional[int] = None):
+    n, hin, win, c1 = x1.shape
+    c2 = 0 if x2 is None else x2.shape[3]
+    hout, wout = out_hw
+    if out_split is None:
+        out1 = torch.empty((n, hout, wout, nout), device=x1.device, dtype=x1.dtype)
+        out2, o1, o2 = None, nout, 0
+    else:
+        o1, o2 = out_split, nout - out_split
+        out1 = torch.empty((n, hout, wout, o1), device=x1.device, dtype=x1.dtype)
+        out2 = torch.empty((n, hout, wout, o2), device=x1.device, dtype=x1.dtype)
+    stats = None
+    if want_stats:
+        stats = torch.empty((n, conv_tiles(mode, hout, wout), nout, 2), device=x1.device, dtype=torch.float32)
+    call("mia_conv_mma", mode, _dt(x1), _p(x1), c1, _p(x2), c2, _p(wpack), npad, kpad, int(flip), _p(bias), _p(out1), o1,
+         _p(out2), o2, _p(stats), n, hin, win, hout, wout, _stream())
+    return out1, out2, stats
+
+
+def conv_wgrad(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], dy: torch.Tensor, grad_shape, nn: int, kk: int) -> torch.Tensor:
+    """Weight gradient in the parameter's native layout (fp32)."""
+    n, hx, wx, c1 = x1.shape
+    c2 = 0 if x2 is None else x2.shape[3]
+    _, hy, wy, cdy = dy.shape
+    dtype = _dt(x1)
+    taps = 4 if mode == WGRAD_2S2 else 9
+    npad, kpad = _pad(nn, 64), _pad(kk, 64)
+    ty, tx = _c_int(), _c_int()
+    call("mia_wgrad_geometry", mode, dtype, hy, wy, ctypes.byref(ty), ctypes.byref(tx))
+    ntiles = n * ty.value * tx.value
+    base = (npad // 64) * (kpad // 64)
+    ksplit = max(1, min(ntiles, -(-512 // base), 1024))
+    slabs = torch.empty((ksplit, taps, npad, kpad), device=x1.device, dtype=torch.float32)
+    call("mia_conv_wgrad", mode, dtype, _p(x1), c1, _p(x2), c2, _p(dy), cdy, _p(slabs), ksplit, npad, kpad, n, hx, wx, hy,
+         wy, _stream())
+    grad = torch.empty(grad_shape, device=x1.device, dtype=torch.float32)
+    call("mia_wgrad_reduce", _p(slabs), ksplit, taps, npad, kpad, _p(grad), nn, kk, 0, _stream())
+    return grad
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    c = x.shape[-1]
+    p = x.numel() // c
+    ws = torch.empty(lib().mia_colsum_workspace(_c_i64(p), c), device=x.device, dtype=torch.float32)
+    out = torch.empty(c, device=x.device, dtype=torch.float32)
+    call("mia_colsum", _p(x), _dt(x), _c_i64(p), c, _p(ws), _p(out), 0, _stream())
+    return out
+
+
+def _slabs_for(hw: int) -> int:
+    return max(1, min(64, hw // 1024))
+
+
+# ------------------------------------------------------------------ PlainBlock: conv3x3 -> dropout2d -> norm -> lrelu
+class NormCfg:
+    __slots__ = ("mode", "training", "eps", "momentum", "running_mean", "running_var", "num_batches", "drop_scale")
+
+    def __init__(self, mode, training, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, num_batches=None,
+                 drop_scale=None):
+        self.mode, self.training, self.eps, self.momentum = mode, training, eps, momentum
+        self.running_mean, self.running_var, self.num_batches, self.drop_scale = running_mean, running_var, num_batches, drop_scale
+
+
+class PlainBlockFn(torch.autograd.Function):
+    """Fused reference PlainBlock (src/models/unet/blocks.py:66-105) on NHWC tensors.
+
+    inputs x1 [N,H,W,C1] (+ optional x2 [N,H,W,C2], concatenated along C: unet.py:213)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, gamma, beta, stride: int, cfg: NormCfg):
+        _need_dev(x1, x2, weight)
+        x1 = x1.contiguous()
+        x2 = None if x2 is None else x2.contiguous()
+        if x2 is not None and (x2.shape[:3] != x1.shape[:3] or x2.dtype != x1.dtype):
+            # same failure point as torch.cat([skip, up], 1) in the reference (unet.py:213)
+            raise RuntimeError(f"Sizes of tensors must match except in dimension 1: {tuple(x1.shape)} vs {tuple(x2.shape)} (NHWC)")
+        dtype = _dt(x1)
+        n, h, w, c1 = x1.shape
+        cout = weight.shape[0]
+        if weight.shape[1] != c1 + (0 if x2 is None else x2.shape[3]):
+            raise RuntimeError(f"conv weight expects {weight.shape[1]} input channels, got {c1 + (0 if x2 is None else x2.shape[3])}")
+        ho, wo = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
+        wp, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=True)
+        mode = CONV_G3S2 if stride == 2 else CONV_G3S1
+        y, _, stats = conv_mma(mode, x1, x2, wp, npad, kpad, False, bias.detach().float(), cout, (ho, wo), want_stats=True)
+        dev = x1.device
+        coefs = torch.empty((4, n, cout), device=dev, dtype=torch.float32)  # xa, xb, scale, shift
+        fixed = cfg.mode == NORM_BATCH and not cfg.training
+        call("mia_norm_finalize", _p(stats), n, stats.shape[1], cout, _c_i64(ho * wo), cfg.mode, int(cfg.training),
+             _p(cfg.drop_scale), _p(gamma.detach()), _p(beta.detach()), _c_float(cfg.eps), _c_float(cfg.momentum),
+             _p(cfg.running_mean), _p(cfg.running_var), _p(cfg.num_batches), _p(coefs[0]), _p(coefs[1]), _p(coefs[2]),
+             _p(coefs[3]), _stream())
+        z = torch.empty_like(y)
+        call("mia_norm_act_fwd", _p(y), _p(z), dtype, _p(coefs[2]), _p(coefs[3]), n, _c_i64(ho * wo), cout,
+             _c_float(LRELU_SLOPE), _stream())
+        ctx.save_for_backward(x1, x2, y, coefs, weight, gamma)
+        ctx.stride, ctx.mode, ctx.fixed = stride, cfg.mode, fixed
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x1, x2, y, coefs, weight, gamma = ctx.saved_tensors
+        dz = dz.contiguous()
+        dtype = _dt(y)
+        n, ho, wo, cout = y.shape
+        dev = y.device
+        hw = ho * wo
+        slabs = _slabs_for(hw)
+        part = torch.empty((n, slabs, cout, 2), device=dev, dtype=torch.float32)
+        cc = torch.empty((2, n, cout), device=dev, dtype=torch.float32)
+        dgamma = torch.empty(cout, device=dev, dtype=torch.float32)
+        dbeta = torch.empty(cout, device=dev, dtype=torch.float32)
+        dy = torch.empty_like(y)
+        call("mia_norm_act_bwd", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]), n,
+             _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(LRELU_SLOPE), slabs, _p(part), _p(cc[0]), _p(cc[1]),
+             _p(dgamma), _p(dbeta), 0, _stream())
+        dbias = colsum(dy)
+        cin = weight.shape[1]
+        wmode = WGRAD_3S2 if ctx.stride == 2 else WGRAD_3S1
+        dw = conv_wgrad(wmode, x1, x2, dy, weight.shape, cout, cin)
+        dx1 = dx2 = None
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
+            wb, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=False)
+            c1 = x1.shape[3]
+            split = c1 if x2 is not None else None
+            if ctx.stride == 2:
+                dx1, dx2, _ = conv_mma(CONV_T3S2, dy, None, wb, npad, kpad, False, None, cin, (x1.shape[1], x1.shape[2]),
+                                       out_split=split)
+            else:
+                dx1, dx2, _ = conv_mma(CONV_G3S1, dy, None, wb, npad, kpad, True, None, cin, (ho, wo), out_split=split)
+        return dx1, dx2, dw, dbias, dgamma, dbeta, None, None
+
+
+# ------------------------------------------------------------------ ConvTranspose2d(k=2, s=2)
+class ConvTranspose2x2Fn(torch.autograd.Function):
+    """nn.ConvTranspose2d(cin, cout, 2, 2) (src/models/unet/unet.py:142) as a pointwise MFMA GEMM + pixel shuffle."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_dev(x, weight)
+        x = x.contiguous()
+        dtype = _dt(x)
+        n, h, w, cin = x.shape
+        cout = weight.shape[1]
+        wp, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=False)  # [tap][co][ci]
+        out, _, _ = conv_mma(CONV_T2S2, x, None, wp, npad, kpad, False, bias.detach().float(), cout, (2 * h, 2 * w))
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight = ctx.saved_tensors
+        dout = dout.contiguous()
+        dtype = _dt(x)
+        n, h, w, cin = x.shape
+        cout = weight.shape[1]
+        dbias = colsum(dout)
+        dw = conv_wgrad(WGRAD_2S2, dout, None, x, weight.shape, cin, cout)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wb, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=True)  # [tap][ci][co]
+            dx, _, _ = conv_mma(CONV_G2S2, dout, None, wb, npad, kpad, False, None, cin, (h, w))
+        return dx, dw, dbias
+
+
+# ------------------------------------------------------------------ 1x1 head
+def _pix_strides(t: torch.Tensor):
+    """(sn, sk, sp) element strides of a logical [B,K,H,W] tensor whose H,W dims collapse, else None."""
+    b, k, h, w = t.shape
+    sn, sk, sh, sw = t.stride()
+    if h == 1 or sh == w * sw:
+        return sn, sk, sw
+    return None
+
+
+class HeadFn(torch.autograd.Function):
+    """seg_output = Conv2d(c0, K1, 1) (src/models/unet/unet.py:176): NHWC activations -> fp32 logits
+    returned as a logical-NCHW view with channels_last strides."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_dev(x, weight)
+        x = x.contiguous()
+        n, h, w, c0 = x.shape
+        k1 = weight.shape[0]
+        w2 = weight.detach().reshape(k1, c0).contiguous()
+        logits = torch.empty((n, h, w, k1), device=x.device, dtype=torch.float32)
+        call("mia_head_fwd", _p(x), _dt(x), _p(w2), _p(bias.detach()), _p(logits), n, _c_i64(h * w), c0, k1,
+             _c_i64(h * w * k1), _c_i64(1), _c_i64(k1), _stream())
+        ctx.save_for_backward(x, weight)
+        return logits.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dl):
+        x, weight = ctx.saved_tensors
+        n, h, w, c0 = x.shape
+        k1 = weight.shape[0]
+        if dl.dtype != torch.float32:
+            dl = dl.float()
+        st = _pix_strides(dl)
+        if st is None:
+            dl = dl.contiguous()
+            st = _pix_strides(dl)
+        w2 = weight.detach().reshape(k1, c0).contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty((k1, c0), device=x.device, dtype=torch.float32)
+        db = torch.empty(k1, device=x.device, dtype=torch.float32)
+        ws = torch.empty(lib().mia_head_bwd_workspace(c0, k1), device=x.device, dtype=torch.float32)
+        call("mia_head_bwd", _p(dl), _p(x), _dt(x), _p(w2), _p(dx), _p(dw), _p(db), _p(ws), n, _c_i64(h * w), c0, k1,
+             _c_i64(st[0]), _c_i64(st[1]), _c_i64(st[2]), 0, _stream())
+        return dx, dw.reshape(weight.shape), db
+
+
+# ------------------------------------------------------------------ Dice + CE
+def loss_flags(softmax: bool, do_bg: bool, batch: bool, squared: bool) -> int:
+    return (LOSS_SOFTMAX if softmax else 0) | (LOSS_DO_BG if do_bg else 0) | (LOSS_BATCH if batch else 0) | \
+        (LOSS_SQUARED if squared else 0)
+
+
+class DiceCEFn(torch.autograd.Function):
+    """dice_w * DiceLoss + ce_w * CrossEntropy in one pass over the logits
+    (src/losses/dice_loss.py:32-76, src/losses/compound_losses.py:33-49)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, flags: int, smooth: float, dice_w: float, ce_w: float, which: int):
+        _need_dev(logits, labels)
+        if logits.dtype != torch.float32:
+            logits = logits.float()
+        st = _pix_strides(logits)
+        if st is None:
+            logits = logits.contiguous()
+            st = _pix_strides(logits)
+        b, k1, h, w = logits.shape
+        labels = labels.reshape(b, h, w)
+        if labels.dtype != torch.long:
+            labels = labels.long()
+        labels = labels.contiguous()
+        hw = h * w
+        slabs = max(1, min(256, hw // 2048))
+        dev = logits.device
+        ws = torch.empty(lib().mia_dice_ce_workspace(b, k1, slabs), device=dev, dtype=torch.float32)
+        sums = torch.empty((b, k1, 3), device=dev, dtype=torch.float32)
+        coef = torch.zeros((b, k1, 2), device=dev, dtype=torch.float32)
+        out = torch.empty(3, device=dev, dtype=torch.float32)
+        bad = torch.zeros(1, device=dev, dtype=torch.int32)
+        call("mia_dice_ce_fwd", _p(logits), _p(labels), b, _c_i64(hw), k1, _c_i64(st[0]), _c_i64(st[1]), _c_i64(st[2]), flags,
+             _c_float(smooth), _c_float(dice_w), _c_float(ce_w), slabs, _p(ws), _p(sums), _p(coef), _p(out), _p(bad), _stream())
+        ctx.save_for_backward(logits, labels, coef)
+        ctx.flags, ctx.dice_w, ctx.ce_w, ctx.st = flags, dice_w, ce_w, st
+        ctx.bad = bad
+        DiceCEFn.last_bad_label = bad
+        DiceCEFn.last_sums = sums
+        return out[which]
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, labels, coef = ctx.saved_tensors
+        b, k1, h, w = logits.shape
+        dl = torch.empty_like(logits)  # preserves (dense) strides
+        gst = _pix_strides(dl)
+        g = gout.reshape(1).float().contiguous()
+        st = ctx.st
+        call("mia_dice_ce_bwd", _p(logits), _p(labels), _p(coef), _p(g), _p(dl), b, _c_i64(h * w), k1, _c_i64(st[0]),
+             _c_i64(st[1]), _c_i64(st[2]), _c_i64(gst[0]), _c_i64(gst[1]), _c_i64(gst[2]), ctx.flags, _c_float(ctx.dice_w),
+             _c_float(ctx.ce_w), _stream())
+        return dl, None, None, None, None, None, None
+
+
+DiceCEFn.last_bad_label = None
+DiceCEFn.last_sums = None
+
+
+# ------------------------------------------------------------------ optimizer helpers
+def grad_norm(flat_grad: torch.Tensor, max_norm: float) -> torch.Tensor:
+    """out[0] = ||g||_2, out[1] = clip coefficient; stays on device (no sync)."""
+    ws = torch.empty(lib().mia_grad_norm_workspace(), device=flat_grad.device, dtype=torch.float32)
+    out = torch.empty(2, device=flat_grad.device, dtype=torch.float32)
+    call("mia_grad_norm", _p(flat_grad), _c_i64(flat_grad.numel()), _c_float(max_norm), _p(ws), _p(out), _stream())
+    return out
+
+
+def optim_step(kind: int, param, grad, m, v, lr, beta1, beta2, eps, wd, step: int, clip: Optional[torch.Tensor],
+               grad_scale: float = 1.0):
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    call("mia_optim_step", _p(param), _p(grad), _p(m), _p(v), _c_i64(param.numel()), kind, _c_float(lr), _c_float(beta1),
+         _c_float(beta2), _c_float(eps), _c_float(wd), _c_float(bc1), _c_float(bc2), int(step == 1), _p(clip),
+         _c_float(grad_scale), _stream())
+
+
+def global_avg_pool(x_nhwc: torch.Tensor) -> torch.Tensor:
+    """[N,H,W,C] -> [N,C] fp32 mean over H,W (adaptive_avg_pool2d(.,1).view(B,-1); reference unet.py:87-91)."""
+    _need_dev(x_nhwc)
+    x = x_nhwc.contiguous()
+    n, h, w, c = x.shape
+    part = torch.empty((n, 1, c, 2), device=x.device, dtype=torch.float32)
+    call("mia_norm_stats", _p(x), _dt(x), n, _c_i64(h * w), c, 1, _p(part), _stream())
+    return part[:, 0, :, 0] / float(h * w)

@@ -1,0 +1,116 @@
+"""Conv blocks of the UNet, MI355X-native.
+
+Same classes / constructor arguments / ``state_dict`` keys as the reference
+(`src/models/unet/blocks.py:66-164`): ``self.all = Sequential(conv, dropout, norm, nonlin)`` holds
+ordinary torch parameter containers (so default init consumes the RNG exactly like the reference and
+checkpoints interchange), but ``forward`` never calls them: the whole block runs as the fused HIP
+sequence conv3x3(MFMA, +stats epilogue) -> finalize -> normalise+LeakyReLU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from mia_hip import NORM_BATCH, NORM_INSTANCE, ops
+
+norm_dict = {"instance": {2: nn.InstanceNorm2d}, "batch": {2: nn.BatchNorm2d}}
+conv_dict = {2: nn.Conv2d}
+dropout_dict = {2: nn.Dropout2d}
+_NORM_MODE = {"instance": NORM_INSTANCE, "batch": NORM_BATCH}
+
+
+def _only_2d(dimension):
+    if dimension != 2:
+        raise NotImplementedError("the MI355X path implements dimension=2 only (the al_train hot path); got %r" % (dimension,))
+
+
+class Identity(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+
+    def forward(self, input):
+        return input
+
+
+class Normalize(nn.Module):
+    def __init__(self, p=2, dim=1):
+        super().__init__()
+        self.p, self.dim = p, dim
+
+    def forward(self, x):
+        return F.normalize(x, p=self.p, dim=self.dim)
+
+
+class Upsample(nn.Module):
+    """reference blocks.py:45-63; bilinear, align_corners=False -> HIP resize kernel."""
+
+    def __init__(self, size=None, scale_factor=None, mode="nearest", align_corners=False):
+        super().__init__()
+        self.align_corners, self.mode, self.scale_factor, self.size = align_corners, mode, scale_factor, size
+
+    def forward(self, x):
+        from transforms import functional_hip as FH
+        n, c, h, w = x.shape
+        if self.size is not None:
+            oh, ow = (self.size, self.size) if isinstance(self.size, int) else self.size
+        else:
+            oh, ow = int(h * self.scale_factor), int(w * self.scale_factor)
+        if self.mode == "bilinear" and not self.align_corners:
+            return FH.ResizeBilinearFn.apply(x, oh, ow)
+        if self.mode == "nearest":
+            return FH.resize_nearest(x, oh, ow)
+        raise NotImplementedError(f"Upsample mode {self.mode!r} align_corners={self.align_corners}")
+
+
+class PlainBlock(nn.Module):
+    def __init__(self, dimension, input_channels, output_channels, stride=1, kernel_size=3, normalization="instance",
+                 dropout_prob=None):
+        super().__init__()
+        _only_2d(dimension)
+        if kernel_size != 3:
+            raise NotImplementedError("MI355X PlainBlock implements kernel_size=3 (the only value the reference uses)")
+        if stride not in (1, 2):
+            raise NotImplementedError("stride must be 1 or 2")
+        conv = conv_dict[dimension](input_channels, output_channels, kernel_size, stride=stride,
+                                    padding=(kernel_size - 1) // 2, bias=True)
+        do = Identity() if dropout_prob is None else dropout_dict[dimension](p=dropout_prob, inplace=True)
+        norm = norm_dict[normalization][dimension](output_channels, eps=1e-5, affine=True)
+        nonlin = nn.LeakyReLU(inplace=True)
+        self.all = nn.Sequential(conv, do, norm, nonlin)
+        self.stride = stride
+        self.normalization = normalization
+        self.dropout_prob = dropout_prob
+        self.drop_mask_override = None  # [N, Cout] tensor of {0, 1/(1-p)} for parity runs
+
+    def _cfg(self, n: int, device) -> ops.NormCfg:
+        norm = self.all[2]
+        drop = None
+        if self.drop_mask_override is not None:
+            drop = self.drop_mask_override.to(device=device, dtype=torch.float32).contiguous()
+        elif self.dropout_prob is not None and self.training and self.dropout_prob > 0:
+            keep = 1.0 - float(self.dropout_prob)
+            drop = torch.empty((n, norm.num_features), device=device, dtype=torch.float32).bernoulli_(keep).div_(keep)
+        if self.normalization == "batch":
+            return ops.NormCfg(NORM_BATCH, self.training, norm.eps, norm.momentum, norm.running_mean, norm.running_var,
+                               norm.num_batches_tracked, drop)
+        return ops.NormCfg(NORM_INSTANCE, self.training, norm.eps, 0.1, None, None, None, drop)
+
+    def forward_nhwc(self, x1, x2=None):
+        conv, norm = self.all[0], self.all[2]
+        return ops.PlainBlockFn.apply(x1, x2, conv.weight, conv.bias, norm.weight, norm.bias, self.stride,
+                                      self._cfg(x1.shape[0], x1.device))
+
+    def forward(self, x):
+        dt = x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        return ops.nhwc_as_nchw(self.forward_nhwc(ops.to_nhwc(x, dt)))
+
+
+class ResidualBlock(nn.Module):
+    """reference blocks.py:108-164.  Unreachable from ``al_train`` (it passes ``normalization=`` where this
+    class takes ``norm_key=`` -> TypeError in the reference too); SURVEY.md section 8a row 2 ranks it last."""
+
+    def __init__(self, dimension, input_channels, output_channels, stride=1, kernel_size=3, norm_key="instance",
+                 dropout_prob=None):
+        super().__init__()
+        raise NotImplementedError("ResidualBlock is not built on the MI355X path yet (unreachable from al_train)")

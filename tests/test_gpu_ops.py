@@ -1,0 +1,288 @@
+"""Kernel-level parity: every libmia_hip entry point against torch-CPU fp32 math on the same seeded
+inputs (run on the GPU box: pytest -m gpu).  Calls go through the C ABI (ctypes)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def relerr(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+
+
+def nhwc(x, dtype, dev):  # NCHW cpu -> NHWC device
+    return x.permute(0, 2, 3, 1).contiguous().to(dev, dtype)
+
+
+def nchw(x):  # NHWC device -> NCHW cpu float
+    return x.float().cpu().permute(0, 3, 1, 2)
+
+
+def q(x, dtype):
+    """Quantise reference inputs to the kernel's storage dtype so only accumulation order differs."""
+    return x.to(dtype).float()
+
+
+CONV_CASES = [
+    # n, cin1, cin2, cout, h, w
+    (2, 16, 0, 16, 16, 16),
+    (1, 64, 0, 64, 32, 32),
+    (2, 8, 0, 24, 20, 28),
+    (2, 1, 0, 8, 16, 16),
+    (1, 32, 32, 32, 24, 16),
+    (1, 12, 20, 40, 9, 13),
+    (1, 128, 0, 80, 8, 8),
+    (3, 5, 0, 7, 7, 5),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_fwd_dgrad_wgrad(case, stride, dtype):
+    from mia_hip import ops, CONV_G3S1, CONV_G3S2, CONV_T3S2, WGRAD_3S1, WGRAD_3S2
+    dev = _dev()
+    n, c1, c2, cout, h, w = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + stride)
+    cin = c1 + c2
+    x = q(torch.randn(n, cin, h, w, generator=g), dtype)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
+    dy = q(torch.randn(n, cout, ho, wo, generator=g), dtype)
+    wq = q(wt, dtype)
+    xr = x.clone().requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b, stride=stride, padding=1)
+    yr.backward(dy)
+
+    x1 = nhwc(x[:, :c1], dtype, dev)
+    x2 = nhwc(x[:, c1:], dtype, dev) if c2 else None
+    wd = wt.to(dev)
+    pc = ops.PackCache()
+    wp, npad, kpad = pc.get(wd, ops._dt(dtype), True)
+    mode = CONV_G3S2 if stride == 2 else CONV_G3S1
+    y, _, stats = ops.conv_mma(mode, x1, x2, wp, npad, kpad, False, b.to(dev), cout, (ho, wo), want_stats=True)
+    torch.cuda.synchronize()
+    assert relerr(nchw(y), yr) < TOL[dtype]
+    # epilogue statistics: per-(n, c) sum and sum of squares
+    s = stats.sum(1).cpu()
+    assert relerr(s[..., 0], yr.detach().sum((2, 3))) < 1e-3 + TOL[dtype]
+    assert relerr(s[..., 1], (yr.detach() ** 2).sum((2, 3))) < 1e-3 + TOL[dtype]
+    # input gradient (two destinations when the input was two sources)
+    dyd = nhwc(dy, dtype, dev)
+    wb, npb, kpb = pc.get(wd, ops._dt(dtype), False)
+    split = c1 if c2 else None
+    if stride == 2:
+        dx1, dx2, _ = ops.conv_mma(CONV_T3S2, dyd, None, wb, npb, kpb, False, None, cin, (h, w), out_split=split)
+    else:
+        dx1, dx2, _ = ops.conv_mma(CONV_G3S1, dyd, None, wb, npb, kpb, True, None, cin, (h, w), out_split=split)
+    dx = nchw(dx1) if dx2 is None else torch.cat([nchw(dx1), nchw(dx2)], 1)
+    assert relerr(dx, xr.grad) < TOL[dtype]
+    # weight gradient
+    dw = ops.conv_wgrad(WGRAD_3S2 if stride == 2 else WGRAD_3S1, x1, x2, dyd, wt.shape, cout, cin)
+    assert relerr(dw, wr.grad) < TOL[dtype]
+    # bias gradient
+    assert relerr(ops.colsum(dyd), dy.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 32, 16, 8, 8), (1, 64, 32, 16, 16), (2, 20, 12, 5, 9), (1, 256, 128, 4, 4)])
+def test_conv_transpose2x2(case, dtype):
+    from mia_hip import ops
+    dev = _dev()
+    n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(5)
+    x = q(torch.randn(n, cin, h, w, generator=g), dtype)
+    wt = torch.randn(cin, cout, 2, 2, generator=g) / math.sqrt(cin)
+    b = torch.randn(cout, generator=g)
+    dy = q(torch.randn(n, cout, 2 * h, 2 * w, generator=g), dtype)
+    xr, wr = x.clone().requires_grad_(True), q(wt, dtype).clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, br, stride=2)
+    yr.backward(dy)
+    xd = nhwc(x, dtype, dev).requires_grad_(True)
+    wd = wt.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    y = ops.ConvTranspose2x2Fn.apply(xd, wd, bd)
+    y.backward(nhwc(dy, dtype, dev))
+    torch.cuda.synchronize()
+    assert relerr(nchw(y), yr) < TOL[dtype]
+    assert relerr(nchw(xd.grad), xr.grad) < TOL[dtype]
+    assert relerr(wd.grad, wr.grad) < TOL[dtype]
+    assert relerr(bd.grad, br.grad) < 1e-3 + TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+@pytest.mark.parametrize("stride,c2", [(1, 0), (2, 0), (1, 8)])
+def test_plain_block_fwd_bwd(norm, stride, c2, dtype):
+    """Fused block vs conv2d -> (dropout mask) -> instance/batch norm -> leaky_relu on CPU."""
+    from mia_hip import ops, NORM_BATCH, NORM_INSTANCE
+    dev = _dev()
+    n, c1, cout, h, w = 3, 8, 24, 20, 12
+    cin = c1 + c2
+    g = torch.Generator().manual_seed(17)
+    x = q(torch.randn(n, cin, h, w, generator=g), dtype)
+    wt = q(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9), dtype)
+    b = torch.randn(cout, generator=g) * 0.1
+    gamma = 1 + 0.2 * torch.randn(cout, generator=g)
+    beta = 0.2 * torch.randn(cout, generator=g)
+    keep = 0.75
+    drop = torch.bernoulli(torch.full((n, cout), keep), generator=g) / keep
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
+    dz = q(torch.randn(n, cout, ho, wo, generator=g), dtype)
+    leaves = [t.clone().requires_grad_(True) for t in (x, wt, b, gamma, beta)]
+    xr, wr, br, gr, ber = leaves
+    y = F.conv2d(xr, wr, br, stride=stride, padding=1) * drop[:, :, None, None]
+    rm, rv = torch.zeros(cout), torch.ones(cout)
+    if norm == "instance":
+        yn = F.instance_norm(y, None, None, gr, ber, True, 0.1, 1e-5)
+    else:
+        yn = F.batch_norm(y, rm, rv, gr, ber, True, 0.1, 1e-5)
+    zr = F.leaky_relu(yn, 0.01)
+    zr.backward(dz)
+
+    x1 = nhwc(x[:, :c1], dtype, dev).requires_grad_(True)
+    x2 = nhwc(x[:, c1:], dtype, dev).requires_grad_(True) if c2 else None
+    pd = [t.to(dev).requires_grad_(True) for t in (wt, b, gamma, beta)]
+    rmd, rvd, nbt = torch.zeros(cout, device=dev), torch.ones(cout, device=dev), torch.zeros((), dtype=torch.long, device=dev)
+    cfg = ops.NormCfg(NORM_BATCH if norm == "batch" else NORM_INSTANCE, True, 1e-5, 0.1,
+                      rmd if norm == "batch" else None, rvd if norm == "batch" else None, nbt if norm == "batch" else None,
+                      drop.to(dev))
+    z = ops.PlainBlockFn.apply(x1, x2, pd[0], pd[1], pd[2], pd[3], stride, cfg)
+    z.backward(nhwc(dz, dtype, dev))
+    torch.cuda.synchronize()
+    tol = TOL[dtype] * 2
+    assert relerr(nchw(z), zr) < tol
+    dx = nchw(x1.grad) if x2 is None else torch.cat([nchw(x1.grad), nchw(x2.grad)], 1)
+    assert relerr(dx, xr.grad) < tol * 2
+    assert relerr(pd[0].grad, wr.grad) < tol * 2
+    assert relerr(pd[2].grad, gr.grad) < tol * 2
+    assert relerr(pd[3].grad, ber.grad) < tol * 2
+    # conv bias in front of a norm layer: gradient is analytically 0
+    assert pd[1].grad.abs().max().item() < 1e-3 * max(1.0, dz.abs().max().item()) * (50 if dtype == torch.bfloat16 else 1)
+    if norm == "batch":
+        assert relerr(rmd, rm) < 1e-4 + TOL[dtype] and relerr(rvd, rv) < 1e-4 + TOL[dtype] and int(nbt.item()) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k1,c0", [(3, 16), (4, 64), (2, 12), (8, 32)])
+def test_head(k1, c0, dtype):
+    from mia_hip import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    n, h, w = 2, 12, 20
+    x = q(torch.randn(n, c0, h, w, generator=g), dtype)
+    wt = torch.randn(k1, c0, 1, 1, generator=g) / math.sqrt(c0)
+    b = torch.randn(k1, generator=g)
+    dl = torch.randn(n, k1, h, w, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (x, wt, b)]
+    yr = F.conv2d(*leaves)
+    yr.backward(dl)
+    xd = nhwc(x, dtype, dev).requires_grad_(True)
+    wd, bd = wt.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ops.HeadFn.apply(xd, wd, bd)
+    assert y.shape == (n, k1, h, w) and y.dtype == torch.float32
+    y.backward(dl.to(dev))  # NCHW-contiguous upstream gradient (stride path)
+    torch.cuda.synchronize()
+    assert relerr(y, yr) < 1e-5
+    assert relerr(nchw(xd.grad), leaves[0].grad) < TOL[dtype]
+    assert relerr(wd.grad, leaves[1].grad) < 1e-4
+    assert relerr(bd.grad, leaves[2].grad) < 1e-4
+
+
+def test_losses_golden(golden_dir):
+    """HIP Dice / CE / Dice+CE against vectors produced by the reference's own loss classes."""
+    import os
+    from losses.compound_losses import DiceAndCELoss
+    from losses.dice_loss import DiceLoss
+    from losses.ce_loss import RobustCrossEntropyLoss
+    dev = _dev()
+    d = dict(np.load(os.path.join(golden_dir, "losses.npz")))
+    logits, labels = torch.from_numpy(d["logits"]).to(dev), torch.from_numpy(d["labels"]).to(dev)
+    for layout in ("nchw", "nhwc"):
+        for do_bg in (False, True):
+            for batch in (False, True):
+                for squared in (False, True):
+                    key = f"dice_bg{int(do_bg)}_b{int(batch)}_s{int(squared)}"
+                    li = logits.clone()
+                    if layout == "nhwc":
+                        li = li.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+                    li.requires_grad_(True)
+                    v = DiceLoss(3, do_bg=do_bg, batch=batch, squared=squared)(li, labels)
+                    v.backward()
+                    assert abs(v.item() - float(d[key])) < 2e-6, key
+                    np.testing.assert_allclose(li.grad.cpu().numpy(), d[key + "_grad"], atol=2e-7, err_msg=key)
+    li = logits.clone().requires_grad_(True)
+    ce = RobustCrossEntropyLoss()(li, labels[:, None])
+    ce.backward()
+    assert abs(ce.item() - float(d["ce"])) < 2e-6
+    np.testing.assert_allclose(li.grad.cpu().numpy(), d["ce_grad"], atol=2e-7)
+    li = logits.clone().requires_grad_(True)
+    comp = DiceAndCELoss(dice_kwargs=dict(num_classes=3, do_bg=True))
+    v = comp(li, labels, dice_weight=0.7, ce_weight=0.3)
+    v.backward()
+    assert abs(v.item() - float(d["dice_ce_w"])) < 2e-6
+    np.testing.assert_allclose(li.grad.cpu().numpy(), d["dice_ce_w_grad"], atol=2e-7)
+    assert abs(comp(logits, labels, dice_weight=0.0, ce_weight=None).item() - float(d["dice_ce_zero_weight_quirk"])) < 2e-6
+    # known answers
+    lab = torch.tensor([[[0, 1], [2, 2]]], device=dev)
+    fn = DiceLoss(2, do_bg=True)
+    assert abs(fn(torch.zeros(1, 3, 2, 2, device=dev), lab).item() - 0.6761878354) < 1e-6
+    perfect = F.one_hot(lab, 3).permute(0, 3, 1, 2).float() * 100
+    assert abs(fn(perfect, lab).item()) < 1e-6
+    assert abs(comp.get_ce_loss(torch.zeros(1, 3, 2, 2, device=dev), lab).item() - math.log(3)) < 1e-6
+    # retain_graph=True (BADGE selector, badge_selector.py:25)
+    li = logits.clone().requires_grad_(True)
+    v = comp(li, labels)
+    v.backward(retain_graph=True)
+    g1 = li.grad.clone()
+    v.backward()
+    np.testing.assert_allclose(li.grad.cpu().numpy(), 2 * g1.cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["adam", "adamw", "sgd"])
+def test_optimizer_and_clip(kind):
+    from mia_hip import ops, OPT_ADAM, OPT_ADAMW, OPT_SGD
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    nel = 10007
+    p0 = torch.randn(nel, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    if kind == "adam":
+        opt = torch.optim.Adam([pr], betas=(0.9, 0.999), weight_decay=5e-4)
+    elif kind == "adamw":
+        opt = torch.optim.AdamW([pr], betas=(0.9, 0.999), weight_decay=5e-4)
+    else:
+        opt = torch.optim.SGD([pr], lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    pd = p0.to(dev)
+    m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    code = {"adam": OPT_ADAM, "adamw": OPT_ADAMW, "sgd": OPT_SGD}[kind]
+    for step in range(1, 4):
+        gr = torch.randn(nel, generator=g) * (3.0 if step == 2 else 0.01)
+        pr.grad = gr.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pr], 10.0)
+        lr = 1e-3 * step
+        for gp in opt.param_groups:
+            gp["lr"] = lr
+        opt.step()
+        gd = gr.to(dev)
+        clip = ops.grad_norm(gd, 10.0)
+        ops.optim_step(code, pd, gd, m, v, lr, 0.9, 0.999, 1e-8, 5e-4, step, clip)
+        torch.cuda.synchronize()
+        assert abs(clip[0].item() - tn.item()) / tn.item() < 1e-5
+        assert relerr(pd, pr) < 2e-6, (kind, step)
