@@ -120,12 +120,48 @@ int mia_dice_ce_bwd(const float* logits, const long long* labels, const float* c
 #define MIA_OPT_ADAMW 1
 #define MIA_OPT_SGD 2
 int mia_grad_norm_workspace(void); /* floats */
-/* out[0] = global L2 norm, out[1] = min(1, max_norm/(norm+1e-6)) (torch.nn.utils.clip_grad_norm_) */
-int mia_grad_norm(const float* grad, int64_t n, float max_norm, float* workspace, float* out, void* stream);
+/* out[0] = L2 norm of grad_scale*grad, out[1] = min(1, max_norm/(norm+1e-6)) (torch.nn.utils.clip_grad_norm_);
+ * grad_scale = 1/world_size when `grad` holds the all-reduced SUM of per-rank gradients */
+int mia_grad_norm(const float* grad, int64_t n, float max_norm, float grad_scale, float* workspace, float* out, void* stream);
 int mia_scale_by_clip(float* x, int64_t n, const float* clip, void* stream);
 int mia_optim_step(float* param, const float* grad, float* m, float* v, int64_t n, int kind, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, int first_step,
                    const float* clip, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ augmentation / resize / normalisation (src/transforms) */
+/* images [B][C][H][W] fp32, labels [B][H][W] int64, per-sample parameter arrays on the device;
+ * apply[b] == 0 (apply may be NULL = all) copies sample b through unchanged. */
+/* RandomAffine / RandomRotation (joint_transform.py:158-206, :100-127): torchvision F.affine / F.rotate tensor path
+ * = inverse matrix mats[b][6] -> base grid -> grid_sample(nearest, zeros, align_corners=False); image and label in one launch. */
+int mia_affine_nearest(const float* img_in, float* img_out, const long long* lab_in, long long* lab_out, int nb, int c, int h,
+                       int w, const float* mats, const int* apply, void* stream);
+/* RandomRotation90 / MirrorTransform (joint_transform.py:40-97): torch.rot90(k) then optional flips; 4- or 8-byte elements */
+int mia_rot90_flip(const void* in, void* out, int elem_bytes, int nb, int c, int h, int w, int k, int flip_h, int flip_w,
+                   void* stream);
+/* RandomGaussianBlur (image_transform.py:145-193): F.gaussian_blur = k x k outer-product kernel, reflect pad */
+int mia_gaussian_blur(const float* in, float* out, int nb, int c, int h, int w, const float* sigma, const int* ksize,
+                      int max_ksize, const int* apply, void* stream);
+/* per-sample (mean, unbiased std) over C*H*W (gray=1, C=3: of the luma image): feeds contrast and z-score */
+int mia_sample_stats_workspace(int nb); /* floats */
+int mia_sample_stats(const float* in, int nb, int c, int64_t hw, int gray, float* workspace, float* mean_std, void* stream);
+#define MIA_EW_GAMMA 0    /* RandomGamma            image_transform.py:31 */
+#define MIA_EW_CONTRAST 1 /* RandomContrast / RandomBrightness (both ColorJitter(contrast=)) image_transform.py:62,:93 */
+#define MIA_EW_NOISE 2    /* RandomGaussianNoise with an explicit noise tensor image_transform.py:130-132 */
+#define MIA_EW_ZSCORE 3   /* ZScoreNormalize        normalization.py:17-21 */
+int mia_elementwise(const float* in, float* out, int64_t per_sample, int nb, int op, const float* p0, const float* mean_std,
+                    const float* aux, const int* apply, void* stream);
+/* RandomGaussianNoise with on-device Philox4x32-10 normal noise (sigma[b]) */
+int mia_noise_clip(const float* in, float* out, int64_t per_sample, int nb, const float* sigma, uint64_t seed, uint64_t offset,
+                   const int* apply, void* stream);
+/* JointResize image path / UnetProcessor.preprocess / deep-supervision Upsample: interpolate(bilinear, align_corners=False);
+ * lowres_hw[b][2] != NULL = SimulateLowRes (image_transform.py:218-225: nearest-exact down, bilinear up) fused in one pass */
+int mia_resize_bilinear(const float* in, float* out, int nb, int c, int h, int w, int oh, int ow, const int* lowres_hw,
+                        const int* apply, void* stream);
+int mia_resize_bilinear_bwd(const float* dout, float* din_zeroed, int nb, int c, int h, int w, int oh, int ow, void* stream);
+/* torchvision >= 0.17 default antialias=True on the tensor path: separable triangle filter (two passes, tmp = [B][C][H][OW]) */
+int mia_resize_bilinear_aa(const float* in, float* tmp, float* out, int nb, int c, int h, int w, int oh, int ow, void* stream);
+/* JointResize label path / UnetProcessor.postprocess: interpolate(nearest) */
+int mia_resize_nearest(const void* in, void* out, int elem_bytes, int64_t planes, int h, int w, int oh, int ow, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,414 @@
+// Batched augmentation / resize / normalisation kernels (gfx950), per-sample parameters.
+//
+// Reference: src/transforms/joint_transform.py (RandomAffine :158-206, RandomRotation :100-127,
+// JointResize :11-38, RandomRotation90 :40-65, MirrorTransform :67-97), image_transform.py (RandomGamma
+// :15-44, RandomContrast/"RandomBrightness" :47-106, RandomGaussianNoise :109-142, RandomGaussianBlur
+// :145-193, SimulateLowRes :196-236), normalization.py:9-26.  The reference runs these per sample on
+// the CPU inside DataLoader workers through torchvision; here every stage is one (or two, where a
+// per-sample statistic is needed) HBM-streaming launch over the whole batch: images [B,C,H,W] fp32,
+// labels [B,H,W] int64, parameters in small per-sample device arrays, `apply[b]==0` = pass-through.
+// Geometric ops move image and label in ONE launch.  All are bandwidth-bound (read once, write once).
+#include "common.h"
+
+__device__ __forceinline__ bool on(const int* apply, int b) { return apply == nullptr || apply[b] != 0; }
+
+// ---------------------------------------------------------------- inverse-affine nearest warp (image + label)
+// mats[b] = the 6 entries of torchvision's inverse affine matrix (centre frame).  Follows
+// _gen_affine_grid + grid_sample(nearest, zeros, align_corners=False): base (x+0.5-W/2, y+0.5-H/2),
+// theta rescaled by (0.5W, 0.5H), unnormalise ((g+1)*size-1)/2, round-half-even, zero outside.
+__global__ void affine_nearest_kernel(const float* __restrict__ img_in, float* __restrict__ img_out,
+                                      const long long* __restrict__ lab_in, long long* __restrict__ lab_out, int nb, int c,
+                                      int h, int w, const float* __restrict__ mats, const int* __restrict__ apply) {
+  const int64_t hw = (int64_t)h * w, total = (int64_t)nb * hw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / hw);
+    const int64_t p = i - (int64_t)b * hw;
+    const int y = (int)(p / w), x = (int)(p - (int64_t)y * w);
+    int sy = y, sx = x;
+    bool inside = true;
+    if (on(apply, b)) {
+      const float* m = mats + b * 6;
+      const float hx = 0.5f * w, hy = 0.5f * h;
+      const float xb = (float)x + 0.5f - hx, yb = (float)y + 0.5f - hy;
+      const float gx = xb * (m[0] / hx) + yb * (m[1] / hx) + (m[2] / hx);
+      const float gy = xb * (m[3] / hy) + yb * (m[4] / hy) + (m[5] / hy);
+      const float fx = ((gx + 1.f) * w - 1.f) * 0.5f, fy = ((gy + 1.f) * h - 1.f) * 0.5f;
+      const float rx = nearbyintf(fx), ry = nearbyintf(fy);
+      inside = (rx >= 0.f && rx <= (float)(w - 1) && ry >= 0.f && ry <= (float)(h - 1));
+      sx = (int)rx; sy = (int)ry;
+    }
+    const int64_t sp = (int64_t)sy * w + sx;
+    if (img_in)
+      for (int ch = 0; ch < c; ++ch)
+        img_out[((int64_t)b * c + ch) * hw + p] = inside ? img_in[((int64_t)b * c + ch) * hw + sp] : 0.f;
+    if (lab_in) lab_out[(int64_t)b * hw + p] = inside ? lab_in[(int64_t)b * hw + sp] : 0;
+  }
+}
+
+extern "C" int mia_affine_nearest(const float* img_in, float* img_out, const long long* lab_in, long long* lab_out, int nb,
+                                  int c, int h, int w, const float* mats, const int* apply, void* stream) {
+  MIA_CHECK_ARG((img_in || lab_in) && mats && nb > 0 && h > 0 && w > 0, "mia_affine_nearest: bad arguments");
+  MIA_CHECK_ARG((img_in == nullptr) == (img_out == nullptr) && (lab_in == nullptr) == (lab_out == nullptr), "mia_affine_nearest: in/out mismatch");
+  const int64_t total = (int64_t)nb * h * w;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(affine_nearest_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), img_in, img_out, lab_in,
+                     lab_out, nb, c, h, w, mats, apply);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------- rot90 (k quarter turns, torch.rot90 on (-2,-1)) + flips
+// out[b][.][y][x] = in[b][.][sy][sx].  Square or non-square: for odd k the output is W x H.
+template <typename T>
+__global__ void rot_flip_kernel(const T* __restrict__ in, T* __restrict__ out, int nb, int c, int h, int w, int k, int flip_h,
+                                int flip_w) {
+  const int oh = (k & 1) ? w : h, ow = (k & 1) ? h : w;
+  const int64_t ohw = (int64_t)oh * ow, total = (int64_t)nb * c * ohw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bc = i / ohw, p = i - bc * ohw;
+    int y = (int)(p / ow), x = (int)(p - (int64_t)y * ow);
+    int sy, sx;
+    // torch.rot90(x, k, (H, W)): k=1 -> out[y][x] = in[x][W-1-y]
+    switch (k & 3) {
+      case 0: sy = y; sx = x; break;
+      case 1: sy = x; sx = w - 1 - y; break;
+      case 2: sy = h - 1 - y; sx = w - 1 - x; break;
+      default: sy = h - 1 - x; sx = y; break;
+    }
+    if (flip_h) sy = h - 1 - sy;
+    if (flip_w) sx = w - 1 - sx;
+    out[i] = in[bc * (int64_t)h * w + (int64_t)sy * w + sx];
+  }
+}
+
+extern "C" int mia_rot90_flip(const void* in, void* out, int elem_bytes, int nb, int c, int h, int w, int k, int flip_h,
+                              int flip_w, void* stream) {
+  MIA_CHECK_ARG(in && out && nb > 0 && c > 0 && h > 0 && w > 0, "mia_rot90_flip: bad arguments");
+  MIA_CHECK_ARG(elem_bytes == 4 || elem_bytes == 8, "mia_rot90_flip: element size %d not 4 or 8", elem_bytes);
+  const int64_t total = (int64_t)nb * c * h * w;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL(rot_flip_kernel<unsigned int>, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned int*>(in), static_cast<unsigned int*>(out), nb, c, h, w, k, flip_h, flip_w);
+  else
+    hipLaunchKernelGGL(rot_flip_kernel<unsigned long long>, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned long long*>(in), static_cast<unsigned long long*>(out), nb, c, h, w, k, flip_h, flip_w);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------- gaussian blur (k x k outer-product kernel, reflect pad)
+#define BLUR_MAXK 9
+__global__ void gaussian_blur_kernel(const float* __restrict__ in, float* __restrict__ out, int nb, int c, int h, int w,
+                                     const float* __restrict__ sigma, const int* __restrict__ ksize, const int* __restrict__ apply) {
+  const int64_t hw = (int64_t)h * w, total = (int64_t)nb * c * hw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bc = i / hw, p = i - bc * hw;
+    const int b = (int)(bc / c);
+    if (!on(apply, b)) { out[i] = in[i]; continue; }
+    const int k = ksize[b], r = k / 2;
+    const float s = sigma[b];
+    float k1[BLUR_MAXK];
+    float ksum = 0.f;
+#pragma unroll
+    for (int j = 0; j < BLUR_MAXK; ++j) {
+      const float xx = (float)(j - r) / s;
+      k1[j] = (j < k) ? expf(-0.5f * xx * xx) : 0.f;
+      ksum += k1[j];
+    }
+#pragma unroll
+    for (int j = 0; j < BLUR_MAXK; ++j) k1[j] /= ksum;
+    const int y = (int)(p / w), x = (int)(p - (int64_t)y * w);
+    const float* src = in + bc * hw;
+    float acc = 0.f;
+    for (int a = 0; a < k; ++a) {
+      int yy = y + a - r;
+      yy = yy < 0 ? -yy : (yy >= h ? 2 * h - 2 - yy : yy);
+      for (int bb = 0; bb < k; ++bb) {
+        int xx = x + bb - r;
+        xx = xx < 0 ? -xx : (xx >= w ? 2 * w - 2 - xx : xx);
+        acc += (k1[a] * k1[bb]) * src[(int64_t)yy * w + xx];
+      }
+    }
+    out[i] = acc;
+  }
+}
+
+extern "C" int mia_gaussian_blur(const float* in, float* out, int nb, int c, int h, int w, const float* sigma, const int* ksize,
+                                 int max_ksize, const int* apply, void* stream) {
+  MIA_CHECK_ARG(in && out && sigma && ksize && nb > 0 && c > 0, "mia_gaussian_blur: bad arguments");
+  MIA_CHECK_ARG(max_ksize >= 1 && max_ksize <= BLUR_MAXK && (max_ksize & 1), "mia_gaussian_blur: kernel size %d not odd in [1,%d]", max_ksize, BLUR_MAXK);
+  MIA_CHECK_ARG(h > max_ksize / 2 && w > max_ksize / 2, "mia_gaussian_blur: reflect padding needs H,W > k/2");
+  const int64_t total = (int64_t)nb * c * h * w;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(gaussian_blur_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, nb, c, h, w, sigma, ksize, apply);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------- per-sample statistics over C*H*W: stats[b] = (sum, sumsq) in double
+// gray=1 with c==3: statistics of 0.2989 r + 0.587 g + 0.114 b (torchvision rgb_to_grayscale) over H*W.
+__global__ void sample_stats_partial_kernel(const float* __restrict__ in, int c, int64_t hw, int gray, int slabs,
+                                            float* __restrict__ part) {
+  __shared__ float red[16];
+  const int b = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  const int64_t n = (gray && c == 3) ? hw : (int64_t)c * hw;
+  const int64_t per = (n + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < n ? r0 + per : n;
+  const float* src = in + (int64_t)b * c * hw;
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+    const float v = (gray && c == 3) ? (0.2989f * src[i] + 0.587f * src[hw + i] + 0.114f * src[2 * hw + i]) : src[i];
+    s1 += v; s2 += v * v;
+  }
+  float r = block_sum(s1, red); if (threadIdx.x == 0) part[(size_t)blockIdx.x * 2] = r;
+  r = block_sum(s2, red); if (threadIdx.x == 0) part[(size_t)blockIdx.x * 2 + 1] = r;
+}
+
+__global__ void sample_stats_final_kernel(const float* __restrict__ part, int nb, int slabs, int64_t n, float* __restrict__ out) {
+  // out[b] = (mean, unbiased std)
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  double s1 = 0, s2 = 0;
+  for (int s = 0; s < slabs; ++s) { s1 += part[((size_t)b * slabs + s) * 2]; s2 += part[((size_t)b * slabs + s) * 2 + 1]; }
+  const double mean = s1 / (double)n;
+  double var = n > 1 ? (s2 - (double)n * mean * mean) / (double)(n - 1) : 0.0;
+  if (var < 0) var = 0;
+  out[b * 2] = (float)mean;
+  out[b * 2 + 1] = (float)sqrt(var);
+}
+
+#define STAT_SLABS 64
+extern "C" int mia_sample_stats_workspace(int nb) { return nb * STAT_SLABS * 2; }
+
+extern "C" int mia_sample_stats(const float* in, int nb, int c, int64_t hw, int gray, float* workspace, float* mean_std, void* stream) {
+  MIA_CHECK_ARG(in && workspace && mean_std && nb > 0 && c > 0 && hw > 0, "mia_sample_stats: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(sample_stats_partial_kernel, dim3(nb * STAT_SLABS), dim3(256), 0, st, in, c, hw, gray, STAT_SLABS, workspace);
+  const int64_t n = (gray && c == 3) ? hw : (int64_t)c * hw;
+  hipLaunchKernelGGL(sample_stats_final_kernel, dim3(ceil_div(nb, 64)), dim3(64), 0, st, workspace, nb, STAT_SLABS, n, mean_std);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------- elementwise intensity ops (in-place safe)
+#define EW_GAMMA 0     /* out = pow(in, p0[b])                                   image_transform.py:31 */
+#define EW_CONTRAST 1  /* out = clamp(p0[b]*in + (1-p0[b])*mean[b], 0, 1)         torchvision _blend    */
+#define EW_NOISE 2     /* out = clamp(in + aux, 0, 1) with explicit noise tensor  image_transform.py:130-132 */
+#define EW_ZSCORE 3    /* out = (in - mean[b]) / max(std[b], 1e-8)                normalization.py:17-21 */
+__global__ void elementwise_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t per_sample, int nb, int op,
+                                   const float* __restrict__ p0, const float* __restrict__ mean_std, const float* __restrict__ aux,
+                                   const int* __restrict__ apply) {
+  const int64_t total = per_sample * nb;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per_sample);
+    float v = in[i];
+    if (on(apply, b)) {
+      if (op == EW_GAMMA) v = powf(v, p0[b]);
+      else if (op == EW_CONTRAST) { const float f = p0[b]; v = f * v + (1.f - f) * mean_std[b * 2]; v = fminf(fmaxf(v, 0.f), 1.f); }
+      else if (op == EW_NOISE) { v = v + aux[i]; v = fminf(fmaxf(v, 0.f), 1.f); }
+      else { const float sd = fmaxf(mean_std[b * 2 + 1], 1e-8f); v = (v - mean_std[b * 2]) / sd; }
+    }
+    out[i] = v;
+  }
+}
+
+extern "C" int mia_elementwise(const float* in, float* out, int64_t per_sample, int nb, int op, const float* p0,
+                               const float* mean_std, const float* aux, const int* apply, void* stream) {
+  MIA_CHECK_ARG(in && out && per_sample > 0 && nb > 0 && op >= 0 && op <= EW_ZSCORE, "mia_elementwise: bad arguments");
+  MIA_CHECK_ARG((op != EW_GAMMA && op != EW_CONTRAST) || p0, "mia_elementwise: missing parameter array");
+  MIA_CHECK_ARG((op != EW_CONTRAST && op != EW_ZSCORE) || mean_std, "mia_elementwise: missing statistics");
+  MIA_CHECK_ARG(op != EW_NOISE || aux, "mia_elementwise: missing noise tensor");
+  const int64_t total = per_sample * nb;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(elementwise_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, per_sample, nb, op, p0, mean_std, aux, apply);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------- gaussian noise with a counter-based generator (Philox4x32-10)
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__global__ void noise_clip_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t per_sample, int nb,
+                                  const float* __restrict__ sigma, unsigned long long seed, unsigned long long offset,
+                                  const int* __restrict__ apply) {
+  const int64_t total = per_sample * nb, quads = (total + 3) / 4;
+  for (int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < quads; qd += (int64_t)gridDim.x * blockDim.x) {
+    unsigned c0 = (unsigned)qd, c1 = (unsigned)(qd >> 32), c2 = (unsigned)offset, c3 = (unsigned)(offset >> 32);
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    const float u0 = ((c0 >> 8) + 0.5f) * (1.f / 16777216.f), u1 = ((c1 >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float u2 = ((c2 >> 8) + 0.5f) * (1.f / 16777216.f), u3 = ((c3 >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+    const float z[4] = {r0 * cosf(6.2831853f * u1), r0 * sinf(6.2831853f * u1), r1 * cosf(6.2831853f * u3), r1 * sinf(6.2831853f * u3)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = qd * 4 + e;
+      if (i >= total) break;
+      const int b = (int)(i / per_sample);
+      float v = in[i];
+      if (on(apply, b)) { v += sigma[b] * z[e]; v = fminf(fmaxf(v, 0.f), 1.f); }
+      out[i] = v;
+    }
+  }
+}
+
+extern "C" int mia_noise_clip(const float* in, float* out, int64_t per_sample, int nb, const float* sigma, uint64_t seed,
+                              uint64_t offset, const int* apply, void* stream) {
+  MIA_CHECK_ARG(in && out && sigma && per_sample > 0 && nb > 0, "mia_noise_clip: bad arguments");
+  const int64_t quads = (per_sample * nb + 3) / 4;
+  const int blocks = (int)((quads + 255) / 256 < 8192 ? (quads + 255) / 256 : 8192);
+  hipLaunchKernelGGL(noise_clip_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, per_sample, nb, sigma,
+                     (unsigned long long)seed, (unsigned long long)offset, apply);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------- resize
+__device__ __forceinline__ float src_index(float scale, int dst) {  // area_pixel_compute_source_index, align_corners=False
+  const float s = scale * ((float)dst + 0.5f) - 0.5f;
+  return s < 0.f ? 0.f : s;
+}
+
+// bilinear (no antialias) with optional per-sample low-res simulation: when lowres != null the source image is
+// first viewed through a nearest-exact downsample to (lh[b], lw[b]) (SimulateLowRes, image_transform.py:218-225).
+__global__ void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int nb, int c, int h, int w, int oh,
+                                       int ow, const int* __restrict__ lowres, const int* __restrict__ apply) {
+  const int64_t ohw = (int64_t)oh * ow, total = (int64_t)nb * c * ohw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bc = i / ohw, p = i - bc * ohw;
+    const int b = (int)(bc / c);
+    const int y = (int)(p / ow), x = (int)(p - (int64_t)y * ow);
+    const float* src = in + bc * (int64_t)h * w;
+    if (lowres != nullptr && !on(apply, b)) { out[i] = src[(int64_t)y * w + x]; continue; }
+    const int lh = lowres ? lowres[b * 2] : h, lw = lowres ? lowres[b * 2 + 1] : w;
+    const float sy = src_index((float)lh / (float)oh, y), sx = src_index((float)lw / (float)ow, x);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < lh - 1 ? 1 : 0), x1 = x0 + (x0 < lw - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    auto fetch = [&](int yy, int xx) -> float {
+      if (lowres) {  // nearest-exact: src = min(floor((dst+0.5)*in/out), in-1)
+        const int iy = min((int)floorf(((float)yy + 0.5f) * ((float)h / (float)lh)), h - 1);
+        const int ix = min((int)floorf(((float)xx + 0.5f) * ((float)w / (float)lw)), w - 1);
+        return src[(int64_t)iy * w + ix];
+      }
+      return src[(int64_t)yy * w + xx];
+    };
+    const float top = (1.f - lx) * fetch(y0, x0) + lx * fetch(y0, x1);
+    const float bot = (1.f - lx) * fetch(y1, x0) + lx * fetch(y1, x1);
+    out[i] = (1.f - ly) * top + ly * bot;
+  }
+}
+
+extern "C" int mia_resize_bilinear(const float* in, float* out, int nb, int c, int h, int w, int oh, int ow, const int* lowres_hw,
+                                   const int* apply, void* stream) {
+  MIA_CHECK_ARG(in && out && nb > 0 && c > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "mia_resize_bilinear: bad arguments");
+  MIA_CHECK_ARG(lowres_hw == nullptr || (oh == h && ow == w), "mia_resize_bilinear: low-res simulation keeps the size");
+  const int64_t total = (int64_t)nb * c * oh * ow;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, nb, c, h, w, oh, ow, lowres_hw, apply);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// adjoint of resize_bilinear (no low-res): din += scatter of dout.  Used by the deep-supervision heads' Upsample.
+__global__ void resize_bilinear_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int nb, int c, int h, int w,
+                                           int oh, int ow) {
+  const int64_t ohw = (int64_t)oh * ow, total = (int64_t)nb * c * ohw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t bc = i / ohw, p = i - bc * ohw;
+    const int y = (int)(p / ow), x = (int)(p - (int64_t)y * ow);
+    const float sy = src_index((float)h / (float)oh, y), sx = src_index((float)w / (float)ow, x);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, g = dout[i];
+    float* dst = din + bc * (int64_t)h * w;
+    atomicAdd(dst + (int64_t)y0 * w + x0, (1.f - ly) * (1.f - lx) * g);
+    atomicAdd(dst + (int64_t)y0 * w + x1, (1.f - ly) * lx * g);
+    atomicAdd(dst + (int64_t)y1 * w + x0, ly * (1.f - lx) * g);
+    atomicAdd(dst + (int64_t)y1 * w + x1, ly * lx * g);
+  }
+}
+
+extern "C" int mia_resize_bilinear_bwd(const float* dout, float* din_zeroed, int nb, int c, int h, int w, int oh, int ow, void* stream) {
+  MIA_CHECK_ARG(dout && din_zeroed && nb > 0 && c > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "mia_resize_bilinear_bwd: bad arguments");
+  const int64_t total = (int64_t)nb * c * oh * ow;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dout, din_zeroed, nb, c, h, w, oh, ow);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// antialiased bilinear, one separable pass along W (axis=1) or H (axis=0): torch _upsample_bilinear2d_aa
+// (triangle filter, support = max(scale,1), weights normalised per output index).
+__global__ void resize_aa_pass_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t planes, int h, int w, int osize,
+                                      int axis) {
+  const int isize = axis ? w : h;
+  const int oh = axis ? h : osize, ow = axis ? osize : w;
+  const float scale = (float)isize / (float)osize;
+  const float support = scale >= 1.f ? scale : 1.f;
+  const float invscale = scale >= 1.f ? 1.f / scale : 1.f;
+  const int64_t ohw = (int64_t)oh * ow, total = planes * ohw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pl = i / ohw, p = i - pl * ohw;
+    const int y = (int)(p / ow), x = (int)(p - (int64_t)y * ow);
+    const int o = axis ? x : y;
+    const float center = scale * ((float)o + 0.5f);
+    int lo = (int)(center - support + 0.5f); if (lo < 0) lo = 0;
+    int hi = (int)(center + support + 0.5f); if (hi > isize) hi = isize;
+    float wsum = 0.f, acc = 0.f;
+    const float* src = in + pl * (int64_t)h * w;
+    for (int j = lo; j < hi; ++j) {
+      float t = ((float)j - center + 0.5f) * invscale;
+      t = t < 0.f ? -t : t;
+      const float wt = t < 1.f ? 1.f - t : 0.f;
+      wsum += wt;
+      acc += wt * (axis ? src[(int64_t)y * w + j] : src[(int64_t)j * w + x]);
+    }
+    out[i] = wsum != 0.f ? acc / wsum : 0.f;
+  }
+}
+
+extern "C" int mia_resize_bilinear_aa(const float* in, float* tmp, float* out, int nb, int c, int h, int w, int oh, int ow, void* stream) {
+  MIA_CHECK_ARG(in && tmp && out && nb > 0 && c > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "mia_resize_bilinear_aa: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t planes = (int64_t)nb * c;
+  // horizontal pass: [h][w] -> tmp [h][ow]; vertical pass: [h][ow] -> out [oh][ow]
+  int64_t total = planes * h * ow;
+  int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(resize_aa_pass_kernel, dim3(blocks), dim3(256), 0, st, in, tmp, planes, h, w, ow, 1);
+  total = planes * oh * ow;
+  blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(resize_aa_pass_kernel, dim3(blocks), dim3(256), 0, st, tmp, out, planes, h, ow, oh, 0);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// nearest (legacy "nearest": src = min(floor(dst * in/out), in-1)), 4- or 8-byte elements (float images, int64 labels)
+template <typename T>
+__global__ void resize_nearest_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t planes, int h, int w, int oh, int ow) {
+  const int64_t ohw = (int64_t)oh * ow, total = planes * ohw;
+  const float sh = (float)h / (float)oh, sw = (float)w / (float)ow;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pl = i / ohw, p = i - pl * ohw;
+    const int y = (int)(p / ow), x = (int)(p - (int64_t)y * ow);
+    const int sy = min((int)floorf((float)y * sh), h - 1), sx = min((int)floorf((float)x * sw), w - 1);
+    out[i] = in[pl * (int64_t)h * w + (int64_t)sy * w + sx];
+  }
+}
+
+extern "C" int mia_resize_nearest(const void* in, void* out, int elem_bytes, int64_t planes, int h, int w, int oh, int ow, void* stream) {
+  MIA_CHECK_ARG(in && out && planes > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "mia_resize_nearest: bad arguments");
+  MIA_CHECK_ARG(elem_bytes == 4 || elem_bytes == 8, "mia_resize_nearest: element size %d not 4 or 8", elem_bytes);
+  const int64_t total = planes * oh * ow;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL(resize_nearest_kernel<unsigned int>, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned int*>(in), static_cast<unsigned int*>(out), planes, h, w, oh, ow);
+  else
+    hipLaunchKernelGGL(resize_nearest_kernel<unsigned long long>, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned long long*>(in), static_cast<unsigned long long*>(out), planes, h, w, oh, ow);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}

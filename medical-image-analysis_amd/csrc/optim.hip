@@ -23,8 +23,8 @@ __global__ void sumsq_partial_kernel(const float* __restrict__ x, int64_t n, flo
   if (threadIdx.x == 0) part[blockIdx.x] = r;
 }
 
-// out[0] = total L2 norm, out[1] = clip coefficient min(1, max_norm/(norm+1e-6))  (torch clip_grad_norm_)
-__global__ void norm_final_kernel(const float* __restrict__ part, int nblk, float max_norm, float* __restrict__ out) {
+// out[0] = L2 norm of grad_scale*g, out[1] = clip coefficient min(1, max_norm/(norm+1e-6))  (torch clip_grad_norm_)
+__global__ void norm_final_kernel(const float* __restrict__ part, int nblk, float max_norm, float grad_scale, float* __restrict__ out) {
   __shared__ double red[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += part[i];
@@ -33,7 +33,7 @@ __global__ void norm_final_kernel(const float* __restrict__ part, int nblk, floa
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int i = 0; i < blockDim.x; ++i) t += red[i];
-    const float nrm = (float)sqrt(t);
+    const float nrm = grad_scale * (float)sqrt(t);
     float coef = max_norm / (nrm + 1e-6f);
     if (coef > 1.f) coef = 1.f;
     out[0] = nrm;
@@ -44,13 +44,13 @@ __global__ void norm_final_kernel(const float* __restrict__ part, int nblk, floa
 #define GN_BLOCKS 1024
 extern "C" int mia_grad_norm_workspace(void) { return GN_BLOCKS; }
 
-extern "C" int mia_grad_norm(const float* grad, int64_t n, float max_norm, float* workspace, float* out, void* stream) {
+extern "C" int mia_grad_norm(const float* grad, int64_t n, float max_norm, float grad_scale, float* workspace, float* out, void* stream) {
   MIA_CHECK_ARG(grad && workspace && out && n > 0, "mia_grad_norm: bad arguments");
   MIA_CHECK_ARG((reinterpret_cast<uintptr_t>(grad) & 15) == 0, "mia_grad_norm: gradient buffer must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int blocks = (int)((n / 4 + 255) / 256 < GN_BLOCKS ? (n / 4 + 255) / 256 + 1 : GN_BLOCKS);
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, grad, n, workspace);
-  hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, st, workspace, blocks, max_norm, out);
+  hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, st, workspace, blocks, max_norm, grad_scale, out);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

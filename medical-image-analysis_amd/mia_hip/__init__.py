@@ -29,7 +29,7 @@ class MiaError(RuntimeError):
 
 
 _CTYPES = {
-    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float,
+    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "float": ctypes.c_float,
 }
 
 
@@ -62,6 +62,13 @@ def lib() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise MiaError(f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as
+        # /opt/rocm's).  Load torch's copy first so the tensors' allocator/streams and our kernels
+        # share a runtime; loading ours first would bind everyone to the system copy.
+        import torch  # noqa: F401
+        tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(tl):
+            ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)
         l = ctypes.CDLL(LIB_PATH)
         for name, (ret, args) in parse_header().items():
             fn = getattr(l, name)

@@ -409,11 +409,12 @@ DiceCEFn.last_sums = None
 
 
 # ------------------------------------------------------------------ optimizer helpers
-def grad_norm(flat_grad: torch.Tensor, max_norm: float) -> torch.Tensor:
-    """out[0] = ||g||_2, out[1] = clip coefficient; stays on device (no sync)."""
+def grad_norm(flat_grad: torch.Tensor, max_norm: float, grad_scale: float = 1.0) -> torch.Tensor:
+    """out[0] = ||grad_scale*g||_2, out[1] = clip coefficient; stays on device (no sync)."""
     ws = torch.empty(lib().mia_grad_norm_workspace(), device=flat_grad.device, dtype=torch.float32)
     out = torch.empty(2, device=flat_grad.device, dtype=torch.float32)
-    call("mia_grad_norm", _p(flat_grad), _c_i64(flat_grad.numel()), _c_float(max_norm), _p(ws), _p(out), _stream())
+    call("mia_grad_norm", _p(flat_grad), _c_i64(flat_grad.numel()), _c_float(max_norm), _c_float(grad_scale), _p(ws), _p(out),
+         _stream())
     return out
 
 

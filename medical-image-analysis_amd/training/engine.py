@@ -1,0 +1,202 @@
+"""Training-step harness for the MI355X UNet path.
+
+Mirrors ``ALTrainer.train_step`` (reference `src/training/al_trainer.py:1350-1399`) with
+``_setup_optimizer`` (:737-780), ``_setup_loss`` (:782-800) and ``PolyLRScheduler.step``
+(`src/scheduler/lr_scheduler.py:31-55`): set lr, forward, Dice+CE, zero_grad, backward,
+clip_grad_norm_(10), optimizer step -- but with
+
+* all parameters / gradients / Adam moments in ONE flat fp32 buffer each (``FlatOptimizer``), so the
+  global norm is one reduction and the update one fused HIP launch, the clip coefficient staying on
+  the device (the reference's per-iteration ``loss.item()`` host sync, :1381, is gone);
+* data parallelism (build-side addition, the reference is single-process): one process per GPU,
+  the minibatch sharded across ranks, ONE exchange per step -- a bucketed RCCL all-reduce (sum) of
+  the flat gradient buffer, issued from autograd hooks while backward is still running (RCCL runs it
+  on its own HIP stream), joined before the global-norm clip; gradients are averaged by folding
+  1/world into the optimizer launch.  Buckets are laid out in REVERSE forward order so the first
+  gradients produced fill the first bucket.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from mia_hip import OPT_ADAM, OPT_ADAMW, OPT_SGD, ops
+from scheduler.lr_scheduler import PolyLRScheduler
+
+_KIND = {"adam": OPT_ADAM, "adamw": OPT_ADAMW, "sgd": OPT_SGD}
+
+
+class FlatOptimizer:
+    """Adam / AdamW / SGD(momentum=0.9) over one flat buffer (reference al_trainer.py:744-761 semantics:
+    betas=(0.9, 0.999), no lr at construction -> torch default 1e-3 until the scheduler overwrites it)."""
+
+    def __init__(self, model: torch.nn.Module, name: str = "adamw", lr: float = 1e-3, weight_decay: float = 0.0,
+                 betas=(0.9, 0.999), eps: float = 1e-8, momentum: float = 0.9, bucket_bytes: int = 32 << 20):
+        if name not in _KIND:
+            raise ValueError(f'Optimizer "{name}" not supported')
+        self.kind = _KIND[name]
+        self.name = name
+        params = [p for p in model.parameters() if p.requires_grad]
+        if not params or not params[0].is_cuda:
+            raise RuntimeError("FlatOptimizer needs the model on a HIP device")
+        dev = params[0].device
+        order = params[::-1]  # reverse forward order: first-ready gradients first
+        offs, total = [], 0
+        for p in order:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned
+        self.flat_param = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(total, device=dev, dtype=torch.float32) if self.kind != OPT_SGD else None
+        self.params, self.offsets = order, offs
+        with torch.no_grad():
+            for p, o in zip(order, offs):
+                n = p.numel()
+                self.flat_param[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat_param[o:o + n].view(p.shape)
+                p.grad = self.flat_grad[o:o + n].view(p.shape)
+        self.param_groups = [dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps, momentum=momentum)]
+        self.step_count = 0
+        self.last_norm: Optional[torch.Tensor] = None
+        # bucket table for data parallelism
+        nb = max(1, bucket_bytes // 4)
+        self.buckets: List[tuple] = []
+        start = 0
+        while start < total:
+            end = min(total, start + nb)
+            # extend to a parameter boundary
+            for o, p in zip(offs, order):
+                pe = o + (p.numel() + 3) // 4 * 4
+                if o < end <= pe:
+                    end = pe
+                    break
+            self.buckets.append((start, end))
+            start = end
+        self.param_bucket = []
+        for o in offs:
+            for bi, (s, e) in enumerate(self.buckets):
+                if s <= o < e:
+                    self.param_bucket.append(bi)
+                    break
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_grad.zero_()
+        for p, o in zip(self.params, self.offsets):  # re-attach if a caller detached the views
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def step(self, max_grad_norm: float = 0.0, grad_scale: float = 1.0):
+        g = self.param_groups[0]
+        self.step_count += 1
+        clip = None
+        if max_grad_norm and max_grad_norm > 0:
+            clip = ops.grad_norm(self.flat_grad, float(max_grad_norm), grad_scale)
+            self.last_norm = clip
+        b1, b2 = (g["momentum"], 0.0) if self.kind == OPT_SGD else g["betas"]
+        ops.optim_step(self.kind, self.flat_param, self.flat_grad, self.m, self.v, float(g["lr"]), b1, b2, g["eps"],
+                       float(g["weight_decay"]), self.step_count, clip, grad_scale)
+
+    def state_dict(self) -> Dict[str, object]:
+        return {"step": self.step_count, "m": self.m, "v": self.v, "param_groups": self.param_groups, "name": self.name}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["m"])
+        if self.v is not None and sd.get("v") is not None:
+            self.v.copy_(sd["v"])
+        self.param_groups[0].update({k: v for k, v in sd["param_groups"][0].items()})
+
+
+class GradBucketReducer:
+    """Bucketed all-reduce of FlatOptimizer.flat_grad overlapped with backward (one process per GPU)."""
+
+    def __init__(self, opt: FlatOptimizer, process_group=None):
+        self.opt = opt
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.pending = [0] * len(opt.buckets)
+        self.counts = [0] * len(opt.buckets)
+        for bi in opt.param_bucket:
+            self.counts[bi] += 1
+        self.works = []
+        self.handles = []
+        if self.world > 1:
+            for p, bi in zip(opt.params, opt.param_bucket):
+                self.handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+
+    def _make_hook(self, bi):
+        def hook(_p):
+            self.pending[bi] += 1
+            if self.pending[bi] == self.counts[bi]:
+                s, e = self.opt.buckets[bi]
+                self.works.append(dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        return hook
+
+    def start_step(self):
+        self.pending = [0] * len(self.pending)
+        self.works = []
+
+    def finish(self):
+        """Join every in-flight bucket; launch buckets whose hooks never fired (unused parameters)."""
+        if self.world == 1:
+            return
+        for bi, (s, e) in enumerate(self.opt.buckets):
+            if self.pending[bi] != self.counts[bi]:
+                self.works.append(dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+
+class TrainEngine:
+    """One object = model + loss + flat optimizer + poly LR (+ DP reducer).  ``train_step`` returns the loss
+    TENSOR (no host sync); call ``.item()`` only when you log."""
+
+    def __init__(self, model, loss_fn, optimizer_name: str = "adam", optimizer_kwargs: Optional[dict] = None,
+                 start_lr: float = 1e-3, num_iters: int = 4000, lr_warmup_iter: int = 250, lr_interval: int = 1,
+                 lr_scheduler_name: str = "poly", grad_norm: float = 10.0, process_group=None, bucket_bytes: int = 32 << 20):
+        self.model = model
+        self.loss_fn = loss_fn
+        kw = dict(optimizer_kwargs or {})
+        self.optimizer = FlatOptimizer(model, optimizer_name, bucket_bytes=bucket_bytes, **kw)
+        if lr_scheduler_name == "poly":
+            self.lr_scheduler = PolyLRScheduler(self.optimizer, initial_lr=start_lr, max_steps=num_iters,
+                                                warmup_steps=lr_warmup_iter, interval=lr_interval)
+        elif lr_scheduler_name == "none":
+            self.lr_scheduler = None
+        else:
+            raise ValueError(f'Learning rate scheduler "{lr_scheduler_name}" not supported')
+        self.grad_norm = grad_norm
+        self.reducer = GradBucketReducer(self.optimizer, process_group)
+        self.current_iter = 0
+
+    def train_step(self, sampled_batch) -> torch.Tensor:
+        self.model.train()
+        if self.lr_scheduler:
+            self.lr_scheduler.step(self.current_iter)
+        dev = self.optimizer.flat_param.device
+        image = sampled_batch["image"].to(dev, dtype=torch.float32, non_blocking=True)
+        label = sampled_batch["label"].to(dev, dtype=torch.long, non_blocking=True)
+        output = self.model(image)
+        loss = self.loss_fn(output, label)
+        self.optimizer.zero_grad()
+        self.reducer.start_step()
+        loss.backward()
+        self.reducer.finish()
+        self.optimizer.step(max_grad_norm=self.grad_norm, grad_scale=self.reducer.grad_scale)
+        self.current_iter += 1
+        return loss.detach()
+
+    @torch.no_grad()
+    def predict(self, image: torch.Tensor) -> torch.Tensor:
+        """valid_slices core (al_trainer.py:1428-1431): eval forward -> softmax -> argmax."""
+        self.model.eval()
+        out = self.model(image.to(self.optimizer.flat_param.device, dtype=torch.float32))
+        return out.softmax(1).argmax(1)

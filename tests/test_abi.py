@@ -25,7 +25,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     rc = l.mia_conv_mma(99, 0, None, 0, None, 0, None, 0, 0, 0, None, None, 0, None, 0, None, 1, 1, 1, 1, 1, None)
     assert rc < 0 and b"bad mode" in l.mia_last_error()
     with pytest.raises(mia_hip.MiaError):
-        mia_hip.call("mia_grad_norm", None, ctypes.c_int64(0), ctypes.c_float(1.0), None, None, None)
+        mia_hip.call("mia_grad_norm", None, ctypes.c_int64(0), ctypes.c_float(1.0), ctypes.c_float(1.0), None, None, None)
 
 
 def test_no_cpu_fallback():

@@ -173,8 +173,10 @@ def test_plain_block_fwd_bwd(norm, stride, c2, dtype):
     assert relerr(pd[0].grad, wr.grad) < tol * 2
     assert relerr(pd[2].grad, gr.grad) < tol * 2
     assert relerr(pd[3].grad, ber.grad) < tol * 2
-    # conv bias in front of a norm layer: gradient is analytically 0
-    assert pd[1].grad.abs().max().item() < 1e-3 * max(1.0, dz.abs().max().item()) * (50 if dtype == torch.bfloat16 else 1)
+    # conv bias in front of a norm layer: analytically 0 for instance norm (rounding noise in the reference),
+    # non-zero for batch norm with per-sample dropout masks -> compare with an absolute tolerance
+    bscale = max(1.0, br.grad.abs().max().item(), dz.abs().sum().sqrt().item())
+    assert (pd[1].grad.cpu() - br.grad).abs().max().item() < (2e-2 if dtype == torch.bfloat16 else 2e-5) * bscale
     if norm == "batch":
         assert relerr(rmd, rm) < 1e-4 + TOL[dtype] and relerr(rvd, rv) < 1e-4 + TOL[dtype] and int(nbt.item()) == 1
 
