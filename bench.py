@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Headline benchmark: training images/sec of the UNet-2D hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one full train step (lr schedule, forward, Dice+CE, backward, gradient all-reduce when
+N>1, clip-by-global-norm 10, Adam) on one synthetic minibatch that is resident in HBM before the
+timed region.  Workload (BASELINE.json metric / configs[2]): UNet channels [64,128,256,512,1024],
+512x512 1-channel, batch 32 per GPU, bf16 activations / MFMA operands with fp32 accumulation,
+statistics, parameters, logits and loss.  Weak scaling: per-GPU batch is fixed.
+
+One JSON line on rank 0 with `roofline` (dominant kernel: the full-resolution C0->C0 3x3 conv launch,
+timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle's train step --
+oracle/train_ref.py, a port of the reference loop validated against the reference -- on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "medical-image-analysis_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: (channels_list, size, per-GPU batch, compute dtype)
+    "cfg1": ([16, 32, 64], 128, 4, "f32"),
+    "cfg2": ([64, 128, 256, 512, 1024], 256, 32, "f32"),
+    "cfg3": ([64, 128, 256, 512, 1024], 512, 32, "bf16"),
+    "cfg4": ([32, 64, 128, 256, 512], 256, 32, "f32"),
+    "cfg5": ([96, 192, 384, 768, 1536, 3072], 768, 16, "bf16"),
+}
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(b, s, seed, k1=3):
+    """Images U[0,1); FUGC-shaped masks: two disjoint filled ellipses (classes 1, 2), background 0."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(b, 1, s, s, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(s, dtype=torch.float32), torch.arange(s, dtype=torch.float32), indexing="ij")
+    lab = torch.zeros(b, s, s, dtype=torch.long)
+    for i in range(b):
+        r = torch.rand(8, generator=g)
+        for cls, (cx, cy, ax, ay) in enumerate([(0.3 + 0.1 * r[0], 0.35 + 0.3 * r[1], 0.10 + 0.06 * r[2], 0.14 + 0.08 * r[3]),
+                                                (0.7 - 0.1 * r[4], 0.35 + 0.3 * r[5], 0.10 + 0.06 * r[6], 0.14 + 0.08 * r[7])], start=1):
+            m = ((xx / s - cx) / ax) ** 2 + ((yy / s - cy) / ay) ** 2 <= 1.0
+            lab[i][m] = min(cls, k1 - 1)
+    return img, lab
+
+
+def cpu_baseline(channels, size, budget_s=25.0):
+    """Oracle train step (port of al_trainer.py:1350-1381) on the host cores, bounded sample."""
+    from oracle import train_ref, unet_ref
+    torch.manual_seed(1337)
+    p = unet_ref.init_params(1, 3, channels, "instance")
+    opt = train_ref.make_optimizer(p, "adam", weight_decay=5e-4)
+    bs = 1
+    img, lab = synth_batch(bs, size, 1337)
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    train_ref.train_step(p, opt, img, lab, 2, "instance", lr=1e-3)  # warm-up (also sizes the sample)
+    first = time.time() - t0
+    steps = max(1, min(5, int(budget_s / max(first, 1e-3)) - 1))
+    t0 = time.time()
+    for _ in range(steps):
+        train_ref.train_step(p, opt, img, lab, 2, "instance", lr=1e-3)
+    dt = (time.time() - t0) / steps
+    return {"value": bs / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{steps} timed train steps (+1 warm-up) of the same UNet at {size}x{size}, batch {bs}, fp32, PyTorch-CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32"])
+    ap.add_argument("--norm", default="instance", choices=["instance", "batch"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from losses.compound_losses import DiceAndCELoss
+    from losses.dice_loss import DiceLoss
+    from mia_hip import CONV_G3S1, ops
+    from models.unet import UNet
+    from training.engine import TrainEngine
+
+    channels, size, batch, dt = CONFIGS[args.config]
+    batch = args.batch or batch
+    dt = args.dtype or dt
+    torch.manual_seed(1337)  # identical weights on every rank
+    model = UNet(2, 1, 3, channels, normalization=args.norm, dropout_prob=None).to(dev)
+    model.set_compute_dtype(torch.bfloat16 if dt == "bf16" else torch.float32)
+    loss_fn = DiceAndCELoss(dice_loss=DiceLoss, dice_kwargs=dict(num_classes=2, smooth=1e-5, do_bg=True, softmax=True,
+                                                                 batch=False, squared=False),
+                            ce_loss=torch.nn.CrossEntropyLoss, ce_kwargs={})
+    eng = TrainEngine(model, loss_fn, "adam", {"weight_decay": 5e-4}, start_lr=1e-3, num_iters=4000, lr_warmup_iter=250)
+    img, lab = synth_batch(batch, size, 1337 + rank)
+    batch_d = {"image": img.to(dev), "label": lab.to(dev)}  # resident in HBM before timing
+
+    c0 = channels[0]
+    probe = ops.LaunchProbe(lambda mode, c1, c2, nout, h, w, flip: mode == CONV_G3S1 and c1 == c0 and c2 == 0 and nout == c0
+                            and h == size and not flip)
+    ops.PROBE = probe
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = eng.train_step(batch_d)
+    sync()
+    probe.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = eng.train_step(batch_d)
+    sync()
+    elapsed = time.perf_counter() - t0
+    probe.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_v = float(loss.item())
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        value = world * batch * args.steps / elapsed
+        kt = probe.times_ms()
+        roof = None
+        if kt:
+            avg_ms = sum(kt) / len(kt)
+            flops = 2.0 * 9 * c0 * c0 * size * size * batch
+            esz = 2 if dt == "bf16" else 4
+            abytes = 2.0 * c0 * size * size * batch * esz + 9 * c0 * c0 * esz
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS[dt], "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_MFMA_TFLOPS[dt], 4), "traffic": None,
+                    "kernel": f"conv_mma_kernel<{dt},G3S1,MT4,NT4> {c0}->{c0} 3x3 @{size}x{size} x{batch} (encoder.levels.0.1)",
+                    "avg_launch_ms": round(avg_ms, 4), "launches": len(kt), "flops_per_launch": flops,
+                    "algorithmic_bytes_per_launch": abytes,
+                    "hbm_frac_of_block_bytes": round(abytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+        out = {"metric": "training images/sec (whole node), UNet 512x512 1ch bs=32/GPU", "value": round(value, 2),
+               "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
+               "config": {"workload": f"UNet-2D channels {channels} {size}x{size} 1ch, batch {batch}/GPU, {args.norm} norm, "
+                                      f"dropout None, Dice+CE, Adam(wd 5e-4), clip 10 ({args.config})",
+                          "global_batch": world * batch, "parallelism": f"dp{world}"},
+               "final_loss": round(loss_v, 6), "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(channels, size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,56 @@
+// Shared geometry / MFMA helpers of the implicit-GEMM conv kernels (conv_mma.hip, conv_mma_fast.hip).
+#pragma once
+#include "common.h"
+
+enum { MODE_G3S1 = 0, MODE_G3S2 = 1, MODE_G2S2 = 2, MODE_T3S2 = 3, MODE_T2S2 = 4, MODE_G1 = 5 };
+
+struct ConvArgs {
+  const void* in1; const void* in2; int c1; int c2;
+  const void* wp; const float* bias;
+  void* out1; void* out2; int o1; int o2;
+  float* stats;
+  int N, Hin, Win, Hout, Wout;
+  int npad, kpad, flip;
+  int tiles_x, tiles_y, nblk_n;
+  int vec_in, vec_out;
+};
+
+__device__ __forceinline__ int pi16(int r) {
+  // rows 4..11 <-> even pixels, rows 0..3 / 12..15 <-> odd pixels (see header comment)
+  return (r >= 4 && r < 12) ? 2 * (r - 4) : (r < 4 ? 2 * r + 1 : 2 * (r - 8) + 1);
+}
+
+template <int MODE, int MT> struct Geo {
+  static constexpr int TH = 4 * MT;
+  static constexpr int S = (MODE == MODE_G3S2 || MODE == MODE_G2S2) ? 2 : 1;
+  static constexpr int IH = MODE == MODE_G3S1 ? TH + 2 : MODE == MODE_G3S2 ? 2 * TH + 1 : MODE == MODE_G2S2 ? 2 * TH
+                          : MODE == MODE_T3S2 ? TH + 1 : TH;
+  static constexpr int IW = MODE == MODE_G3S1 ? 18 : MODE == MODE_G3S2 ? 33 : MODE == MODE_G2S2 ? 32
+                          : MODE == MODE_T3S2 ? 17 : 16;
+  static constexpr int IWH = (S == 2) ? (IW + 1) / 2 : 0;
+  static constexpr int PITCH = (S == 2) ? 2 * IWH : IW;
+  static constexpr int NPIX = IH * PITCH;
+  static constexpr int NPA = ((NPIX + 13) / 16) * 16 + 2;  // >= NPIX, == 2 (mod 16)
+  static constexpr int MAXTAPS = (MODE == MODE_G3S1 || MODE == MODE_G3S2) ? 9 : (MODE == MODE_G2S2 || MODE == MODE_T3S2) ? 4 : 1;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, f32x4 c) {
+    const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], c, 0, 0, 0);
+    return c;
+  }
+};
+
+
+// conv_mma_fast.hip: branch-free variant (buffer loads/stores with hardware OOB zero-fill); returns false when the
+// shape does not meet its alignment contract and the generic kernel must be used.
+bool conv_mma_fast_eligible(int dtype, const ConvArgs& a, int nt);
+int conv_mma_fast_launch(int mode, int dtype, const ConvArgs& a, int mt, int nt, int grid_y, hipStream_t st);

@@ -18,57 +18,10 @@
 // bf16: v_mfma_f32_16x16x32_bf16, one per 32-channel block; fp32: 4 x v_mfma_f32_16x16x4_f32 per
 // 16-channel block (exact fp32 fma chains).  Epilogue: +bias, optional per-(image,tile,channel)
 // sum / sum-of-squares partials for the norm layer, tile transposed through LDS, 16-byte stores.
-#include "common.h"
-
-enum { MODE_G3S1 = 0, MODE_G3S2 = 1, MODE_G2S2 = 2, MODE_T3S2 = 3, MODE_T2S2 = 4, MODE_G1 = 5 };
-
-struct ConvArgs {
-  const void* in1; const void* in2; int c1; int c2;
-  const void* wp; const float* bias;
-  void* out1; void* out2; int o1; int o2;
-  float* stats;
-  int N, Hin, Win, Hout, Wout;
-  int npad, kpad, flip;
-  int tiles_x, tiles_y, nblk_n;
-  int vec_in, vec_out;
-};
-
-__device__ __forceinline__ int pi16(int r) {
-  // rows 4..11 <-> even pixels, rows 0..3 / 12..15 <-> odd pixels (see header comment)
-  return (r >= 4 && r < 12) ? 2 * (r - 4) : (r < 4 ? 2 * r + 1 : 2 * (r - 8) + 1);
-}
-
-template <int MODE, int MT> struct Geo {
-  static constexpr int TH = 4 * MT;
-  static constexpr int S = (MODE == MODE_G3S2 || MODE == MODE_G2S2) ? 2 : 1;
-  static constexpr int IH = MODE == MODE_G3S1 ? TH + 2 : MODE == MODE_G3S2 ? 2 * TH + 1 : MODE == MODE_G2S2 ? 2 * TH
-                          : MODE == MODE_T3S2 ? TH + 1 : TH;
-  static constexpr int IW = MODE == MODE_G3S1 ? 18 : MODE == MODE_G3S2 ? 33 : MODE == MODE_G2S2 ? 32
-                          : MODE == MODE_T3S2 ? 17 : 16;
-  static constexpr int IWH = (S == 2) ? (IW + 1) / 2 : 0;
-  static constexpr int PITCH = (S == 2) ? 2 * IWH : IW;
-  static constexpr int NPIX = IH * PITCH;
-  static constexpr int NPA = ((NPIX + 13) / 16) * 16 + 2;  // >= NPIX, == 2 (mod 16)
-  static constexpr int MAXTAPS = (MODE == MODE_G3S1 || MODE == MODE_G3S2) ? 9 : (MODE == MODE_G2S2 || MODE == MODE_T3S2) ? 4 : 1;
-};
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  static __device__ __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  static __device__ __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, f32x4 c) {
-    const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], c, 0, 0, 0);
-    return c;
-  }
-};
+#include "conv_common.h"
 
 template <typename T, int MODE, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_mma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_mma_kernel(const ConvArgs a) {
   using G = Geo<MODE, MT>;
   constexpr int TH = G::TH, BN = 16 * NT, EPU = Elem<T>::EPU, KB = 4 * EPU;
   constexpr int NPA = G::NPA, NPB = BN + 2, PITCH = G::PITCH, S = G::S, IW = G::IW, IH = G::IH;
@@ -129,20 +82,44 @@ __global__ __launch_bounds__(256) void conv_mma_kernel(const ConvArgs a) {
   const T* in2 = static_cast<const T*>(a.in2);
   const T* wp = static_cast<const T*>(a.wp);
 
-  for (int c0 = 0; c0 < ctot; c0 += KB) {
-    // ---- stage input halo tile: unit u -> (pixel, channel group g); g fastest => 64 contiguous bytes per pixel
-    for (int u = tid; u < IH * IW * 4; u += 256) {
-      const int g = u & 3, pix = u >> 2;
+  // ---- software pipeline: chunk k+1 is fetched global -> VGPR while chunk k's MFMAs run from LDS
+  constexpr int A_N = IH * IW * 4, A_IT = (A_N + 255) / 256;
+  constexpr int B_NMAX = G::MAXTAPS * 4 * BN, B_IT = (B_NMAX + 255) / 256;
+  const int ntaps = nth * ntw;
+  const int b_n = ntaps * 4 * BN;
+  // chunk-invariant addressing of this thread's staging units (32-bit element offsets; LDS slots are recomputed)
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  unsigned a_pix[A_IT];  // global pixel index, OOB = outside the image / not owned (zero fill)
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int u = tid + i * 256;
+    a_pix[i] = OOB;
+    if (u < A_N) {
+      const int pix = u >> 2;
       const int iy = pix / IW, ix = pix - iy * IW;
-      const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + g * EPU;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      if (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) a_pix[i] = (unsigned)(((int64_t)img * a.Hin + gy) * a.Win + gx);
+    }
+  }
+  auto b_src = [&](int u) -> size_t {  // element offset into wp of (tap, n0+n, 0) + g*EPU (recomputed: saves VGPRs)
+    const int g = u & 3, n = (u >> 2) % BN, tl = u / (4 * BN);
+    const int ta = tl / ntw, tb = tl - ta * ntw;
+    return ((size_t)tap_w(ta, tb) * a.npad + n0 + n) * a.kpad + g * EPU;
+  };
+  u32x4 pa[A_IT], pb[B_IT];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int g = (tid + i * 256) & 3;
+      const int c = c0 + g * EPU;
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win && c < ctot) {
-        const size_t p = ((size_t)img * a.Hin + gy) * a.Win + gx;
+      if (a_pix[i] != OOB && c < ctot) {
+        const size_t p = a_pix[i];
         if (a.vec_in) {
           const T* src = (c < a.c1) ? in1 + p * a.c1 + c : in2 + p * a.c2 + (c - a.c1);
           v = *reinterpret_cast<const u32x4*>(src);
         } else {
-          T tmp[EPU];
+          alignas(16) T tmp[EPU];
 #pragma unroll
           for (int e = 0; e < EPU; ++e) {
             const int ce = c + e;
@@ -154,18 +131,35 @@ __global__ __launch_bounds__(256) void conv_mma_kernel(const ConvArgs a) {
           v = *reinterpret_cast<const u32x4*>(tmp);
         }
       }
-      const int lidx = (S == 2) ? iy * PITCH + (ix & 1) * G::IWH + (ix >> 1) : iy * PITCH + ix;
-      ldsA[g * NPA + lidx] = v;
+      pa[i] = v;
     }
-    // ---- stage weights for this chunk: [tap][group][n]
-    const int ntaps = nth * ntw;
-    for (int u = tid; u < ntaps * 4 * BN; u += 256) {
-      const int g = u & 3, n = (u >> 2) % BN, tl = u / (4 * BN);
-      const int ta = tl / ntw, tb = tl - ta * ntw;
-      const T* src = wp + ((size_t)tap_w(ta, tb) * a.npad + n0 + n) * a.kpad + c0 + g * EPU;
-      ldsB[(tl * 4 + g) * NPB + n] = *reinterpret_cast<const u32x4*>(src);
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i)
+      if (tid + i * 256 < b_n) pb[i] = *reinterpret_cast<const u32x4*>(wp + b_src(tid + i * 256) + c0);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int u = tid + i * 256;
+      if (u < A_N) {
+        const int pix = u >> 2;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int lidx = (S == 2) ? iy * PITCH + (ix & 1) * G::IWH + (ix >> 1) : iy * PITCH + ix;
+        ldsA[(u & 3) * NPA + lidx] = pa[i];
+      }
     }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int u = tid + i * 256;
+      if (u < b_n) ldsB[((u / (4 * BN)) * 4 + (u & 3)) * NPB + ((u >> 2) % BN)] = pb[i];
+    }
+  };
+
+  fetch(0);
+  for (int c0 = 0; c0 < ctot; c0 += KB) {
+    commit();
     __syncthreads();
+    if (c0 + KB < ctot) fetch(c0 + KB);
 
     // ---- MFMA over taps
     for (int ta = 0; ta < nth; ++ta) {
@@ -341,7 +335,9 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
   const bool tmode = (mode == MODE_T3S2 || mode == MODE_T2S2);
   const int grid_y = tmode ? 4 : 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);
+  int rc;
+  if (conv_mma_fast_eligible(dtype, a, nt)) rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
+  else rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);
   if (rc != MIA_OK) return rc;
   MIA_LAUNCH_CHECK();
   return MIA_OK;

@@ -1,0 +1,287 @@
+// Branch-free fast path of the implicit-GEMM conv (same math / tiling / LDS layout as conv_mma.hip).
+//
+// The generic kernel spends most of its issue slots on per-element predicates (image border, channel
+// tails, two-source select) -- rocprofv3 showed SQ_ACTIVE_INST_ANY ~3x the MFMA issue time.  Here every
+// global access is a raw buffer load/store against a per-image descriptor, so the image border and the
+// tile tail become an out-of-range offset that the hardware turns into a zero (loads) or a dropped write
+// (stores); channel chunks never straddle a source; all staging addresses are "thread constant +
+// compile-time immediate"; the epilogue writes LDS at immediate offsets.  Contract (checked on the host,
+// otherwise the generic kernel runs): c1 % KB == 0, c2 % KB == 0, o1 % EPU == 0, o1 % BN == 0 when the
+// output is split, 16-byte aligned pointers, per-image tensors < 2 GiB.
+#include "conv_common.h"
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define SENT 0xFFFFFFF0u /* always beyond num_records */
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <typename T, int MODE, int MT, int NT>
+__global__ __launch_bounds__(256, 2) void conv_mma_fast_kernel(const ConvArgs a) {
+  using G = Geo<MODE, MT>;
+  constexpr int TH = G::TH, BN = 16 * NT, EPU = Elem<T>::EPU, KB = 4 * EPU, ES = (int)sizeof(T);
+  constexpr int PITCH = G::PITCH, S = G::S, IW = G::IW, IH = G::IH;
+  constexpr int A_IT = (IH * IW + 63) / 64;  // 64 pixels (x 4 channel groups) per staging iteration
+  constexpr int NPIX_ALLOC = (S == 1) ? (A_IT * 64 > G::NPIX ? A_IT * 64 : G::NPIX) : G::NPIX + 1;  // S==2: +1 dummy slot
+  constexpr int NPA = ((NPIX_ALLOC + 13) / 16) * 16 + 2;
+  constexpr int NPB = BN + 2;
+  constexpr int TPI = 64 / BN;  // taps staged per iteration
+  constexpr int B_IT = (G::MAXTAPS + TPI - 1) / TPI;
+  constexpr int OSTR = BN + EPU;
+  constexpr int A_UNITS = 4 * NPA, B_UNITS = B_IT * TPI * 4 * NPB;
+  constexpr int STAGE_BYTES = (A_UNITS + B_UNITS) * 16;
+  constexpr int OUT_BYTES = TH * 16 * OSTR * ES;
+  constexpr int LDS_BYTES = STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + 2 * 4 * BN * 4];
+  u32x4* ldsA = reinterpret_cast<u32x4*>(smem);
+  u32x4* ldsB = ldsA + A_UNITS;
+  T* ldsO = reinterpret_cast<T*>(smem);
+  float* ldsR = reinterpret_cast<float*>(smem + LDS_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, r16 = lane & 15;
+  const int pr = pi16(r16);
+  const int g = tid & 3, p4 = tid >> 2;
+
+  int bid = blockIdx.x;
+  const int nb = bid % a.nblk_n; bid /= a.nblk_n;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; bid /= a.tiles_y;
+  const int img = bid;
+  const int n0 = nb * BN;
+  constexpr bool TMODE = (MODE == MODE_T3S2 || MODE == MODE_T2S2);
+  const int ph = TMODE ? (int)(blockIdx.y >> 1) : 0;
+  const int pw = TMODE ? (int)(blockIdx.y & 1) : 0;
+  const int oy0 = ty * TH, ox0 = tx * 16;
+  const int iy0 = MODE == MODE_G3S1 ? oy0 - 1 : MODE == MODE_G3S2 ? 2 * oy0 - 1 : MODE == MODE_G2S2 ? 2 * oy0 : oy0;
+  const int ix0 = MODE == MODE_G3S1 ? ox0 - 1 : MODE == MODE_G3S2 ? 2 * ox0 - 1 : MODE == MODE_G2S2 ? 2 * ox0 : ox0;
+
+  const int nth = (MODE == MODE_G3S1 || MODE == MODE_G3S2) ? 3 : MODE == MODE_G2S2 ? 2 : MODE == MODE_T3S2 ? (ph ? 2 : 1) : 1;
+  const int ntw = (MODE == MODE_G3S1 || MODE == MODE_G3S2) ? 3 : MODE == MODE_G2S2 ? 2 : MODE == MODE_T3S2 ? (pw ? 2 : 1) : 1;
+  const int ntaps = nth * ntw;
+  auto tap_w = [&](int ta, int tb) -> int {
+    if (MODE == MODE_G3S1) { const int t = ta * 3 + tb; return a.flip ? 8 - t : t; }
+    if (MODE == MODE_G3S2) return ta * 3 + tb;
+    if (MODE == MODE_G2S2) return ta * 2 + tb;
+    if (MODE == MODE_T3S2) { const int kh = ph ? (ta == 0 ? 0 : 2) : 1; const int kw = pw ? (tb == 0 ? 0 : 2) : 1; return kh * 3 + kw; }
+    if (MODE == MODE_T2S2) return ph * 2 + pw;
+    return 0;
+  };
+  auto tap_off = [&](int ta, int tb) -> int {
+    if (MODE == MODE_G3S1) return ta * PITCH + tb;
+    if (MODE == MODE_G3S2 || MODE == MODE_G2S2) return ta * PITCH + (tb & 1) * G::IWH + (tb >> 1);
+    if (MODE == MODE_T3S2) { const int dh = ph ? (ta == 0 ? 1 : 0) : 0; const int dw = pw ? (tb == 0 ? 1 : 0) : 0; return dh * PITCH + dw; }
+    return 0;
+  };
+
+  const int ctot = a.c1 + a.c2;
+  const T* in1 = static_cast<const T*>(a.in1);
+  const T* in2 = static_cast<const T*>(a.in2);
+  const size_t ipix = (size_t)a.Hin * a.Win;
+  const rsrc_t rs1 = make_rsrc(in1 + (size_t)img * ipix * a.c1, (unsigned)(ipix * a.c1 * ES));
+  const rsrc_t rs2 = make_rsrc(a.c2 ? in2 + (size_t)img * ipix * a.c2 : in1, (unsigned)(ipix * (a.c2 ? a.c2 : 0) * ES));
+  constexpr int WTAPS = (MODE == MODE_G3S1 || MODE == MODE_G3S2 || MODE == MODE_T3S2) ? 9 : (MODE == MODE_G1 ? 1 : 4);
+  const rsrc_t rsw = make_rsrc(a.wp, (unsigned)((size_t)WTAPS * a.npad * a.kpad * ES));
+
+  // ---- thread-constant staging addresses
+  unsigned a_pixoff[A_IT];
+  unsigned a_valid = 0;
+  int a_lds[S == 2 ? A_IT : 1];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int pix = p4 + 64 * i;
+    const int iy = pix / IW, ix = pix - iy * IW;
+    const int gy = iy0 + iy, gx = ix0 + ix;
+    const bool ok = pix < IH * IW && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+    a_pixoff[i] = (unsigned)(gy * a.Win + gx);
+    a_valid |= (ok ? 1u : 0u) << i;
+    if (S == 2) a_lds[i] = pix < IH * IW ? iy * PITCH + (ix & 1) * G::IWH + (ix >> 1) : G::NPIX;
+  }
+  const int bn_ = p4 % BN, tsub = p4 / BN;
+  unsigned b_voff[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int tl = i * TPI + tsub;
+    const int ta = tl / ntw, tb = tl - ta * ntw;
+    b_voff[i] = tl < ntaps ? (unsigned)((((size_t)tap_w(ta, tb) * a.npad + n0 + bn_) * a.kpad + g * EPU) * ES) : SENT;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 pa[A_IT], pb[B_IT];
+  auto fetch = [&](int c0) {
+    const bool second = c0 >= a.c1;  // uniform: chunks never straddle the two sources
+    const rsrc_t rs = second ? rs2 : rs1;
+    const unsigned cs_es = (unsigned)((second ? a.c2 : a.c1) * ES);
+    const int soff = (second ? c0 - a.c1 : c0) * ES;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const unsigned voff = ((a_valid >> i) & 1u) ? a_pixoff[i] * cs_es + (unsigned)(g * 16) : SENT;
+      pa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)b_voff[i], c0 * ES, 0);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) ldsA[g * NPA + (S == 2 ? a_lds[i] : p4 + 64 * i)] = pa[i];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) ldsB[((i * TPI + tsub) * 4 + g) * NPB + bn_] = pb[i];
+  };
+
+  fetch(0);
+  for (int c0 = 0; c0 < ctot; c0 += KB) {
+    commit();
+    __syncthreads();
+    if (c0 + KB < ctot) fetch(c0 + KB);
+    for (int ta = 0; ta < nth; ++ta) {
+      for (int tb = 0; tb < ntw; ++tb) {
+        const int tl = ta * ntw + tb;
+        const int toff = tap_off(ta, tb);
+        u32x4 bf[NT], af[MT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bf[n] = ldsB[(tl * 4 + q) * NPB + n * 16 + pr];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = ldsA[q * NPA + S * (wave * MT + m) * PITCH + toff + pr];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = Mma<T>::run(af[m], bf[n], acc[m][n]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  const int hd = TMODE ? (a.Hout - ph + 1) / 2 : a.Hout;
+  const int wd = TMODE ? (a.Wout - pw + 1) / 2 : a.Wout;
+  const int nout = a.o1 + a.o2;
+  float bv[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    int bi = n0 + n * 16 + pr;
+    bi = bi < nout ? bi : nout - 1;
+    bv[n] = a.bias ? a.bias[bi] : 0.f;
+  }
+  int rowoff[4];
+  float cmask[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int px = pi16(4 * q + r);
+    rowoff[r] = (wave * MT * 16 + px) * OSTR + pr;
+    cmask[r] = (ox0 + px < wd) ? 1.f : 0.f;
+  }
+  const bool full = (oy0 + TH <= hd) && (ox0 + 16 <= wd);
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) { s1[n] = 0.f; s2[n] = 0.f; }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const float rm = (oy0 + wave * MT + m < hd) ? 1.f : 0.f;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[m][n][r] + bv[n];
+        if (a.stats != nullptr) {
+          const float vm = full ? v : v * (rm * cmask[r]);
+          s1[n] += vm; s2[n] += vm * v;
+        }
+        ldsO[rowoff[r] + m * 16 * OSTR + n * 16] = Elem<T>::cvt(v);
+      }
+    }
+  }
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      float t1 = s1[n], t2 = s2[n];
+      t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
+      t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
+      if (q == 0) { ldsR[(0 * 4 + wave) * BN + n * 16 + pr] = t1; ldsR[(1 * 4 + wave) * BN + n * 16 + pr] = t2; }
+    }
+  }
+  __syncthreads();
+  if (a.stats != nullptr && tid < BN && n0 + tid < nout) {
+    const float t1 = ldsR[0 * BN + tid] + ldsR[1 * BN + tid] + ldsR[2 * BN + tid] + ldsR[3 * BN + tid];
+    const float t2 = ldsR[4 * BN + tid] + ldsR[5 * BN + tid] + ldsR[6 * BN + tid] + ldsR[7 * BN + tid];
+    const size_t tile = (size_t)img * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx;
+    float* dst = a.stats + (tile * nout + n0 + tid) * 2;
+    dst[0] = t1; dst[1] = t2;
+  }
+  // coalesced 16-byte stores; the block's channel range lies in exactly one destination
+  constexpr int UPP = BN / EPU, PPI = 256 / UPP, O_IT = TH * 16 / PPI;
+  const bool second = n0 >= a.o1;
+  const int cn = second ? a.o2 : a.o1;
+  T* obase = second ? static_cast<T*>(a.out2) : static_cast<T*>(a.out1);
+  const size_t opix = (size_t)a.Hout * a.Wout;
+  const rsrc_t rso = make_rsrc(obase + (size_t)img * opix * cn, (unsigned)(opix * cn * ES));
+  const int cu = tid % UPP, pl0 = tid / UPP;
+  const int y0 = pl0 >> 4, px = pl0 & 15;
+  const int nloc = (second ? n0 - a.o1 : n0) + cu * EPU;
+  const bool colok = (ox0 + px < wd) && (n0 + cu * EPU < nout);
+  const int ox = TMODE ? 2 * (ox0 + px) + pw : ox0 + px;
+#pragma unroll
+  for (int i = 0; i < O_IT; ++i) {
+    const int y = y0 + i * (PPI / 16);
+    const int oy = TMODE ? 2 * (oy0 + y) + ph : oy0 + y;
+    const unsigned voff = (colok && oy0 + y < hd) ? (unsigned)((((size_t)oy * a.Wout + ox) * cn + nloc) * ES) : SENT;
+    const u32x4 d = *reinterpret_cast<const u32x4*>(ldsO + (pl0 + i * PPI) * OSTR + cu * EPU);
+    __builtin_amdgcn_raw_buffer_store_b128(d, rso, (int)voff, 0, 0);
+  }
+}
+
+template <typename T, int MODE, int MT, int NT>
+static void flaunch(const ConvArgs& a, int grid_y, hipStream_t st) {
+  const int grid_x = a.N * a.tiles_x * a.tiles_y * a.nblk_n;
+  hipLaunchKernelGGL((conv_mma_fast_kernel<T, MODE, MT, NT>), dim3(grid_x, grid_y), dim3(256), 0, st, a);
+}
+template <typename T, int MODE, int MT>
+static void flaunch_nt(const ConvArgs& a, int nt, int grid_y, hipStream_t st) {
+  if (nt == 4) flaunch<T, MODE, MT, 4>(a, grid_y, st);
+  else if (nt == 2) flaunch<T, MODE, MT, 2>(a, grid_y, st);
+  else flaunch<T, MODE, MT, 1>(a, grid_y, st);
+}
+template <typename T, int MODE>
+static void flaunch_mt(const ConvArgs& a, int mt, int nt, int grid_y, hipStream_t st) {
+  if constexpr (MODE == MODE_G3S2 || MODE == MODE_G2S2) {
+    flaunch_nt<T, MODE, 2>(a, nt, grid_y, st);
+  } else {
+    if (mt == 4) flaunch_nt<T, MODE, 4>(a, nt, grid_y, st);
+    else flaunch_nt<T, MODE, 2>(a, nt, grid_y, st);
+  }
+}
+template <typename T>
+static int fdispatch(int mode, const ConvArgs& a, int mt, int nt, int grid_y, hipStream_t st) {
+  switch (mode) {
+    case MODE_G3S1: flaunch_mt<T, MODE_G3S1>(a, mt, nt, grid_y, st); break;
+    case MODE_G3S2: flaunch_mt<T, MODE_G3S2>(a, mt, nt, grid_y, st); break;
+    case MODE_G2S2: flaunch_mt<T, MODE_G2S2>(a, mt, nt, grid_y, st); break;
+    case MODE_T3S2: flaunch_mt<T, MODE_T3S2>(a, mt, nt, grid_y, st); break;
+    case MODE_T2S2: flaunch_mt<T, MODE_T2S2>(a, mt, nt, grid_y, st); break;
+    case MODE_G1: flaunch_mt<T, MODE_G1>(a, mt, nt, grid_y, st); break;
+    default: return MIA_EARG;
+  }
+  return MIA_OK;
+}
+
+bool conv_mma_fast_eligible(int dtype, const ConvArgs& a, int nt) {
+  const int epu = dtype == MIA_BF16 ? 8 : 4, kb = 4 * epu, es = dtype == MIA_BF16 ? 2 : 4, bn = 16 * nt;
+  if (!a.vec_in || !a.vec_out) return false;
+  if (a.c1 % kb != 0 || a.c2 % kb != 0) return false;
+  if (a.o2 != 0 && (a.o1 % bn != 0)) return false;
+  const size_t lim = (size_t)1 << 31;
+  const size_t ipix = (size_t)a.Hin * a.Win, opix = (size_t)a.Hout * a.Wout;
+  if (ipix * (a.c1 > a.c2 ? a.c1 : a.c2) * es >= lim) return false;
+  if (opix * (a.o1 > a.o2 ? a.o1 : a.o2) * es >= lim) return false;
+  if ((size_t)9 * a.npad * a.kpad * es >= lim) return false;
+  return true;
+}
+
+int conv_mma_fast_launch(int mode, int dtype, const ConvArgs& a, int mt, int nt, int grid_y, hipStream_t st) {
+  return dtype == MIA_BF16 ? fdispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : fdispatch<float>(mode, a, mt, nt, grid_y, st);
+}

@@ -128,6 +128,20 @@ def cast_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ raw op wrappers
+class LaunchProbe:
+    """Brackets matching conv_mma launches with HIP events on the launch stream (bench.py roofline leg)."""
+
+    def __init__(self, match):
+        self.match, self.pairs, self.enabled = match, [], False
+
+    def times_ms(self):
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in self.pairs]
+
+
+PROBE: Optional[LaunchProbe] = None
+
+
 def conv_tiles(mode: int, hout: int, wout: int) -> int:
     ty, tx, th = _c_int(), _c_int(), _c_int()
     call("mia_conv_mma_tiles", mode, hout, wout, ctypes.byref(ty), ctypes.byref(tx), ctypes.byref(th))
@@ -150,8 +164,15 @@ def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: tor
     stats = None
     if want_stats:
         stats = torch.empty((n, conv_tiles(mode, hout, wout), nout, 2), device=x1.device, dtype=torch.float32)
+    probe = PROBE if (PROBE is not None and PROBE.enabled and PROBE.match(mode, c1, c2, nout, hin, win, bool(flip))) else None
+    if probe is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("mia_conv_mma", mode, _dt(x1), _p(x1), c1, _p(x2), c2, _p(wpack), npad, kpad, int(flip), _p(bias), _p(out1), o1,
          _p(out2), o2, _p(stats), n, hin, win, hout, wout, _stream())
+    if probe is not None:
+        e1.record()
+        probe.pairs.append((e0, e1))
     return out1, out2, stats
 
 

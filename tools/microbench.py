@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Isolated kernel micro-benchmarks for profiling (rocprofv3 --pmc / --kernel-trace).
+
+    python tools/microbench.py conv   --c 64 --size 512 --batch 32 --dtype bf16 --iters 5
+    python tools/microbench.py wgrad  --c 64 --size 512 --batch 32
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "medical-image-analysis_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["conv", "dgrad", "wgrad", "block"])
+    ap.add_argument("--c", type=int, default=64)
+    ap.add_argument("--cout", type=int, default=None)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--stride", type=int, default=1)
+    a = ap.parse_args()
+    from mia_hip import CONV_G3S1, CONV_G3S2, WGRAD_3S1, WGRAD_3S2, ops
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    cout = a.cout or a.c
+    s, so = a.size, a.size // a.stride
+    x = torch.randn(a.batch, s, s, a.c, device=dev).to(dt)
+    dy = torch.randn(a.batch, so, so, cout, device=dev).to(dt)
+    w = torch.randn(cout, a.c, 3, 3, device=dev) * 0.05
+    b = torch.zeros(cout, device=dev)
+    pc = ops.PackCache()
+    wp, npad, kpad = pc.get(w, ops._dt(dt), True)
+    wb, npb, kpb = pc.get(w, ops._dt(dt), False)
+
+    def run():
+        if a.what == "conv":
+            ops.conv_mma(CONV_G3S2 if a.stride == 2 else CONV_G3S1, x, None, wp, npad, kpad, False, b, cout, (so, so), want_stats=True)
+        elif a.what == "dgrad":
+            ops.conv_mma(CONV_G3S1, dy, None, wb, npb, kpb, True, None, a.c, (s, s))
+        elif a.what == "wgrad":
+            ops.conv_wgrad(WGRAD_3S2 if a.stride == 2 else WGRAD_3S1, x, None, dy, w.shape, cout, a.c)
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / a.iters * 1e3
+    fl = 2.0 * 9 * a.c * cout * so * so * a.batch
+    print(f"{a.what} c={a.c}->{cout} {s}x{s} b={a.batch} {a.dtype}: {ms:.3f} ms/iter  {fl / ms / 1e9:.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
