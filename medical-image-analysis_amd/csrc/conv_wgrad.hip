@@ -174,6 +174,137 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgs a) {
       }
 }
 
+// ---------------------------------------------------------------- bf16 fast path
+// Same tiling / LDS image / MFMA schedule as wgrad_bf16_kernel, but (a) the NEXT pixel tile is fetched
+// global -> VGPR while the current tile's MFMAs run (the generic kernel idles the matrix pipe for the
+// whole staging phase: rocprofv3 SQ_WAIT_ANY = 63 % of wave cycles), and (b) every access is a raw
+// buffer load against a per-image descriptor, so borders are out-of-range offsets -> zeros, no branches.
+// Contract: c1 % 64 == 0, c2 % 64 == 0, cdy % 64 == 0, 16-byte aligned, per-image tensors < 2 GiB.
+typedef __amdgpu_buffer_rsrc_t wrsrc_t;
+#define WSENT 0xFFFFFFF0u
+__device__ __forceinline__ wrsrc_t wmake_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
+  using G = WGeo<MODE>;
+  constexpr int KS = G::KS, S = G::S, PAD = G::PAD, TAPS = G::TAPS;
+  constexpr int TH = (S == 1) ? 8 : 4;
+  constexpr int XH = (TH - 1) * S + KS, XW = 15 * S + KS;
+  constexpr int X_IT = (XH * XW + 31) / 32, D_IT = TH * 16 / 32;  // 32 pixels x 8 chunks per iteration
+  constexpr int X_BYTES = X_IT * 32 * 128, D_BYTES = TH * 16 * 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[X_BYTES + D_BYTES];
+  unsigned char* xs = smem;
+  unsigned char* ds = smem + X_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, i16 = lane & 15, qp = i16 >> 2, pp = i16 & 3;
+  const int ch8 = tid & 7, p8 = tid >> 3;
+  const int nkb = a.kpad / 64;
+  const int kblk = blockIdx.x % nkb, nblk = blockIdx.x / nkb;
+  const int n0 = nblk * 64, k0 = kblk * 64;
+  const bool second = k0 >= a.c1;
+  const bf16_t* xsrc = static_cast<const bf16_t*>(second ? a.x2 : a.x1);
+  const int cs = second ? a.c2 : a.c1, kloc = second ? k0 - a.c1 : k0;
+  const bf16_t* dy = static_cast<const bf16_t*>(a.dy);
+  const size_t xpix = (size_t)a.Hx * a.Wx, ypix = (size_t)a.Hy * a.Wy;
+
+  // tile-invariant unit geometry
+  int x_iy[X_IT], x_ix[X_IT];
+#pragma unroll
+  for (int i = 0; i < X_IT; ++i) {
+    const int pix = p8 + 32 * i;
+    x_iy[i] = pix < XH * XW ? pix / XW : -100000;
+    x_ix[i] = pix - (pix / XW) * XW;
+  }
+  const int lds_x0 = swz_off(p8, ch8), lds_d0 = swz_off(p8, ch8);  // + 4096 per iteration (32 rows)
+
+  f32x4 acc[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 px[X_IT], pd[D_IT];
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  auto fetch = [&](int tile) {
+    int tt = tile;
+    const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+    const int ty = tt % a.tiles_y; tt /= a.tiles_y;
+    const int img = tt;
+    const int oy0 = ty * TH, ox0 = tx * 16;
+    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    const wrsrc_t rx = wmake_rsrc(xsrc + (size_t)img * xpix * cs, (unsigned)(xpix * cs * 2));
+    const wrsrc_t rd = wmake_rsrc(dy + (size_t)img * ypix * a.cdy, (unsigned)(ypix * a.cdy * 2));
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int gy = iy0 + x_iy[i], gx = ix0 + x_ix[i];
+      const bool ok = gy >= 0 && gy < a.Hx && gx >= 0 && gx < a.Wx;
+      const unsigned voff = ok ? (unsigned)(((gy * a.Wx + gx) * cs + kloc + ch8 * 8) * 2) : WSENT;
+      px[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < D_IT; ++i) {
+      const int pix = p8 + 32 * i;
+      const int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
+      const bool ok = gy < a.Hy && gx < a.Wy;
+      const unsigned voff = ok ? (unsigned)(((gy * a.Wy + gx) * a.cdy + n0 + ch8 * 8) * 2) : WSENT;
+      pd[i] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)voff, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.y;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += a.ksplit) {
+    __syncthreads();  // previous tile's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) *reinterpret_cast<u32x4*>(xs + lds_x0 + 4096 * i) = px[i];
+#pragma unroll
+    for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(ds + lds_d0 + 4096 * i) = pd[i];
+    __syncthreads();
+    if (tile + a.ksplit < ntiles) fetch(tile + a.ksplit);
+#pragma unroll
+    for (int kb = 0; kb < TH / 2; ++kb) {
+      const int yy = 2 * kb + (grp >> 1), xb = 8 * (grp & 1) + qp;
+      u32x4 af[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ch = 2 * c + (pp >> 1);
+        const int r0 = yy * 16 + xb;
+        const s16x4 lo = tr_read(ds, swz_off(r0, ch) + 8 * (pp & 1));
+        const s16x4 hi = tr_read(ds, swz_off(r0 + 4, ch) + 8 * (pp & 1));
+        af[c] = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int kh = 0; kh < KS; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+          const int ch = 2 * wave + (pp >> 1);
+          const int r0 = (yy * S + kh) * XW + xb * S + kw;
+          const s16x4 lo = tr_read(xs, swz_off(r0, ch) + 8 * (pp & 1));
+          const s16x4 hi = tr_read(xs, swz_off(r0 + 4 * S, ch) + 8 * (pp & 1));
+          const bf16x8 b = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[kh * KS + kw][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[c]), b,
+                                                                             acc[kh * KS + kw][c], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* slab = a.slabs + (size_t)blockIdx.y * TAPS * a.npad * a.kpad;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + c * 16 + 4 * grp + r, k = k0 + wave * 16 + i16;
+        slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+      }
+}
+
 // ---------------------------------------------------------------- fp32
 template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgArgs a) {
@@ -331,7 +462,14 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   a.vec_dy = (cdy % epu == 0) && al16(dy);
   dim3 grid((npad / 64) * (kpad / 64), ksplit);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == MIA_BF16) {
+  const size_t lim = (size_t)1 << 31;
+  const bool fast = dtype == MIA_BF16 && a.vec_x && a.vec_dy && c1 % 64 == 0 && c2 % 64 == 0 && cdy % 64 == 0 &&
+                    (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 2 < lim && (size_t)hy * wy * cdy * 2 < lim;
+  if (fast) {
+    if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_bf16_fast_kernel<MODE_W3S1>, grid, dim3(256), 0, st, a);
+    else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_bf16_fast_kernel<MODE_W3S2>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_bf16_fast_kernel<MODE_W2S2>, grid, dim3(256), 0, st, a);
+  } else if (dtype == MIA_BF16) {
     if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W3S1>, grid, dim3(256), 0, st, a);
     else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W3S2>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W2S2>, grid, dim3(256), 0, st, a);
