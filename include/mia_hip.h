@@ -81,16 +81,18 @@ int mia_wgrad_reduce(const float* slabs, int ksplit, int taps, int npad, int kpa
 int mia_norm_finalize(const float* partials, int n, int tiles, int c, int64_t hw, int mode, int training,
                       const float* drop_scale, const float* gamma, const float* beta, float eps, float momentum,
                       float* running_mean, float* running_var, long long* num_batches, float* xa, float* xb,
-                      float* scale, float* shift, void* stream);
+                      float* scale, float* shift, float* ysum, void* stream);
 /* stand-alone statistics partials [N][slabs][C][2] when no conv epilogue produced them */
 int mia_norm_stats(const void* y, int dtype, int n, int64_t hw, int c, int slabs, float* partials, void* stream);
 int mia_norm_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift, int n, int64_t hw, int c,
                      float slope, void* stream);
-/* backward of (dropout . norm . lrelu): dy, dgamma, dbeta.  partials: [N][slabs][C][2]; c1, c2: [N][C]. */
+/* backward of (dropout . norm . lrelu): dy, dgamma, dbeta.  partials: [N][slabs][C][2]; c1, c2: [N][C].
+ * dbias (optional, with ysum [N][C] from mia_norm_finalize) = gradient of the Conv2d bias in front of the norm
+ * (= sum over pixels of dy) in closed form from the reduction sums: no extra pass over dy. */
 int mia_norm_act_bwd(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
-                     const float* xa, const float* xb, int n, int64_t hw, int c, int mode, int fixed_stats, float slope,
-                     int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta, int accumulate,
-                     void* stream);
+                     const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
+                     int fixed_stats, float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma,
+                     float* dbeta, float* dbias, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ 1x1 head + Dice/CE loss */
 /* seg_output = Conv2d(c0, K1, 1) (unet.py:176), K1 <= 8.  Logits are fp32 with element strides (osn, osk, osp). */

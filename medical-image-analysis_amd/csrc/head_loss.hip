@@ -135,18 +135,106 @@ __global__ void head_bwd_weight_kernel(const float* __restrict__ dl, const T* __
   }
 }
 
+// block = 16 outputs x 16 lanes sweeping the partial blocks
 __global__ void head_bwd_final_kernel(const float* __restrict__ part, int nblk, int k1, int c0, float* __restrict__ dw,
                                       float* __restrict__ db, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= k1 * (c0 + 1)) return;
-  const int k = i / (c0 + 1), ch = i % (c0 + 1);
+  __shared__ float sh[16][17];
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + cl;
+  const int tot = k1 * (c0 + 1);
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[((size_t)b * k1 + k) * (c0 + 1) + ch];
-  if (ch < c0) dw[k * c0 + ch] = accumulate ? dw[k * c0 + ch] + s : s;
-  else db[k] = accumulate ? db[k] + s : s;
+  if (i < tot)
+    for (int b = tl; b < nblk; b += 16) s += part[(size_t)b * tot + i];
+  sh[tl][cl] = s;
+  __syncthreads();
+  if (tl == 0 && i < tot) {
+    float t = 0.f;
+    for (int j = 0; j < 16; ++j) t += sh[j][cl];
+    const int k = i / (c0 + 1), ch = i % (c0 + 1);
+    if (ch < c0) dw[k * c0 + ch] = accumulate ? dw[k * c0 + ch] + t : t;
+    else db[k] = accumulate ? db[k] + t : t;
+  }
 }
 
-#define HEAD_BWD_BLOCKS 512
+// vectorised variants (c0 % EPU == 0, 16-byte aligned): thread = (pixel lane, 16-byte unit)
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_input_vec_kernel(const float* __restrict__ dl, const float* __restrict__ w,
+                                                                 T* __restrict__ dx, int64_t npix, int c0, int k1, int64_t gsp,
+                                                                 int64_t gsk, int64_t gsn, int64_t hw) {
+  extern __shared__ float wsh[];
+  for (int i = threadIdx.x; i < k1 * c0; i += blockDim.x) wsh[i] = w[i];
+  __syncthreads();
+  constexpr int EPU = Elem<T>::EPU;
+  const int upp = c0 / EPU;
+  const int64_t total = npix * upp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / upp;
+    const int ch = (int)(i - p * upp) * EPU;
+    const float* g = dl + (p / hw) * gsn + (p % hw) * gsp;
+    float acc[EPU];
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) acc[e] = 0.f;
+    for (int k = 0; k < k1; ++k) {
+      const float gv = g[k * gsk];
+#pragma unroll
+      for (int e = 0; e < EPU; ++e) acc[e] += gv * wsh[k * c0 + ch + e];
+    }
+    alignas(16) T out[EPU];
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) out[e] = Elem<T>::cvt(acc[e]);
+    *reinterpret_cast<u32x4*>(dx + i * EPU) = *reinterpret_cast<const u32x4*>(out);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_weight_vec_kernel(const float* __restrict__ dl, const T* __restrict__ x,
+                                                                  float* __restrict__ part, int64_t npix, int c0, int k1,
+                                                                  int64_t gsp, int64_t gsk, int64_t gsn, int64_t hw) {
+  // part: [gridDim.x][k1][c0 + 1]; requires c0 <= 256 and c0 % EPU == 0
+  constexpr int EPU = Elem<T>::EPU;
+  extern __shared__ float shd[];  // [lanes][c0 + 1]
+  const int shs = c0 + 1;
+  const int upp = c0 / EPU, lanes = 256 / upp;
+  const int u = threadIdx.x % upp, pl = threadIdx.x / upp;
+  const int64_t per = (npix + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = r0 + per < npix ? r0 + per : npix;
+  float acc[MAXK][EPU], bacc[MAXK];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) {
+    bacc[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) acc[k][e] = 0.f;
+  }
+  if (pl < lanes)
+    for (int64_t p = r0 + pl; p < r1; p += lanes) {
+      alignas(16) T v[EPU];
+      *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(x + p * c0 + u * EPU);
+      const float* g = dl + (p / hw) * gsn + (p % hw) * gsp;
+#pragma unroll
+      for (int k = 0; k < MAXK; ++k)
+        if (k < k1) {
+          const float gv = g[k * gsk];
+          bacc[k] += gv;
+#pragma unroll
+          for (int e = 0; e < EPU; ++e) acc[k][e] += gv * Elem<T>::ld(v + e);
+        }
+    }
+  for (int k = 0; k < k1; ++k) {
+    __syncthreads();
+    if (pl < lanes) {
+#pragma unroll
+      for (int e = 0; e < EPU; ++e) shd[pl * shs + u * EPU + e] = acc[k][e];
+      if (u == 0) shd[pl * shs + c0] = bacc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x <= c0) {
+      float t = 0.f;
+      for (int j = 0; j < lanes; ++j) t += shd[j * shs + threadIdx.x];
+      part[((size_t)blockIdx.x * k1 + k) * (c0 + 1) + threadIdx.x] = t;
+    }
+  }
+}
+
+#define HEAD_BWD_BLOCKS 2048
 extern "C" int mia_head_bwd_workspace(int c0, int k1) { return HEAD_BWD_BLOCKS * k1 * (c0 + 1); }
 
 extern "C" int mia_head_bwd(const float* dlogits, const void* x, int dtype, const float* w, void* dx, float* dw, float* db,
@@ -159,14 +247,27 @@ extern "C" int mia_head_bwd(const float* dlogits, const void* x, int dtype, cons
   const int64_t total = npix * c0;
   const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   const int wblocks = (int)(npix / 64 < 1 ? 1 : (npix / 64 > HEAD_BWD_BLOCKS ? HEAD_BWD_BLOCKS : npix / 64));
-  if (dtype == MIA_BF16) {
+  const int epu = dtype == MIA_BF16 ? 8 : 4;
+  const bool vec = (c0 % epu == 0) && c0 <= 255 && c0 / epu <= 128 && (256 / (c0 / epu)) <= 128 &&
+                   ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+  if (vec && (dtype == MIA_BF16 || dtype == MIA_F32)) {
+    const int64_t units = npix * (c0 / epu);
+    const int vblocks = (int)((units + 255) / 256 < 16384 ? (units + 255) / 256 : 16384);
+    if (dtype == MIA_BF16) {
+      if (dx) hipLaunchKernelGGL(head_bwd_input_vec_kernel<bf16_t>, dim3(vblocks), dim3(256), k1 * c0 * 4, st, dlogits, w, static_cast<bf16_t*>(dx), npix, c0, k1, gsp, gsk, gsn, hw);
+      hipLaunchKernelGGL(head_bwd_weight_vec_kernel<bf16_t>, dim3(wblocks), dim3(256), (256 / (c0 / epu)) * (c0 + 1) * 4, st, dlogits, static_cast<const bf16_t*>(x), workspace, npix, c0, k1, gsp, gsk, gsn, hw);
+    } else {
+      if (dx) hipLaunchKernelGGL(head_bwd_input_vec_kernel<float>, dim3(vblocks), dim3(256), k1 * c0 * 4, st, dlogits, w, static_cast<float*>(dx), npix, c0, k1, gsp, gsk, gsn, hw);
+      hipLaunchKernelGGL(head_bwd_weight_vec_kernel<float>, dim3(wblocks), dim3(256), (256 / (c0 / epu)) * (c0 + 1) * 4, st, dlogits, static_cast<const float*>(x), workspace, npix, c0, k1, gsp, gsk, gsn, hw);
+    }
+  } else if (dtype == MIA_BF16) {
     if (dx) hipLaunchKernelGGL(head_bwd_input_kernel<bf16_t>, dim3(blocks), dim3(256), k1 * c0 * 4, st, dlogits, w, static_cast<bf16_t*>(dx), npix, c0, k1, gsp, gsk, gsn, hw);
     hipLaunchKernelGGL(head_bwd_weight_kernel<bf16_t>, dim3(wblocks), dim3(256), 512 * 4, st, dlogits, static_cast<const bf16_t*>(x), workspace, npix, c0, k1, gsp, gsk, gsn, hw);
   } else if (dtype == MIA_F32) {
     if (dx) hipLaunchKernelGGL(head_bwd_input_kernel<float>, dim3(blocks), dim3(256), k1 * c0 * 4, st, dlogits, w, static_cast<float*>(dx), npix, c0, k1, gsp, gsk, gsn, hw);
     hipLaunchKernelGGL(head_bwd_weight_kernel<float>, dim3(wblocks), dim3(256), 512 * 4, st, dlogits, static_cast<const float*>(x), workspace, npix, c0, k1, gsp, gsk, gsn, hw);
   } else { mia_set_error("mia_head_bwd: bad dtype"); return MIA_EARG; }
-  hipLaunchKernelGGL(head_bwd_final_kernel, dim3(ceil_div(k1 * (c0 + 1), 128)), dim3(128), 0, st, workspace, wblocks, k1, c0, dw, db, accumulate);
+  hipLaunchKernelGGL(head_bwd_final_kernel, dim3(ceil_div(k1 * (c0 + 1), 16)), dim3(256), 0, st, workspace, wblocks, k1, c0, dw, db, accumulate);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

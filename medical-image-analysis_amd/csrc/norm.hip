@@ -14,84 +14,165 @@
 #define NORM_BATCH 1
 
 // ---------------------------------------------------------------- forward statistics finalize
-// partials: [N][T][C][2] (sum, sumsq) of the raw conv output.  One thread per (n, c) for instance,
-// per c for batch (loops n).  Accumulates in double: var = E[y^2] - mean^2 must not cancel in fp32.
+// partials: [N][T][C][2] (sum, sumsq) of the raw conv output.  Block = 16 channels x 16 tile-lanes; instance mode:
+// one block per (image, channel group); batch mode: one block per channel group, lanes sweep (image, tile).
+// Accumulates in double: var = E[y^2] - mean^2 must not cancel in fp32.  ysum[N][C] (optional) keeps the
+// per-(n,c) sum of y for the closed-form conv-bias gradient in the backward pass.
 __global__ void norm_finalize_kernel(const float* __restrict__ part, int n_img, int tiles, int c, int64_t hw, int mode,
                                      int training, const float* __restrict__ drop, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float eps, float momentum, float* running_mean,
                                      float* running_var, long long* num_batches, float* __restrict__ xa,
-                                     float* __restrict__ xb, float* __restrict__ scale, float* __restrict__ shift) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+                                     float* __restrict__ xb, float* __restrict__ scale, float* __restrict__ shift,
+                                     float* __restrict__ ysum) {
+  __shared__ double sh1[16][17], sh2[16][17];
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int cgroups = (c + 15) / 16;
+  const int cg = blockIdx.x % cgroups;
+  const int ch = cg * 16 + cl;
   if (mode == NORM_INSTANCE) {
-    if (idx >= n_img * c) return;
-    const int n = idx / c, ch = idx % c;
+    const int n = blockIdx.x / cgroups;
     double s1 = 0.0, s2 = 0.0;
-    for (int t = 0; t < tiles; ++t) {
-      const float* p = part + (((size_t)n * tiles + t) * c + ch) * 2;
-      s1 += p[0]; s2 += p[1];
-    }
-    const double m = drop ? (double)drop[idx] : 1.0;
-    const double mean = s1 / (double)hw;
-    double var = s2 / (double)hw - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(m * m * var + (double)eps);
-    const float a = (float)(m * rstd), b = (float)(-m * mean * rstd);
-    xa[idx] = a; xb[idx] = b;
-    scale[idx] = gamma[ch] * a; shift[idx] = gamma[ch] * b + beta[ch];
-    return;
-  }
-  // batch
-  if (idx >= c) return;
-  const int ch = idx;
-  double rstd, meanp;
-  if (training) {
-    double e1 = 0.0, e2 = 0.0;
-    for (int n = 0; n < n_img; ++n) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int t = 0; t < tiles; ++t) {
+    if (ch < c)
+      for (int t = tl; t < tiles; t += 16) {
         const float* p = part + (((size_t)n * tiles + t) * c + ch) * 2;
         s1 += p[0]; s2 += p[1];
       }
-      const double m = drop ? (double)drop[n * c + ch] : 1.0;
-      e1 += m * s1; e2 += m * m * s2;
+    sh1[tl][cl] = s1; sh2[tl][cl] = s2;
+    __syncthreads();
+    if (tl == 0 && ch < c) {
+      s1 = 0.0; s2 = 0.0;
+      for (int j = 0; j < 16; ++j) { s1 += sh1[j][cl]; s2 += sh2[j][cl]; }
+      const int idx = n * c + ch;
+      const double m = drop ? (double)drop[idx] : 1.0;
+      const double mean = s1 / (double)hw;
+      double var = s2 / (double)hw - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double rstd = 1.0 / sqrt(m * m * var + (double)eps);
+      const float a_ = (float)(m * rstd), b_ = (float)(-m * mean * rstd);
+      xa[idx] = a_; xb[idx] = b_;
+      scale[idx] = gamma[ch] * a_; shift[idx] = gamma[ch] * b_ + beta[ch];
+      if (ysum) ysum[idx] = (float)s1;
     }
-    const double cnt = (double)n_img * (double)hw;
-    meanp = e1 / cnt;
-    double var = e2 / cnt - meanp * meanp;
-    if (var < 0.0) var = 0.0;
-    rstd = 1.0 / sqrt(var + (double)eps);
-    if (running_mean) {
-      const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-      running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * meanp);
-      running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
-      if (ch == 0 && num_batches) *num_batches += 1;
+    return;
+  }
+  // batch
+  double rstd = 0.0, meanp = 0.0;
+  if (training) {
+    double e1 = 0.0, e2 = 0.0;
+    if (ch < c)
+      for (int it = tl; it < n_img * tiles; it += 16) {
+        const int n = it / tiles;
+        const float* p = part + ((size_t)it * c + ch) * 2;
+        const double m = drop ? (double)drop[n * c + ch] : 1.0;
+        e1 += m * p[0]; e2 += m * m * p[1];
+      }
+    sh1[tl][cl] = e1; sh2[tl][cl] = e2;
+    __syncthreads();
+    if (tl == 0 && ch < c) {
+      e1 = 0.0; e2 = 0.0;
+      for (int j = 0; j < 16; ++j) { e1 += sh1[j][cl]; e2 += sh2[j][cl]; }
+      const double cnt = (double)n_img * (double)hw;
+      meanp = e1 / cnt;
+      double var = e2 / cnt - meanp * meanp;
+      if (var < 0.0) var = 0.0;
+      rstd = 1.0 / sqrt(var + (double)eps);
+      if (running_mean) {
+        const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * meanp);
+        running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+        if (ch == 0 && num_batches) *num_batches += 1;
+      }
+      sh1[0][cl] = meanp; sh2[0][cl] = rstd;
     }
-  } else {
+    __syncthreads();
+    meanp = sh1[0][cl]; rstd = sh2[0][cl];
+    if (ysum && ch < c)  // per-(n,c) raw sums (lanes sweep images)
+      for (int n = tl; n < n_img; n += 16) {
+        double s1 = 0.0;
+        for (int t = 0; t < tiles; ++t) s1 += part[(((size_t)n * tiles + t) * c + ch) * 2];
+        ysum[n * c + ch] = (float)s1;
+      }
+  } else if (ch < c) {
     meanp = running_mean[ch];
     rstd = 1.0 / sqrt((double)running_var[ch] + (double)eps);
   }
-  for (int n = 0; n < n_img; ++n) {
-    const double m = (training && drop) ? (double)drop[n * c + ch] : 1.0;
-    const float a = (float)(m * rstd), b = (float)(-meanp * rstd);
-    xa[n * c + ch] = a; xb[n * c + ch] = b;
-    scale[n * c + ch] = gamma[ch] * a; shift[n * c + ch] = gamma[ch] * b + beta[ch];
-  }
+  if (ch < c)
+    for (int n = tl; n < n_img; n += 16) {
+      const double m = (training && drop) ? (double)drop[n * c + ch] : 1.0;
+      const float a_ = (float)(m * rstd), b_ = (float)(-meanp * rstd);
+      xa[n * c + ch] = a_; xb[n * c + ch] = b_;
+      scale[n * c + ch] = gamma[ch] * a_; shift[n * c + ch] = gamma[ch] * b_ + beta[ch];
+    }
 }
 
 extern "C" int mia_norm_finalize(const float* partials, int n, int tiles, int c, int64_t hw, int mode, int training,
                                  const float* drop_scale, const float* gamma, const float* beta, float eps, float momentum,
                                  float* running_mean, float* running_var, long long* num_batches, float* xa, float* xb,
-                                 float* scale, float* shift, void* stream) {
+                                 float* scale, float* shift, float* ysum, void* stream) {
   MIA_CHECK_ARG(mode == NORM_INSTANCE || mode == NORM_BATCH, "mia_norm_finalize: bad mode %d", mode);
   MIA_CHECK_ARG(gamma && beta && xa && xb && scale && shift && n > 0 && c > 0 && hw > 0, "mia_norm_finalize: bad arguments");
   MIA_CHECK_ARG(partials || (mode == NORM_BATCH && !training), "mia_norm_finalize: partials required");
   MIA_CHECK_ARG(mode == NORM_INSTANCE || training || (running_mean && running_var), "mia_norm_finalize: eval batch norm needs running stats");
-  const int work = mode == NORM_INSTANCE ? n * c : c;
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3(ceil_div(work, 128)), dim3(128), 0, static_cast<hipStream_t>(stream), partials,
-                     n, tiles, c, hw, mode, training, drop_scale, gamma, beta, eps, momentum, running_mean, running_var,
-                     num_batches, xa, xb, scale, shift);
+  const int cgroups = ceil_div(c, 16);
+  const int blocks = mode == NORM_INSTANCE ? n * cgroups : cgroups;
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), partials, n, tiles, c, hw,
+                     mode, training, drop_scale, gamma, beta, eps, momentum, running_mean, running_var, num_batches, xa, xb,
+                     scale, shift, (partials && training) || mode == NORM_INSTANCE ? ysum : nullptr);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
+}
+
+// ---------------------------------------------------------------- vectorised per-channel reductions (C % 64 == 0)
+// block = (64 channels = UPB 16-byte units) x (256/UPB pixel lanes); grid = (n*slabs, C/64).  Each thread streams
+// 16-byte units of its slab, keeps EPU x 2 running sums in registers, lanes are combined through LDS.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void colreduce_vec_kernel(const T* __restrict__ a0, const T* __restrict__ a1,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ xa, const float* __restrict__ xb,
+                                                            int64_t hw, int c, int slabs, float slope, float* __restrict__ part) {
+  constexpr int EPU = Elem<T>::EPU, UPB = 64 / EPU, LANES = 256 / UPB;
+  __shared__ float sh[2][LANES][64 + 1];
+  const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  const int u = threadIdx.x % UPB, pl = threadIdx.x / UPB;
+  const int ch0 = blockIdx.y * 64 + u * EPU;
+  const int64_t per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  const size_t base = (size_t)n * hw * c + ch0;
+  float s1[EPU], s2[EPU], sc[EPU], sf[EPU], ka[EPU], kb[EPU];
+#pragma unroll
+  for (int e = 0; e < EPU; ++e) {
+    s1[e] = 0.f; s2[e] = 0.f;
+    if (BWD) {
+      const size_t o = (size_t)n * c + ch0 + e;
+      sc[e] = scale[o]; sf[e] = shift[o]; ka[e] = xa[o]; kb[e] = xb[o];
+    }
+  }
+  for (int64_t r = r0 + pl; r < r1; r += LANES) {
+    alignas(16) T v0[EPU]; alignas(16) T v1[EPU];
+    *reinterpret_cast<u32x4*>(v0) = *reinterpret_cast<const u32x4*>(a0 + base + r * c);
+    if (BWD) *reinterpret_cast<u32x4*>(v1) = *reinterpret_cast<const u32x4*>(a1 + base + r * c);
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) {
+      if (BWD) {  // a0 = dz, a1 = y
+        const float yv = Elem<T>::ld(v1 + e);
+        float g = Elem<T>::ld(v0 + e);
+        if (!(sc[e] * yv + sf[e] > 0.f)) g *= slope;
+        s1[e] += g; s2[e] += g * (ka[e] * yv + kb[e]);
+      } else {
+        const float v = Elem<T>::ld(v0 + e);
+        s1[e] += v; s2[e] += v * v;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPU; ++e) { sh[0][pl][u * EPU + e] = s1[e]; sh[1][pl][u * EPU + e] = s2[e]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int k = threadIdx.x >> 6, chl = threadIdx.x & 63;
+    float t = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < LANES; ++j) t += sh[k][j][chl];
+    part[(((size_t)n * slabs + s) * c + blockIdx.y * 64 + chl) * 2 + k] = t;
+  }
 }
 
 // ---------------------------------------------------------------- stand-alone statistics (no conv epilogue available)
@@ -124,6 +205,14 @@ __global__ void norm_stats_kernel(const T* __restrict__ y, int64_t hw, int c, in
 extern "C" int mia_norm_stats(const void* y, int dtype, int n, int64_t hw, int c, int slabs, float* partials, void* stream) {
   MIA_CHECK_ARG(y && partials && n > 0 && hw > 0 && c > 0 && slabs > 0, "mia_norm_stats: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (c % 64 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (dtype == MIA_BF16 || dtype == MIA_F32)) {
+    if (dtype == MIA_BF16)
+      hipLaunchKernelGGL((colreduce_vec_kernel<bf16_t, false>), dim3(n * slabs, c / 64), dim3(256), 0, st, static_cast<const bf16_t*>(y), static_cast<const bf16_t*>(nullptr), nullptr, nullptr, nullptr, nullptr, hw, c, slabs, 0.f, partials);
+    else
+      hipLaunchKernelGGL((colreduce_vec_kernel<float, false>), dim3(n * slabs, c / 64), dim3(256), 0, st, static_cast<const float*>(y), static_cast<const float*>(nullptr), nullptr, nullptr, nullptr, nullptr, hw, c, slabs, 0.f, partials);
+    MIA_LAUNCH_CHECK();
+    return MIA_OK;
+  }
   if (dtype == MIA_BF16)
     hipLaunchKernelGGL(norm_stats_kernel<bf16_t>, dim3(n * slabs, ceil_div(c, 256)), dim3(256), 512 * sizeof(float), st, static_cast<const bf16_t*>(y), hw, c, slabs, partials);
   else if (dtype == MIA_F32)
@@ -217,34 +306,79 @@ __global__ void norm_act_bwd_reduce_kernel(const T* __restrict__ dz, const T* __
   }
 }
 
-// pass 1b: combine partials -> per-(n,c) group means c1 = mean(g), c2 = mean(g*xhat); dgamma, dbeta
+// pass 1b: combine partials -> per-(n,c) group means c1 = mean(g), c2 = mean(g*xhat); dgamma, dbeta, and the
+// gradient of the conv bias in front of the norm in closed form:
+//   sum_p dy = scale * (Sg - M*c1 - c2*Sxhat),  Sxhat = xa*Sy + M*xb   (M = H*W, per image)
+// (analytically 0 for instance norm -- the reference's autograd produces rounding noise there too).
+// Block = 16 channels x 16 lanes sweeping (image, slab).
 __global__ void norm_bwd_finalize_kernel(const float* __restrict__ part, int n_img, int slabs, int c, int64_t hw, int mode,
-                                         int fixed_stats, float* __restrict__ c1, float* __restrict__ c2,
-                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double tg = 0.0, tgx = 0.0;
-  for (int n = 0; n < n_img; ++n) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int s = 0; s < slabs; ++s) {
-      const float* p = part + (((size_t)n * slabs + s) * c + ch) * 2;
-      s1 += p[0]; s2 += p[1];
+                                         int fixed_stats, const float* __restrict__ scale, const float* __restrict__ xa,
+                                         const float* __restrict__ xb, const float* __restrict__ ysum, float* __restrict__ c1,
+                                         float* __restrict__ c2, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                         float* __restrict__ dbias, int accumulate) {
+  __shared__ double sh1[16][17], sh2[16][17];
+  __shared__ double sg[16][33], sgx[16][33];  // per-image sums for up to 32 images per pass (instance / dbias)
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double tg = 0.0, tgx = 0.0, tb = 0.0;
+  for (int nb0 = 0; nb0 < n_img; nb0 += 32) {
+    const int ncnt = n_img - nb0 < 32 ? n_img - nb0 : 32;
+    // each lane owns images nb0 + tl, nb0 + tl + 16
+    for (int j = tl; j < ncnt; j += 16) {
+      double s1 = 0.0, s2 = 0.0;
+      if (ch < c)
+        for (int s = 0; s < slabs; ++s) {
+          const float* p = part + (((size_t)(nb0 + j) * slabs + s) * c + ch) * 2;
+          s1 += p[0]; s2 += p[1];
+        }
+      sg[cl][j] = s1; sgx[cl][j] = s2;
     }
-    tg += s1; tgx += s2;
-    if (mode == NORM_INSTANCE) {
-      c1[n * c + ch] = fixed_stats ? 0.f : (float)(s1 / (double)hw);
-      c2[n * c + ch] = fixed_stats ? 0.f : (float)(s2 / (double)hw);
-    }
+    __syncthreads();
+    if (tl == 0 && ch < c)
+      for (int j = 0; j < ncnt; ++j) { tg += sg[cl][j]; tgx += sgx[cl][j]; }
+    if (mode == NORM_INSTANCE && ch < c)
+      for (int j = tl; j < ncnt; j += 16) {
+        const int idx = (nb0 + j) * c + ch;
+        const double m1 = fixed_stats ? 0.0 : sg[cl][j] / (double)hw, m2 = fixed_stats ? 0.0 : sgx[cl][j] / (double)hw;
+        c1[idx] = (float)m1; c2[idx] = (float)m2;
+      }
+    if (mode == NORM_INSTANCE && dbias && tl == 0 && ch < c)
+      for (int j = 0; j < ncnt; ++j) {
+        const int idx = (nb0 + j) * c + ch;
+        const double m1 = fixed_stats ? 0.0 : sg[cl][j] / (double)hw, m2 = fixed_stats ? 0.0 : sgx[cl][j] / (double)hw;
+        const double sxh = ysum ? (double)xa[idx] * ysum[idx] + (double)hw * xb[idx] : 0.0;
+        tb += (double)scale[idx] * (sg[cl][j] - (double)hw * m1 - m2 * sxh);
+      }
+    __syncthreads();
   }
-  if (mode == NORM_BATCH) {
+  sh1[tl][cl] = 0; sh2[tl][cl] = 0;
+  if (tl == 0) { sh1[0][cl] = tg; sh2[0][cl] = tgx; }
+  __syncthreads();
+  tg = sh1[0][cl]; tgx = sh2[0][cl];
+  __syncthreads();  // everyone has read the totals before sh1 is reused below
+  if (mode == NORM_BATCH && ch < c) {
     const double cnt = (double)n_img * (double)hw;
-    for (int n = 0; n < n_img; ++n) {
-      c1[n * c + ch] = fixed_stats ? 0.f : (float)(tg / cnt);
-      c2[n * c + ch] = fixed_stats ? 0.f : (float)(tgx / cnt);
+    const double m1 = fixed_stats ? 0.0 : tg / cnt, m2 = fixed_stats ? 0.0 : tgx / cnt;
+    double tbl = 0.0;
+    for (int n = tl; n < n_img; n += 16) {
+      const int idx = n * c + ch;
+      c1[idx] = (float)m1; c2[idx] = (float)m2;
+      if (dbias) {
+        double s1 = 0.0;
+        for (int s = 0; s < slabs; ++s) s1 += part[(((size_t)n * slabs + s) * c + ch) * 2];
+        const double sxh = ysum ? (double)xa[idx] * ysum[idx] + (double)hw * xb[idx] : 0.0;
+        tbl += (double)scale[idx] * (s1 - (double)hw * m1 - m2 * sxh);
+      }
     }
+    sh1[tl][cl] = tbl;
   }
-  dgamma[ch] = accumulate ? dgamma[ch] + (float)tgx : (float)tgx;
-  dbeta[ch] = accumulate ? dbeta[ch] + (float)tg : (float)tg;
+  __syncthreads();
+  if (tl == 0 && ch < c) {
+    if (mode == NORM_BATCH) { tb = 0.0; for (int j = 0; j < 16; ++j) tb += sh1[j][cl]; }
+    dgamma[ch] = accumulate ? dgamma[ch] + (float)tgx : (float)tgx;
+    dbeta[ch] = accumulate ? dbeta[ch] + (float)tg : (float)tg;
+    if (dbias) dbias[ch] = accumulate ? dbias[ch] + (float)tb : (float)tb;
+  }
 }
 
 // pass 2: dy = xa*gamma*(g - c1 - xhat*c2)
@@ -280,9 +414,9 @@ __global__ void norm_act_bwd_apply_kernel(const T* __restrict__ dz, const T* __r
 }
 
 extern "C" int mia_norm_act_bwd(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
-                                const float* xa, const float* xb, int n, int64_t hw, int c, int mode, int fixed_stats,
-                                float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta,
-                                int accumulate, void* stream) {
+                                const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
+                                int fixed_stats, float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma,
+                                float* dbeta, float* dbias, int accumulate, void* stream) {
   MIA_CHECK_ARG(dz && y && dy && scale && shift && xa && xb && partials && c1 && c2 && dgamma && dbeta,
                 "mia_norm_act_bwd: null pointer");
   MIA_CHECK_ARG(n > 0 && hw > 0 && c > 0 && slabs > 0, "mia_norm_act_bwd: bad shape");
@@ -298,10 +432,15 @@ extern "C" int mia_norm_act_bwd(const void* dz, const void* y, void* dy, int dty
 #define AP(T, V) hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, V>), dim3(blocks), dim3(256), 0, st,                   \
                                     static_cast<const T*>(dz), static_cast<const T*>(y), static_cast<T*>(dy), scale, shift, \
                                     xa, xb, c1, c2, hw, c, units, slope)
-  if (dtype == MIA_BF16) RD(bf16_t); else if (dtype == MIA_F32) RD(float);
-  else { mia_set_error("mia_norm_act_bwd: bad dtype"); return MIA_EARG; }
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, st, partials, n, slabs, c, hw, mode,
-                     fixed_stats, c1, c2, dgamma, dbeta, accumulate);
+  if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_norm_act_bwd: bad dtype"); return MIA_EARG; }
+  if (vec && c % 64 == 0) {
+    if (dtype == MIA_BF16)
+      hipLaunchKernelGGL((colreduce_vec_kernel<bf16_t, true>), dim3(n * slabs, c / 64), dim3(256), 0, st, static_cast<const bf16_t*>(dz), static_cast<const bf16_t*>(y), scale, shift, xa, xb, hw, c, slabs, slope, partials);
+    else
+      hipLaunchKernelGGL((colreduce_vec_kernel<float, true>), dim3(n * slabs, c / 64), dim3(256), 0, st, static_cast<const float*>(dz), static_cast<const float*>(y), scale, shift, xa, xb, hw, c, slabs, slope, partials);
+  } else if (dtype == MIA_BF16) RD(bf16_t); else RD(float);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, partials, n, slabs, c, hw, mode,
+                     fixed_stats, scale, xa, xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate);
   if (dtype == MIA_BF16) { if (vec) AP(bf16_t, true); else AP(bf16_t, false); }
   else { if (vec) AP(float, true); else AP(float, false); }
 #undef RD

@@ -85,11 +85,39 @@ extern "C" int mia_relayout(const void* src, int src_dtype, void* dst, int dst_d
 }
 
 // ---- per-channel column sum over P rows of an NHWC tensor: out[c] (+)= sum_p x[p][c]   (bias gradients)
+#define COLSUM_BLOCKS 256
+// vectorised: block = 64 channels (UPB 16-byte units) x pixel lanes; grid = (blocks, C/64)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, int64_t p, int c, float* __restrict__ part) {
+  constexpr int EPU = Elem<T>::EPU, UPB = 64 / EPU, LANES = 256 / UPB;
+  __shared__ float sh[LANES][64 + 1];
+  const int u = threadIdx.x % UPB, pl = threadIdx.x / UPB;
+  const int ch0 = blockIdx.y * 64 + u * EPU;
+  const int64_t per = (p + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = r0 + per < p ? r0 + per : p;
+  float s1[EPU];
+#pragma unroll
+  for (int e = 0; e < EPU; ++e) s1[e] = 0.f;
+  for (int64_t r = r0 + pl; r < r1; r += LANES) {
+    alignas(16) T v[EPU];
+    *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(x + r * c + ch0);
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) s1[e] += Elem<T>::ld(v + e);
+  }
+#pragma unroll
+  for (int e = 0; e < EPU; ++e) sh[pl][u * EPU + e] = s1[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < LANES; ++j) t += sh[j][threadIdx.x];
+    part[(size_t)blockIdx.x * c + blockIdx.y * 64 + threadIdx.x] = t;
+  }
+}
+
 template <typename T>
 __global__ void colsum_partial_kernel(const T* __restrict__ x, int64_t p, int c, float* __restrict__ part) {
-  // block = 256 threads: thread t -> channel (t % cw), row lane (t / cw); cw = min(c, 256) rounded to pow2 by host
   extern __shared__ float sh[];
-  const int cw = blockDim.x >= c ? c : blockDim.x;  // channels covered per pass
+  const int cw = blockDim.x >= c ? c : blockDim.x;
   const int rows_par = blockDim.x / cw;
   const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
   const int64_t rows_per_blk = (p + gridDim.x - 1) / gridDim.x;
@@ -110,32 +138,44 @@ __global__ void colsum_partial_kernel(const T* __restrict__ x, int64_t p, int c,
   }
 }
 
+// block = 16 channels x 16 lanes sweeping the partial rows
 __global__ void colsum_final_kernel(const float* __restrict__ part, int nblk, int c, float* __restrict__ out, int accumulate) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+  __shared__ float sh[16][17];
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * c + ch];
-  out[ch] = accumulate ? out[ch] + s : s;
+  if (ch < c)
+    for (int b = tl; b < nblk; b += 16) s += part[(size_t)b * c + ch];
+  sh[tl][cl] = s;
+  __syncthreads();
+  if (tl == 0 && ch < c) {
+    float t = 0.f;
+    for (int j = 0; j < 16; ++j) t += sh[j][cl];
+    out[ch] = accumulate ? out[ch] + t : t;
+  }
 }
 
-extern "C" int mia_colsum_workspace(int64_t p, int c) {
-  const int blocks = (int)(p / 64 < 1 ? 1 : (p / 64 > 1024 ? 1024 : p / 64));
-  return blocks * c;  // floats
-}
+static int colsum_blocks(int64_t p) { return (int)(p / 64 < 1 ? 1 : (p / 64 > COLSUM_BLOCKS ? COLSUM_BLOCKS : p / 64)); }
+
+extern "C" int mia_colsum_workspace(int64_t p, int c) { return colsum_blocks(p) * c; }
 
 extern "C" int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, float* out, int accumulate,
                           void* stream) {
   MIA_CHECK_ARG(x && workspace && out && p > 0 && c > 0, "mia_colsum: bad arguments");
-  const int blocks = (int)(p / 64 < 1 ? 1 : (p / 64 > 1024 ? 1024 : p / 64));
+  MIA_CHECK_ARG(dtype == MIA_BF16 || dtype == MIA_F32, "mia_colsum: bad dtype");
+  const int blocks = colsum_blocks(p);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == MIA_BF16)
+  if (c % 64 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    if (dtype == MIA_BF16) hipLaunchKernelGGL(colsum_vec_kernel<bf16_t>, dim3(blocks, c / 64), dim3(256), 0, st, static_cast<const bf16_t*>(x), p, c, workspace);
+    else hipLaunchKernelGGL(colsum_vec_kernel<float>, dim3(blocks, c / 64), dim3(256), 0, st, static_cast<const float*>(x), p, c, workspace);
+  } else if (dtype == MIA_BF16) {
     hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(blocks, ceil_div(c, 256)), dim3(256), 256 * sizeof(float), st,
                        static_cast<const bf16_t*>(x), p, c, workspace);
-  else if (dtype == MIA_F32)
+  } else {
     hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(blocks, ceil_div(c, 256)), dim3(256), 256 * sizeof(float), st,
                        static_cast<const float*>(x), p, c, workspace);
-  else { mia_set_error("mia_colsum: bad dtype"); return MIA_EARG; }
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, st, workspace, blocks, c, out, accumulate);
+  }
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, workspace, blocks, c, out, accumulate);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

@@ -243,12 +243,12 @@ class PlainBlockFn(torch.autograd.Function):
         mode = CONV_G3S2 if stride == 2 else CONV_G3S1
         y, _, stats = conv_mma(mode, x1, x2, wp, npad, kpad, False, bias.detach().float(), cout, (ho, wo), want_stats=True)
         dev = x1.device
-        coefs = torch.empty((4, n, cout), device=dev, dtype=torch.float32)  # xa, xb, scale, shift
+        coefs = torch.empty((5, n, cout), device=dev, dtype=torch.float32)  # xa, xb, scale, shift, sum_y
         fixed = cfg.mode == NORM_BATCH and not cfg.training
         call("mia_norm_finalize", _p(stats), n, stats.shape[1], cout, _c_i64(ho * wo), cfg.mode, int(cfg.training),
              _p(cfg.drop_scale), _p(gamma.detach()), _p(beta.detach()), _c_float(cfg.eps), _c_float(cfg.momentum),
              _p(cfg.running_mean), _p(cfg.running_var), _p(cfg.num_batches), _p(coefs[0]), _p(coefs[1]), _p(coefs[2]),
-             _p(coefs[3]), _stream())
+             _p(coefs[3]), _p(coefs[4]), _stream())
         z = torch.empty_like(y)
         call("mia_norm_act_fwd", _p(y), _p(z), dtype, _p(coefs[2]), _p(coefs[3]), n, _c_i64(ho * wo), cout,
              _c_float(LRELU_SLOPE), _stream())
@@ -267,13 +267,12 @@ class PlainBlockFn(torch.autograd.Function):
         slabs = _slabs_for(hw)
         part = torch.empty((n, slabs, cout, 2), device=dev, dtype=torch.float32)
         cc = torch.empty((2, n, cout), device=dev, dtype=torch.float32)
-        dgamma = torch.empty(cout, device=dev, dtype=torch.float32)
-        dbeta = torch.empty(cout, device=dev, dtype=torch.float32)
+        dgb = torch.empty((3, cout), device=dev, dtype=torch.float32)
+        dgamma, dbeta, dbias = dgb[0], dgb[1], dgb[2]
         dy = torch.empty_like(y)
-        call("mia_norm_act_bwd", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]), n,
-             _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(LRELU_SLOPE), slabs, _p(part), _p(cc[0]), _p(cc[1]),
-             _p(dgamma), _p(dbeta), 0, _stream())
-        dbias = colsum(dy)
+        call("mia_norm_act_bwd", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
+             _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(LRELU_SLOPE), slabs,
+             _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
         cin = weight.shape[1]
         wmode = WGRAD_3S2 if ctx.stride == 2 else WGRAD_3S1
         dw = conv_wgrad(wmode, x1, x2, dy, weight.shape, cout, cin)
