@@ -39,9 +39,9 @@ class FlatOptimizer:
         self.kind = _KIND[name]
         self.name = name
         params = [p for p in model.parameters() if p.requires_grad]
-        if not params or not params[0].is_cuda:
-            raise RuntimeError("FlatOptimizer needs the model on a HIP device")
-        dev = params[0].device
+        if not params:
+            raise RuntimeError("FlatOptimizer: the model has no trainable parameters")
+        dev = params[0].device  # buffers follow the model; step() itself needs a HIP device (no CPU fallback)
         order = params[::-1]  # reverse forward order: first-ready gradients first
         offs, total = [], 0
         for p in order:

@@ -75,8 +75,8 @@ def gaussian_blur(img: torch.Tensor, sigma: Sequence[float], ksize: Sequence[int
     x = _f32(img)
     b, c, h, w = x.shape
     out = torch.empty_like(x)
-    call("mia_gaussian_blur", _p(x), _p(out), b, c, h, w, _p(_dev_f(sigma, x.device)), _p(_dev_i(ksize, x.device)),
-         int(max(ksize)), _p(_apply(apply, x.device)), _stream())
+    sg, ks, ap = _dev_f(sigma, x.device), _dev_i(ksize, x.device), _apply(apply, x.device)  # keep alive across the launch
+    call("mia_gaussian_blur", _p(x), _p(out), b, c, h, w, _p(sg), _p(ks), int(max(ksize)), _p(ap), _stream())
     return out
 
 
@@ -98,8 +98,8 @@ def elementwise(img: torch.Tensor, op: int, p0=None, mean_std: Optional[torch.Te
     pp = None if p0 is None else _dev_f(p0, x.device)
     if aux is not None:
         aux = _f32(aux)
-    call("mia_elementwise", _p(x), _p(out), _c_i64(x.numel() // b), b, op, _p(pp), _p(mean_std), _p(aux),
-         _p(_apply(apply, x.device)), _stream())
+    ap = _apply(apply, x.device)
+    call("mia_elementwise", _p(x), _p(out), _c_i64(x.numel() // b), b, op, _p(pp), _p(mean_std), _p(aux), _p(ap), _stream())
     return out
 
 
@@ -107,8 +107,9 @@ def noise_clip(img: torch.Tensor, sigma: Sequence[float], seed: int, offset: int
     x = _f32(img)
     b = x.shape[0]
     out = torch.empty_like(x)
-    call("mia_noise_clip", _p(x), _p(out), _c_i64(x.numel() // b), b, _p(_dev_f(sigma, x.device)), ctypes.c_uint64(seed),
-         ctypes.c_uint64(offset), _p(_apply(apply, x.device)), _stream())
+    sg, ap = _dev_f(sigma, x.device), _apply(apply, x.device)
+    call("mia_noise_clip", _p(x), _p(out), _c_i64(x.numel() // b), b, _p(sg), ctypes.c_uint64(seed), ctypes.c_uint64(offset),
+         _p(ap), _stream())
     return out
 
 
@@ -131,7 +132,8 @@ def lowres(img: torch.Tensor, low_hw: Sequence[Sequence[int]], apply=None) -> to
     b, c, h, w = x.shape
     out = torch.empty_like(x)
     lw = torch.tensor([[int(a), int(d)] for a, d in low_hw], dtype=torch.int32, device=x.device)
-    call("mia_resize_bilinear", _p(x), _p(out), b, c, h, w, h, w, _p(lw), _p(_apply(apply, x.device)), _stream())
+    ap = _apply(apply, x.device)
+    call("mia_resize_bilinear", _p(x), _p(out), b, c, h, w, h, w, _p(lw), _p(ap), _stream())
     return out
 
 
