@@ -60,6 +60,16 @@ int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const void* in2, 
                  int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2, int o2,
                  float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream);
 
+/* Stem: Conv2d(1, C0, 3, padding=1) (first encoder block, unet.py:54-66 with input_channels=1): HBM-streaming VALU
+ * kernels (9 FMAs per output; MFMA would idle 31/32 of its K).  x is the [N][H][W] image in x_dtype (fp32 or bf16),
+ * y / dy are NHWC in `dtype`; stat_partials [N][mia_stem_slabs()][C0][2]; grad is the [C0][1][3][3] parameter layout. */
+int mia_stem_slabs(void);
+int mia_stem_wgrad_workspace(int c0); /* floats */
+int mia_stem_fwd(const void* x, int x_dtype, const float* w, const float* bias, void* y, int dtype, float* stat_partials, int n,
+                 int h, int wd, int c0, void* stream);
+int mia_stem_wgrad(const void* x, int x_dtype, const void* dy, int dtype, float* workspace, float* grad, int n, int h, int wd,
+                   int c0, int accumulate, void* stream);
+
 #define MIA_WGRAD_3S1 0
 #define MIA_WGRAD_3S2 1
 #define MIA_WGRAD_2S2 2 /* ConvTranspose2d: x := grad_output (fine grid), dy := layer input (coarse grid) */

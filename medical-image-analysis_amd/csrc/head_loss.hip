@@ -52,7 +52,7 @@ __global__ void head_fwd_kernel(const T* __restrict__ x, const float* __restrict
       if (k < k1) {
         float v = acc[k];
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-        if (sub == 0) out[(p / hw) * osn + (p % hw) * osp + k * osk] = v + b[k];
+        if (sub == 0) out[(osn == hw * osp ? p * osp : (p / hw) * osn + (p % hw) * osp) + k * osk] = v + b[k];
       }
     }
   }
@@ -86,7 +86,7 @@ __global__ void head_bwd_input_kernel(const float* __restrict__ dl, const float*
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p = i / c0;
     const int ch = (int)(i - p * c0);
-    const float* g = dl + (p / hw) * gsn + (p % hw) * gsp;
+    const float* g = dl + (gsn == hw * gsp ? p * gsp : (p / hw) * gsn + (p % hw) * gsp);
     float s = 0.f;
     for (int k = 0; k < k1; ++k) s += g[k * gsk] * wsh[k * c0 + ch];
     Elem<T>::st(dx + i, s);
@@ -110,7 +110,7 @@ __global__ void head_bwd_weight_kernel(const float* __restrict__ dl, const T* __
     if (ch < c0 && tr < rows_par)
       for (int64_t p = r0 + tr; p < r1; p += rows_par) {
         const float xv = Elem<T>::ld(x + p * c0 + ch);
-        const float* g = dl + (p / hw) * gsn + (p % hw) * gsp;
+        const float* g = dl + (gsn == hw * gsp ? p * gsp : (p / hw) * gsn + (p % hw) * gsp);
 #pragma unroll
         for (int k = 0; k < MAXK; ++k)
           if (k < k1) { const float gv = g[k * gsk]; acc[k] += gv * xv; bacc[k] += gv; }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void head_bwd_input_vec_kernel(const float* __
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p = i / upp;
     const int ch = (int)(i - p * upp) * EPU;
-    const float* g = dl + (p / hw) * gsn + (p % hw) * gsp;
+    const float* g = dl + (gsn == hw * gsp ? p * gsp : (p / hw) * gsn + (p % hw) * gsp);
     float acc[EPU];
 #pragma unroll
     for (int e = 0; e < EPU; ++e) acc[e] = 0.f;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void head_bwd_weight_vec_kernel(const float* _
     for (int64_t p = r0 + pl; p < r1; p += lanes) {
       alignas(16) T v[EPU];
       *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(x + p * c0 + u * EPU);
-      const float* g = dl + (p / hw) * gsn + (p % hw) * gsp;
+      const float* g = dl + (gsn == hw * gsp ? p * gsp : (p / hw) * gsn + (p % hw) * gsp);
 #pragma unroll
       for (int k = 0; k < MAXK; ++k)
         if (k < k1) {

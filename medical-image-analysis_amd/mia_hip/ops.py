@@ -226,10 +226,18 @@ class PlainBlockFn(torch.autograd.Function):
     inputs x1 [N,H,W,C1] (+ optional x2 [N,H,W,C2], concatenated along C: unet.py:213)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, gamma, beta, stride: int, cfg: NormCfg):
+    def forward(ctx, x1, x2, weight, bias, gamma, beta, stride: int, cfg: NormCfg, out_dtype=None):
         _need_dev(x1, x2, weight)
         x1 = x1.contiguous()
         x2 = None if x2 is None else x2.contiguous()
+        out_dtype = out_dtype or x1.dtype
+        cout_ = weight.shape[0]
+        stem = (weight.shape[1] == 1 and x2 is None and stride == 1 and x1.shape[3] == 1 and not x1.requires_grad
+                and cout_ % (8 if out_dtype == torch.bfloat16 else 4) == 0 and cout_ <= 256)
+        if stem:
+            return PlainBlockFn._stem_forward(ctx, x1, weight, bias, gamma, beta, cfg, out_dtype)
+        if x1.dtype != out_dtype:
+            x1 = cast_nhwc(x1, out_dtype)
         if x2 is not None and (x2.shape[:3] != x1.shape[:3] or x2.dtype != x1.dtype):
             # same failure point as torch.cat([skip, up], 1) in the reference (unet.py:213)
             raise RuntimeError(f"Sizes of tensors must match except in dimension 1: {tuple(x1.shape)} vs {tuple(x2.shape)} (NHWC)")
@@ -253,7 +261,36 @@ class PlainBlockFn(torch.autograd.Function):
         call("mia_norm_act_fwd", _p(y), _p(z), dtype, _p(coefs[2]), _p(coefs[3]), n, _c_i64(ho * wo), cout,
              _c_float(LRELU_SLOPE), _stream())
         ctx.save_for_backward(x1, x2, y, coefs, weight, gamma)
-        ctx.stride, ctx.mode, ctx.fixed = stride, cfg.mode, fixed
+        ctx.stride, ctx.mode, ctx.fixed, ctx.stem = stride, cfg.mode, fixed, False
+        return z
+
+    @staticmethod
+    def _norm_act(ctx, y, stats, gamma, beta, cfg, n, cout, hw):
+        dev = y.device
+        coefs = torch.empty((5, n, cout), device=dev, dtype=torch.float32)  # xa, xb, scale, shift, sum_y
+        call("mia_norm_finalize", _p(stats), n, stats.shape[1], cout, _c_i64(hw), cfg.mode, int(cfg.training),
+             _p(cfg.drop_scale), _p(gamma.detach()), _p(beta.detach()), _c_float(cfg.eps), _c_float(cfg.momentum),
+             _p(cfg.running_mean), _p(cfg.running_var), _p(cfg.num_batches), _p(coefs[0]), _p(coefs[1]), _p(coefs[2]),
+             _p(coefs[3]), _p(coefs[4]), _stream())
+        z = torch.empty_like(y)
+        call("mia_norm_act_fwd", _p(y), _p(z), _dt(y), _p(coefs[2]), _p(coefs[3]), n, _c_i64(hw), cout, _c_float(LRELU_SLOPE),
+             _stream())
+        return z, coefs
+
+    @staticmethod
+    def _stem_forward(ctx, x1, weight, bias, gamma, beta, cfg, out_dtype):
+        n, h, w, _ = x1.shape
+        cout = weight.shape[0]
+        dev = x1.device
+        y = torch.empty((n, h, w, cout), device=dev, dtype=out_dtype)
+        stats = torch.empty((n, lib().mia_stem_slabs(), cout, 2), device=dev, dtype=torch.float32)
+        w2 = weight.detach().reshape(cout, 9)
+        if not w2.is_contiguous():
+            w2 = w2.contiguous()
+        call("mia_stem_fwd", _p(x1), _dt(x1), _p(w2), _p(bias.detach()), _p(y), _dt(y), _p(stats), n, h, w, cout, _stream())
+        z, coefs = PlainBlockFn._norm_act(ctx, y, stats, gamma, beta, cfg, n, cout, h * w)
+        ctx.save_for_backward(x1, None, y, coefs, weight, gamma)
+        ctx.stride, ctx.mode, ctx.fixed, ctx.stem = 1, cfg.mode, cfg.mode == NORM_BATCH and not cfg.training, True
         return z
 
     @staticmethod
@@ -274,6 +311,11 @@ class PlainBlockFn(torch.autograd.Function):
              _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(LRELU_SLOPE), slabs,
              _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
         cin = weight.shape[1]
+        if ctx.stem:
+            ws = torch.empty(lib().mia_stem_wgrad_workspace(cout), device=dev, dtype=torch.float32)
+            dw = torch.empty(weight.shape, device=dev, dtype=torch.float32)
+            call("mia_stem_wgrad", _p(x1), _dt(x1), _p(dy), dtype, _p(ws), _p(dw), n, ho, wo, cout, 0, _stream())
+            return None, None, dw, dbias, dgamma, dbeta, None, None, None
         wmode = WGRAD_3S2 if ctx.stride == 2 else WGRAD_3S1
         dw = conv_wgrad(wmode, x1, x2, dy, weight.shape, cout, cin)
         dx1 = dx2 = None
@@ -286,7 +328,7 @@ class PlainBlockFn(torch.autograd.Function):
                                        out_split=split)
             else:
                 dx1, dx2, _ = conv_mma(CONV_G3S1, dy, None, wb, npad, kpad, True, None, cin, (ho, wo), out_split=split)
-        return dx1, dx2, dw, dbias, dgamma, dbeta, None, None
+        return dx1, dx2, dw, dbias, dgamma, dbeta, None, None, None
 
 
 # ------------------------------------------------------------------ ConvTranspose2d(k=2, s=2)

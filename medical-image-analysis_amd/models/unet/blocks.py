@@ -96,10 +96,10 @@ class PlainBlock(nn.Module):
                                norm.num_batches_tracked, drop)
         return ops.NormCfg(NORM_INSTANCE, self.training, norm.eps, 0.1, None, None, None, drop)
 
-    def forward_nhwc(self, x1, x2=None):
+    def forward_nhwc(self, x1, x2=None, out_dtype=None):
         conv, norm = self.all[0], self.all[2]
         return ops.PlainBlockFn.apply(x1, x2, conv.weight, conv.bias, norm.weight, norm.bias, self.stride,
-                                      self._cfg(x1.shape[0], x1.device))
+                                      self._cfg(x1.shape[0], x1.device), out_dtype)
 
     def forward(self, x):
         dt = x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32

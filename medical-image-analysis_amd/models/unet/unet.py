@@ -36,10 +36,12 @@ class UNetEncoder(nn.Module):
                 block(dimension, in_channels, num_channels, stride=first_stride, **block_kwargs),
                 block(dimension, num_channels, num_channels, stride=1, **block_kwargs)))
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, compute_dtype=None):
+        """x: NHWC.  A 1-channel fp32 image may be passed as is: the stem kernel reads it directly and emits
+        `compute_dtype` activations (no separate cast pass)."""
         skips = []
-        for s in self.levels:
-            x = s[1].forward_nhwc(s[0].forward_nhwc(x))
+        for l, s in enumerate(self.levels):
+            x = s[1].forward_nhwc(s[0].forward_nhwc(x, out_dtype=compute_dtype if l == 0 else None))
             skips.append(x)
         return skips
 
@@ -163,7 +165,9 @@ class UNet(nn.Module):
         return self
 
     def _skips(self, x):
-        return self.encoder.forward_nhwc(ops.to_nhwc(x, self.compute_dtype))
+        if x.shape[1] == 1 and x.dtype == torch.float32:  # stem reads the fp32 image directly
+            return self.encoder.forward_nhwc(ops.to_nhwc(x, torch.float32), self.compute_dtype)
+        return self.encoder.forward_nhwc(ops.to_nhwc(x, self.compute_dtype), self.compute_dtype)
 
     def forward(self, x, return_ds=False):
         return self.decoder.forward_nhwc(self._skips(x), return_ds=return_ds)
