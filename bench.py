@@ -157,8 +157,11 @@ def main():
             esz = 2 if dt == "bf16" else 4
             abytes = 2.0 * c0 * size * size * batch * esz + 9 * c0 * c0 * esz
             ach = flops / (avg_ms * 1e-3) / 1e12
+            # HBM bytes per launch from rocprofv3 PMC passes on this exact launch (tools/microbench.py conv, cfg3 shape):
+            # 2 x FETCH_SIZE (gfx950 half-count correction) + WRITE_SIZE; profiles/r01_pmc_conv64_{fetch,write}_size.csv
+            traffic = 2.0 * 588160.0 * 1024 + 1064960.0 * 1024 if (args.config == "cfg3" and batch == 32 and dt == "bf16") else None
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS[dt], "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_MFMA_TFLOPS[dt], 4), "traffic": None,
+                    "frac": round(ach / PEAK_MFMA_TFLOPS[dt], 4), "traffic": traffic,
                     "kernel": f"conv_mma_kernel<{dt},G3S1,MT4,NT4> {c0}->{c0} 3x3 @{size}x{size} x{batch} (encoder.levels.0.1)",
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(kt), "flops_per_launch": flops,
                     "algorithmic_bytes_per_launch": abytes,

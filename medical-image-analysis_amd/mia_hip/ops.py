@@ -52,15 +52,25 @@ def _kb(dtype: int) -> int:
 
 
 # ------------------------------------------------------------------ weight packing (cached per parameter version)
+PARAM_EPOCH = 0
+
+
+def bump_param_epoch() -> None:
+    """Parameters were modified behind torch's back (the fused optimizer kernel writes the flat buffer directly and
+    does not touch tensor version counters): invalidate every packed-weight cache."""
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
+
+
 class PackCache:
-    """Packed copies of one fp32 parameter, invalidated by the tensor's version counter."""
+    """Packed copies of one fp32 parameter, invalidated by the tensor's version counter or the global epoch."""
 
     def __init__(self):
         self._store = {}
 
     def get(self, w: torch.Tensor, dtype: int, n_from_d0: bool, kpad_mult: Optional[int] = None) -> Tuple[torch.Tensor, int, int]:
         key = (dtype, n_from_d0)
-        ver = (w._version, w.data_ptr())
+        ver = (w._version, w.data_ptr(), PARAM_EPOCH)
         hit = self._store.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1], hit[2], hit[3]

@@ -98,6 +98,7 @@ class FlatOptimizer:
         b1, b2 = (g["momentum"], 0.0) if self.kind == OPT_SGD else g["betas"]
         ops.optim_step(self.kind, self.flat_param, self.flat_grad, self.m, self.v, float(g["lr"]), b1, b2, g["eps"],
                        float(g["weight_decay"]), self.step_count, clip, grad_scale)
+        ops.bump_param_epoch()  # the kernel bypasses tensor version counters: packed weights must be rebuilt
 
     def state_dict(self) -> Dict[str, object]:
         return {"step": self.step_count, "m": self.m, "v": self.v, "param_groups": self.param_groups, "name": self.name}
