@@ -186,11 +186,10 @@ __device__ __forceinline__ wrsrc_t wmake_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
-template <int MODE>
+template <int MODE, int TH>
 __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
   using G = WGeo<MODE>;
   constexpr int KS = G::KS, S = G::S, PAD = G::PAD, TAPS = G::TAPS;
-  constexpr int TH = (S == 1) ? 8 : 4;
   constexpr int XH = (TH - 1) * S + KS, XW = 15 * S + KS;
   constexpr int X_IT = (XH * XW + 31) / 32, D_IT = TH * 16 / 32;  // 32 pixels x 8 chunks per iteration
   constexpr int X_BYTES = X_IT * 32 * 128, D_BYTES = TH * 16 * 128;
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
     for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(ds + lds_d0 + 4096 * i) = pd[i];
     __syncthreads();
     if (tile + a.ksplit < ntiles) fetch(tile + a.ksplit);
-#pragma unroll
+#pragma unroll 2
     for (int kb = 0; kb < TH / 2; ++kb) {
       const int yy = 2 * kb + (grp >> 1), xb = 8 * (grp & 1) + qp;
       u32x4 af[4];
@@ -432,9 +431,16 @@ __global__ void wgrad_reduce_kernel(const float* slabs, int ksplit, int taps, in
   }
 }
 
-extern "C" int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x) {
+// tile heights (rows of 16 output pixels per split-K step)
+static int wgrad_tile_h(int mode, int dtype, int hy, bool fast) {
   const int s = mode == MODE_W3S1 ? 1 : 2;
-  const int th = dtype == MIA_BF16 ? (s == 1 ? 8 : 4) : (s == 1 ? 4 : 2);
+  if (dtype != MIA_BF16) return s == 1 ? 4 : 2;
+  (void)hy; (void)fast;  // 16-row tiles measured slower (more VGPRs, partial unroll): 575 vs 621 TFLOP/s at 64ch 512x512
+  return s == 1 ? 8 : 4;
+}
+
+extern "C" int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x) {
+  const int th = wgrad_tile_h(mode, dtype, hy, false);
   if (tiles_y) *tiles_y = ceil_div(hy, th);
   if (tiles_x) *tiles_x = ceil_div(wy, 16);
   return MIA_OK;
@@ -455,7 +461,6 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   WgArgs a;
   a.x1 = x1; a.x2 = x2; a.c1 = c1; a.c2 = c2; a.dy = dy; a.cdy = cdy; a.slabs = slabs;
   a.N = n; a.Hx = hx; a.Wx = wx; a.Hy = hy; a.Wy = wy; a.npad = npad; a.kpad = kpad; a.ksplit = ksplit;
-  mia_wgrad_geometry(mode, dtype, hy, wy, &a.tiles_y, &a.tiles_x);
   const int epu = dtype == MIA_BF16 ? 8 : 4;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vec_x = (c1 % epu == 0) && (c2 % epu == 0) && al16(x1) && (x2 == nullptr || al16(x2));
@@ -465,10 +470,14 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   const size_t lim = (size_t)1 << 31;
   const bool fast = dtype == MIA_BF16 && a.vec_x && a.vec_dy && c1 % 64 == 0 && c2 % 64 == 0 && cdy % 64 == 0 &&
                     (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 2 < lim && (size_t)hy * wy * cdy * 2 < lim;
+  const int th = wgrad_tile_h(mode, dtype, hy, fast);
+  a.tiles_y = ceil_div(hy, th);
+  a.tiles_x = ceil_div(wy, 16);
   if (fast) {
-    if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_bf16_fast_kernel<MODE_W3S1>, grid, dim3(256), 0, st, a);
-    else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_bf16_fast_kernel<MODE_W3S2>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wgrad_bf16_fast_kernel<MODE_W2S2>, grid, dim3(256), 0, st, a);
+    if (mode == MODE_W3S1 && th == 16) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 16>), grid, dim3(256), 0, st, a);
+    else if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 8>), grid, dim3(256), 0, st, a);
+    else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S2, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W2S2, 4>), grid, dim3(256), 0, st, a);
   } else if (dtype == MIA_BF16) {
     if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W3S1>, grid, dim3(256), 0, st, a);
     else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W3S2>, grid, dim3(256), 0, st, a);
