@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
     for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(ds + lds_d0 + 4096 * i) = pd[i];
     __syncthreads();
     if (tile + a.ksplit < ntiles) fetch(tile + a.ksplit);
-#pragma unroll 2
+#pragma unroll(TH <= 8 ? TH / 2 : 2)
     for (int kb = 0; kb < TH / 2; ++kb) {
       const int yy = 2 * kb + (grp >> 1), xb = 8 * (grp & 1) + qp;
       u32x4 af[4];

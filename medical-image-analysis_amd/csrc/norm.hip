@@ -222,6 +222,87 @@ extern "C" int mia_norm_stats(const void* y, int dtype, int n, int64_t hw, int c
   return MIA_OK;
 }
 
+// ---------------------------------------------------------------- streaming apply kernels (C % EPU == 0)
+// grid = (n * slabs, ceil(UPP / UPB)); a thread owns ONE 16-byte channel unit of image n, keeps that unit's
+// per-(n,c) coefficients in registers and streams its slab's pixels: no per-element coefficient loads or divisions.
+template <typename T>
+__global__ __launch_bounds__(256) void norm_act_fwd_stream_kernel(const T* __restrict__ y, T* __restrict__ z,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  int64_t hw, int c, int slabs, int upb, float slope) {
+  constexpr int EPU = Elem<T>::EPU;
+  const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  const int lanes = 256 / upb;
+  const int u = blockIdx.y * upb + threadIdx.x % upb, pl = threadIdx.x / upb;
+  if (u * EPU >= c) return;
+  const int64_t per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  float sc[EPU], sf[EPU];
+#pragma unroll
+  for (int e = 0; e < EPU; ++e) { sc[e] = scale[(size_t)n * c + u * EPU + e]; sf[e] = shift[(size_t)n * c + u * EPU + e]; }
+  const size_t base = (size_t)n * hw * c + (size_t)u * EPU;
+  for (int64_t r = r0 + pl; r < r1; r += lanes) {
+    alignas(16) T in[EPU]; alignas(16) T out[EPU];
+    *reinterpret_cast<u32x4*>(in) = *reinterpret_cast<const u32x4*>(y + base + r * c);
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) {
+      const float v = sc[e] * Elem<T>::ld(in + e) + sf[e];
+      out[e] = Elem<T>::cvt(v > 0.f ? v : v * slope);
+    }
+    *reinterpret_cast<u32x4*>(z + base + r * c) = *reinterpret_cast<const u32x4*>(out);
+  }
+}
+
+// dy = scale*(g - c1 - xhat*c2) = scale*g + ka*y + kb  with ka = -scale*c2*xa, kb = -scale*(c1 + c2*xb)
+template <typename T>
+__global__ __launch_bounds__(256) void norm_act_bwd_stream_kernel(const T* __restrict__ dz, const T* __restrict__ y, T* __restrict__ dy,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const float* __restrict__ xa, const float* __restrict__ xb,
+                                                                  const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                  int64_t hw, int c, int slabs, int upb, float slope) {
+  constexpr int EPU = Elem<T>::EPU;
+  const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  const int lanes = 256 / upb;
+  const int u = blockIdx.y * upb + threadIdx.x % upb, pl = threadIdx.x / upb;
+  if (u * EPU >= c) return;
+  const int64_t per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  float sc[EPU], sf[EPU], ka[EPU], kb[EPU];
+#pragma unroll
+  for (int e = 0; e < EPU; ++e) {
+    const size_t o = (size_t)n * c + u * EPU + e;
+    sc[e] = scale[o]; sf[e] = shift[o];
+    ka[e] = -sc[e] * c2[o] * xa[o];
+    kb[e] = -sc[e] * (c1[o] + c2[o] * xb[o]);
+  }
+  const size_t base = (size_t)n * hw * c + (size_t)u * EPU;
+  for (int64_t r = r0 + pl; r < r1; r += lanes) {
+    alignas(16) T gin[EPU]; alignas(16) T yin[EPU]; alignas(16) T out[EPU];
+    *reinterpret_cast<u32x4*>(gin) = *reinterpret_cast<const u32x4*>(dz + base + r * c);
+    *reinterpret_cast<u32x4*>(yin) = *reinterpret_cast<const u32x4*>(y + base + r * c);
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) {
+      const float yv = Elem<T>::ld(yin + e);
+      float g = Elem<T>::ld(gin + e);
+      if (!(sc[e] * yv + sf[e] > 0.f)) g *= slope;
+      out[e] = Elem<T>::cvt(sc[e] * g + ka[e] * yv + kb[e]);
+    }
+    *reinterpret_cast<u32x4*>(dy + base + r * c) = *reinterpret_cast<const u32x4*>(out);
+  }
+}
+
+static void stream_geometry(int n, int64_t hw, int c, int epu, int* slabs, int* upb, int* gy) {
+  const int upp = c / epu;
+  int ub = 1;
+  while (ub < upp && ub < 64) ub <<= 1;  // units per block (power of two <= 64): >= 4 pixel lanes
+  *upb = ub;
+  *gy = (upp + ub - 1) / ub;
+  // ~4096 blocks in total, each lane streaming >= 8 pixels
+  const int lanes = 256 / ub;
+  int64_t sl = 4096 / ((int64_t)n * *gy);
+  const int64_t maxsl = hw / (lanes * 8) > 0 ? hw / (lanes * 8) : 1;
+  if (sl > maxsl) sl = maxsl;
+  if (sl < 1) sl = 1;
+  *slabs = (int)sl;
+}
+
 // ---------------------------------------------------------------- forward apply: z = lrelu(scale*y + shift)
 template <typename T, bool VEC>
 __global__ void norm_act_fwd_kernel(const T* __restrict__ y, T* __restrict__ z, const float* __restrict__ scale,
@@ -259,6 +340,16 @@ extern "C" int mia_norm_act_fwd(const void* y, void* z, int dtype, const float* 
   const int64_t units = (int64_t)n * hw * (vec ? c / epu : c);
   const int blocks = (int)((units + 255) / 256 < 16384 ? (units + 255) / 256 : 16384);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (vec && (dtype == MIA_BF16 || dtype == MIA_F32)) {
+    int sl, upb, gy;
+    stream_geometry(n, hw, c, epu, &sl, &upb, &gy);
+    if (dtype == MIA_BF16)
+      hipLaunchKernelGGL(norm_act_fwd_stream_kernel<bf16_t>, dim3(n * sl, gy), dim3(256), 0, st, static_cast<const bf16_t*>(y), static_cast<bf16_t*>(z), scale, shift, hw, c, sl, upb, slope);
+    else
+      hipLaunchKernelGGL(norm_act_fwd_stream_kernel<float>, dim3(n * sl, gy), dim3(256), 0, st, static_cast<const float*>(y), static_cast<float*>(z), scale, shift, hw, c, sl, upb, slope);
+    MIA_LAUNCH_CHECK();
+    return MIA_OK;
+  }
 #define NA(T, V) hipLaunchKernelGGL((norm_act_fwd_kernel<T, V>), dim3(blocks), dim3(256), 0, st, static_cast<const T*>(y), \
                                     static_cast<T*>(z), scale, shift, hw, c, units, slope)
   if (dtype == MIA_BF16) { if (vec) NA(bf16_t, true); else NA(bf16_t, false); }
@@ -306,75 +397,72 @@ __global__ void norm_act_bwd_reduce_kernel(const T* __restrict__ dz, const T* __
   }
 }
 
-// pass 1b: combine partials -> per-(n,c) group means c1 = mean(g), c2 = mean(g*xhat); dgamma, dbeta, and the
-// gradient of the conv bias in front of the norm in closed form:
-//   sum_p dy = scale * (Sg - M*c1 - c2*Sxhat),  Sxhat = xa*Sy + M*xb   (M = H*W, per image)
-// (analytically 0 for instance norm -- the reference's autograd produces rounding noise there too).
-// Block = 16 channels x 16 lanes sweeping (image, slab).
-__global__ void norm_bwd_finalize_kernel(const float* __restrict__ part, int n_img, int slabs, int c, int64_t hw, int mode,
-                                         int fixed_stats, const float* __restrict__ scale, const float* __restrict__ xa,
-                                         const float* __restrict__ xb, const float* __restrict__ ysum, float* __restrict__ c1,
-                                         float* __restrict__ c2, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                         float* __restrict__ dbias, int accumulate) {
+// pass 1b (two tiny launches, fully parallel, fixed summation order):
+//  K1  grid (image, 16-channel group): the 16 lanes of each channel sweep the slab partials -> per-(n,c) sums
+//      Sg = sum g, Sgx = sum g*xhat, parked in c1 / c2.
+//  K2  grid (16-channel group): lanes sweep images -> dgamma = sum_n Sgx, dbeta = sum_n Sg, the group means
+//      c1 = mean(g), c2 = mean(g*xhat) (per image for instance norm, over the batch for batch norm; 0 for frozen
+//      statistics), and the gradient of the conv bias in front of the norm in closed form:
+//        sum_p dy = scale * (Sg - M*c1 - c2*Sxhat),  Sxhat = xa*Sy + M*xb   (M = H*W)
+//      (analytically 0 for instance norm -- the reference's autograd produces rounding noise there too).
+__global__ void norm_bwd_sum_kernel(const float* __restrict__ part, int slabs, int c, float* __restrict__ c1,
+                                    float* __restrict__ c2) {
   __shared__ double sh1[16][17], sh2[16][17];
-  __shared__ double sg[16][33], sgx[16][33];  // per-image sums for up to 32 images per pass (instance / dbias)
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
-  const int ch = blockIdx.x * 16 + cl;
-  double tg = 0.0, tgx = 0.0, tb = 0.0;
-  for (int nb0 = 0; nb0 < n_img; nb0 += 32) {
-    const int ncnt = n_img - nb0 < 32 ? n_img - nb0 : 32;
-    // each lane owns images nb0 + tl, nb0 + tl + 16
-    for (int j = tl; j < ncnt; j += 16) {
-      double s1 = 0.0, s2 = 0.0;
-      if (ch < c)
-        for (int s = 0; s < slabs; ++s) {
-          const float* p = part + (((size_t)(nb0 + j) * slabs + s) * c + ch) * 2;
-          s1 += p[0]; s2 += p[1];
-        }
-      sg[cl][j] = s1; sgx[cl][j] = s2;
+  const int n = blockIdx.x, ch = blockIdx.y * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (ch < c)
+    for (int s = tl; s < slabs; s += 16) {
+      const float* p = part + (((size_t)n * slabs + s) * c + ch) * 2;
+      s1 += p[0]; s2 += p[1];
     }
-    __syncthreads();
-    if (tl == 0 && ch < c)
-      for (int j = 0; j < ncnt; ++j) { tg += sg[cl][j]; tgx += sgx[cl][j]; }
-    if (mode == NORM_INSTANCE && ch < c)
-      for (int j = tl; j < ncnt; j += 16) {
-        const int idx = (nb0 + j) * c + ch;
-        const double m1 = fixed_stats ? 0.0 : sg[cl][j] / (double)hw, m2 = fixed_stats ? 0.0 : sgx[cl][j] / (double)hw;
-        c1[idx] = (float)m1; c2[idx] = (float)m2;
-      }
-    if (mode == NORM_INSTANCE && dbias && tl == 0 && ch < c)
-      for (int j = 0; j < ncnt; ++j) {
-        const int idx = (nb0 + j) * c + ch;
-        const double m1 = fixed_stats ? 0.0 : sg[cl][j] / (double)hw, m2 = fixed_stats ? 0.0 : sgx[cl][j] / (double)hw;
-        const double sxh = ysum ? (double)xa[idx] * ysum[idx] + (double)hw * xb[idx] : 0.0;
-        tb += (double)scale[idx] * (sg[cl][j] - (double)hw * m1 - m2 * sxh);
-      }
-    __syncthreads();
-  }
-  sh1[tl][cl] = 0; sh2[tl][cl] = 0;
-  if (tl == 0) { sh1[0][cl] = tg; sh2[0][cl] = tgx; }
-  __syncthreads();
-  tg = sh1[0][cl]; tgx = sh2[0][cl];
-  __syncthreads();  // everyone has read the totals before sh1 is reused below
-  if (mode == NORM_BATCH && ch < c) {
-    const double cnt = (double)n_img * (double)hw;
-    const double m1 = fixed_stats ? 0.0 : tg / cnt, m2 = fixed_stats ? 0.0 : tgx / cnt;
-    double tbl = 0.0;
-    for (int n = tl; n < n_img; n += 16) {
-      const int idx = n * c + ch;
-      c1[idx] = (float)m1; c2[idx] = (float)m2;
-      if (dbias) {
-        double s1 = 0.0;
-        for (int s = 0; s < slabs; ++s) s1 += part[(((size_t)n * slabs + s) * c + ch) * 2];
-        const double sxh = ysum ? (double)xa[idx] * ysum[idx] + (double)hw * xb[idx] : 0.0;
-        tbl += (double)scale[idx] * (s1 - (double)hw * m1 - m2 * sxh);
-      }
-    }
-    sh1[tl][cl] = tbl;
-  }
+  sh1[tl][cl] = s1; sh2[tl][cl] = s2;
   __syncthreads();
   if (tl == 0 && ch < c) {
-    if (mode == NORM_BATCH) { tb = 0.0; for (int j = 0; j < 16; ++j) tb += sh1[j][cl]; }
+    s1 = 0.0; s2 = 0.0;
+    for (int j = 0; j < 16; ++j) { s1 += sh1[j][cl]; s2 += sh2[j][cl]; }
+    c1[(size_t)n * c + ch] = (float)s1; c2[(size_t)n * c + ch] = (float)s2;
+  }
+}
+
+__global__ void norm_bwd_finalize_kernel(int n_img, int c, int64_t hw, int mode, int fixed_stats, const float* __restrict__ scale,
+                                         const float* __restrict__ xa, const float* __restrict__ xb, const float* __restrict__ ysum,
+                                         float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ dgamma,
+                                         float* __restrict__ dbeta, float* __restrict__ dbias, int accumulate) {
+  __shared__ double sh1[16][17], sh2[16][17], sh3[16][17];
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  const double M = (double)hw;
+  double tg = 0.0, tgx = 0.0;
+  if (ch < c)
+    for (int n = tl; n < n_img; n += 16) { tg += c1[(size_t)n * c + ch]; tgx += c2[(size_t)n * c + ch]; }
+  sh1[tl][cl] = tg; sh2[tl][cl] = tgx;
+  __syncthreads();
+  tg = 0.0; tgx = 0.0;
+  for (int j = 0; j < 16; ++j) { tg += sh1[j][cl]; tgx += sh2[j][cl]; }
+  __syncthreads();
+  const double cnt = (double)n_img * M;
+  double tb = 0.0;
+  if (ch < c)
+    for (int n = tl; n < n_img; n += 16) {
+      const size_t idx = (size_t)n * c + ch;
+      const double sg = c1[idx], sgx = c2[idx];
+      double m1 = 0.0, m2 = 0.0;
+      if (!fixed_stats) {
+        if (mode == NORM_INSTANCE) { m1 = sg / M; m2 = sgx / M; }
+        else { m1 = tg / cnt; m2 = tgx / cnt; }
+      }
+      c1[idx] = (float)m1; c2[idx] = (float)m2;
+      if (dbias) {
+        const double sxh = ysum ? (double)xa[idx] * ysum[idx] + M * xb[idx] : 0.0;
+        tb += (double)scale[idx] * (sg - M * m1 - m2 * sxh);
+      }
+    }
+  sh3[tl][cl] = tb;
+  __syncthreads();
+  if (tl == 0 && ch < c) {
+    tb = 0.0;
+    for (int j = 0; j < 16; ++j) tb += sh3[j][cl];
     dgamma[ch] = accumulate ? dgamma[ch] + (float)tgx : (float)tgx;
     dbeta[ch] = accumulate ? dbeta[ch] + (float)tg : (float)tg;
     if (dbias) dbias[ch] = accumulate ? dbias[ch] + (float)tb : (float)tb;
@@ -439,10 +527,18 @@ extern "C" int mia_norm_act_bwd(const void* dz, const void* y, void* dy, int dty
     else
       hipLaunchKernelGGL((colreduce_vec_kernel<float, true>), dim3(n * slabs, c / 64), dim3(256), 0, st, static_cast<const float*>(dz), static_cast<const float*>(y), scale, shift, xa, xb, hw, c, slabs, slope, partials);
   } else if (dtype == MIA_BF16) RD(bf16_t); else RD(float);
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, partials, n, slabs, c, hw, mode,
-                     fixed_stats, scale, xa, xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate);
-  if (dtype == MIA_BF16) { if (vec) AP(bf16_t, true); else AP(bf16_t, false); }
-  else { if (vec) AP(float, true); else AP(float, false); }
+  hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3(n, ceil_div(c, 16)), dim3(256), 0, st, partials, slabs, c, c1, c2);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, mode, fixed_stats, scale, xa,
+                     xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate);
+  if (vec) {
+    int sl, upb, gy;
+    stream_geometry(n, hw, c, epu, &sl, &upb, &gy);
+    if (dtype == MIA_BF16)
+      hipLaunchKernelGGL(norm_act_bwd_stream_kernel<bf16_t>, dim3(n * sl, gy), dim3(256), 0, st, static_cast<const bf16_t*>(dz), static_cast<const bf16_t*>(y), static_cast<bf16_t*>(dy), scale, shift, xa, xb, c1, c2, hw, c, sl, upb, slope);
+    else
+      hipLaunchKernelGGL(norm_act_bwd_stream_kernel<float>, dim3(n * sl, gy), dim3(256), 0, st, static_cast<const float*>(dz), static_cast<const float*>(y), static_cast<float*>(dy), scale, shift, xa, xb, c1, c2, hw, c, sl, upb, slope);
+  } else if (dtype == MIA_BF16) AP(bf16_t, false);
+  else AP(float, false);
 #undef RD
 #undef AP
   MIA_LAUNCH_CHECK();
