@@ -18,6 +18,8 @@
 // bf16: v_mfma_f32_16x16x32_bf16, one per 32-channel block; fp32: 4 x v_mfma_f32_16x16x4_f32 per
 // 16-channel block (exact fp32 fma chains).  Epilogue: +bias, optional per-(image,tile,channel)
 // sum / sum-of-squares partials for the norm layer, tile transposed through LDS, 16-byte stores.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 template <typename T, int MODE, int MT, int NT>
@@ -266,7 +268,7 @@ static void launch_mt(const ConvArgs& a, int mt, int nt, int grid_y, hipStream_t
   if constexpr (MODE == MODE_G3S2 || MODE == MODE_G2S2) {
     launch_nt<T, MODE, 2>(a, nt, grid_y, st);
   } else {
-    if (mt == 4) launch_nt<T, MODE, 4>(a, nt, grid_y, st);
+    if (mt >= 4) launch_nt<T, MODE, 4>(a, nt, grid_y, st);
     else launch_nt<T, MODE, 2>(a, nt, grid_y, st);
   }
 }
@@ -286,10 +288,14 @@ static int dispatch(int mode, const ConvArgs& a, int mt, int nt, int grid_y, hip
 }
 
 // Tile-domain geometry shared with the host (stats buffer sizing): see include/mia_hip.h.
+static int g_big_tiles = -1;  // MIA_CONV_MT8=1: 32-row tiles for bf16 3x3 s1 (experiment knob, default off)
+
 extern "C" int mia_conv_mma_tiles(int mode, int hout, int wout, int* tiles_y, int* tiles_x, int* tile_h) {
   const bool tmode = (mode == MODE_T3S2 || mode == MODE_T2S2);
   const int hd = tmode ? (hout + 1) / 2 : hout, wd = tmode ? (wout + 1) / 2 : wout;
+  if (g_big_tiles < 0) { const char* e = getenv("MIA_CONV_MT8"); g_big_tiles = (e && e[0] == '1') ? 1 : 0; }
   int mt = (mode == MODE_G3S2 || mode == MODE_G2S2) ? 2 : (hd > 8 ? 4 : 2);
+  if (g_big_tiles && mode == MODE_G3S1 && hd >= 32) mt = 8;
   const int th = 4 * mt;
   if (tiles_y) *tiles_y = ceil_div(hd, th);
   if (tiles_x) *tiles_x = ceil_div(wd, 16);
@@ -336,7 +342,12 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
   const int grid_y = tmode ? 4 : 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;
-  if (conv_mma_fast_eligible(dtype, a, nt)) rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
+  const bool fast = conv_mma_fast_eligible(dtype, a, nt);
+  if (mt == 8 && !(fast && dtype == MIA_BF16 && nt == 4 && mode == MODE_G3S1)) {
+    mia_set_error("mia_conv_mma: MIA_CONV_MT8 tiles need the bf16 fast path with >= 64 output channels");
+    return MIA_EUNSUPPORTED;
+  }
+  if (fast) rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
   else rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);
   if (rc != MIA_OK) return rc;
   MIA_LAUNCH_CHECK();

@@ -18,7 +18,7 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 }
 
 template <typename T, int MODE, int MT, int NT>
-__global__ __launch_bounds__(256, 2) void conv_mma_fast_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(const ConvArgs a) {
   using G = Geo<MODE, MT>;
   constexpr int TH = G::TH, BN = 16 * NT, EPU = Elem<T>::EPU, KB = 4 * EPU, ES = (int)sizeof(T);
   constexpr int PITCH = G::PITCH, S = G::S, IW = G::IW, IH = G::IH;
@@ -251,7 +251,10 @@ static void flaunch_mt(const ConvArgs& a, int mt, int nt, int grid_y, hipStream_
   if constexpr (MODE == MODE_G3S2 || MODE == MODE_G2S2) {
     flaunch_nt<T, MODE, 2>(a, nt, grid_y, st);
   } else {
-    if (mt == 4) flaunch_nt<T, MODE, 4>(a, nt, grid_y, st);
+    if constexpr (MODE == MODE_G3S1 && sizeof(T) == 2) {
+      if (mt == 8 && nt == 4) { flaunch<T, MODE, 8, 4>(a, grid_y, st); return; }
+    }
+    if (mt >= 4) flaunch_nt<T, MODE, 4>(a, nt, grid_y, st);
     else flaunch_nt<T, MODE, 2>(a, nt, grid_y, st);
   }
 }

@@ -115,7 +115,9 @@ __global__ void head_bwd_weight_kernel(const float* __restrict__ dl, const T* __
         for (int k = 0; k < MAXK; ++k)
           if (k < k1) { const float gv = g[k * gsk]; acc[k] += gv * xv; bacc[k] += gv; }
       }
-    for (int k = 0; k < k1; ++k) {
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      if (k >= k1) break;
       __syncthreads();
       sh[threadIdx.x] = acc[k];
       sh[blockDim.x + threadIdx.x] = bacc[k];
@@ -174,11 +176,13 @@ __global__ __launch_bounds__(256) void head_bwd_input_vec_kernel(const float* __
     float acc[EPU];
 #pragma unroll
     for (int e = 0; e < EPU; ++e) acc[e] = 0.f;
-    for (int k = 0; k < k1; ++k) {
-      const float gv = g[k * gsk];
 #pragma unroll
-      for (int e = 0; e < EPU; ++e) acc[e] += gv * wsh[k * c0 + ch + e];
-    }
+    for (int k = 0; k < MAXK; ++k)
+      if (k < k1) {
+        const float gv = g[k * gsk];
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) acc[e] += gv * wsh[k * c0 + ch + e];
+      }
     alignas(16) T out[EPU];
 #pragma unroll
     for (int e = 0; e < EPU; ++e) out[e] = Elem<T>::cvt(acc[e]);
@@ -218,18 +222,21 @@ __global__ __launch_bounds__(256) void head_bwd_weight_vec_kernel(const float* _
           for (int e = 0; e < EPU; ++e) acc[k][e] += gv * Elem<T>::ld(v + e);
         }
     }
-  for (int k = 0; k < k1; ++k) {
-    __syncthreads();
-    if (pl < lanes) {
 #pragma unroll
-      for (int e = 0; e < EPU; ++e) shd[pl * shs + u * EPU + e] = acc[k][e];
-      if (u == 0) shd[pl * shs + c0] = bacc[k];
-    }
-    __syncthreads();
-    if (threadIdx.x <= c0) {
-      float t = 0.f;
-      for (int j = 0; j < lanes; ++j) t += shd[j * shs + threadIdx.x];
-      part[((size_t)blockIdx.x * k1 + k) * (c0 + 1) + threadIdx.x] = t;
+  for (int k = 0; k < MAXK; ++k) {  // static indexing: a runtime k would push acc[][] to scratch memory
+    if (k < k1) {
+      __syncthreads();
+      if (pl < lanes) {
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) shd[pl * shs + u * EPU + e] = acc[k][e];
+        if (u == 0) shd[pl * shs + c0] = bacc[k];
+      }
+      __syncthreads();
+      if (threadIdx.x <= c0) {
+        float t = 0.f;
+        for (int j = 0; j < lanes; ++j) t += shd[j * shs + threadIdx.x];
+        part[((size_t)blockIdx.x * k1 + k) * (c0 + 1) + threadIdx.x] = t;
+      }
     }
   }
 }

@@ -14,94 +14,95 @@
 #define NORM_BATCH 1
 
 // ---------------------------------------------------------------- forward statistics finalize
-// partials: [N][T][C][2] (sum, sumsq) of the raw conv output.  Block = 16 channels x 16 tile-lanes; instance mode:
-// one block per (image, channel group); batch mode: one block per channel group, lanes sweep (image, tile).
-// Accumulates in double: var = E[y^2] - mean^2 must not cancel in fp32.  ysum[N][C] (optional) keeps the
-// per-(n,c) sum of y for the closed-form conv-bias gradient in the backward pass.
-__global__ void norm_finalize_kernel(const float* __restrict__ part, int n_img, int tiles, int c, int64_t hw, int mode,
-                                     int training, const float* __restrict__ drop, const float* __restrict__ gamma,
-                                     const float* __restrict__ beta, float eps, float momentum, float* running_mean,
-                                     float* running_var, long long* num_batches, float* __restrict__ xa,
+// partials: [N][T][C][2] (sum, sumsq) of the raw conv output, from the conv epilogue.  Two tiny launches, fully
+// parallel, fixed summation order, double accumulation (var = E[y^2] - mean^2 must not cancel in fp32):
+//  K1  grid (image, 16-channel group): the 16 lanes of a channel sweep the tile partials -> per-(n,c) sum / sumsq,
+//      parked in xa / xb.
+//  K2  grid (16-channel group): lanes sweep images.  Instance norm: coefficients per (n,c).  Batch norm: combine
+//      over the batch (with the Dropout2d masks folded in), update running statistics, then per-(n,c) coefficients.
+// ysum[N][C] (optional) keeps sum(y) for the closed-form conv-bias gradient of the backward pass.
+__global__ void norm_fwd_sum_kernel(const float* __restrict__ part, int tiles, int c, float* __restrict__ xa, float* __restrict__ xb) {
+  __shared__ double sh1[16][17], sh2[16][17];
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int n = blockIdx.x, ch = blockIdx.y * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (ch < c)
+    for (int t = tl; t < tiles; t += 16) {
+      const float* p = part + (((size_t)n * tiles + t) * c + ch) * 2;
+      s1 += p[0]; s2 += p[1];
+    }
+  sh1[tl][cl] = s1; sh2[tl][cl] = s2;
+  __syncthreads();
+  if (tl == 0 && ch < c) {
+    s1 = 0.0; s2 = 0.0;
+    for (int j = 0; j < 16; ++j) { s1 += sh1[j][cl]; s2 += sh2[j][cl]; }
+    xa[(size_t)n * c + ch] = (float)s1; xb[(size_t)n * c + ch] = (float)s2;
+  }
+}
+
+__global__ void norm_finalize_kernel(int n_img, int c, int64_t hw, int mode, int training, const float* __restrict__ drop,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                     float* running_mean, float* running_var, long long* num_batches, float* __restrict__ xa,
                                      float* __restrict__ xb, float* __restrict__ scale, float* __restrict__ shift,
                                      float* __restrict__ ysum) {
   __shared__ double sh1[16][17], sh2[16][17];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
-  const int cgroups = (c + 15) / 16;
-  const int cg = blockIdx.x % cgroups;
-  const int ch = cg * 16 + cl;
+  const int ch = blockIdx.x * 16 + cl;
+  const double M = (double)hw;
   if (mode == NORM_INSTANCE) {
-    const int n = blockIdx.x / cgroups;
-    double s1 = 0.0, s2 = 0.0;
     if (ch < c)
-      for (int t = tl; t < tiles; t += 16) {
-        const float* p = part + (((size_t)n * tiles + t) * c + ch) * 2;
-        s1 += p[0]; s2 += p[1];
+      for (int n = tl; n < n_img; n += 16) {
+        const size_t idx = (size_t)n * c + ch;
+        const double s1 = xa[idx], s2 = xb[idx];
+        const double m = drop ? (double)drop[idx] : 1.0;
+        const double mean = s1 / M;
+        double var = s2 / M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(m * m * var + (double)eps);
+        const float a_ = (float)(m * rstd), b_ = (float)(-m * mean * rstd);
+        xa[idx] = a_; xb[idx] = b_;
+        scale[idx] = gamma[ch] * a_; shift[idx] = gamma[ch] * b_ + beta[ch];
+        if (ysum) ysum[idx] = (float)s1;
       }
-    sh1[tl][cl] = s1; sh2[tl][cl] = s2;
-    __syncthreads();
-    if (tl == 0 && ch < c) {
-      s1 = 0.0; s2 = 0.0;
-      for (int j = 0; j < 16; ++j) { s1 += sh1[j][cl]; s2 += sh2[j][cl]; }
-      const int idx = n * c + ch;
-      const double m = drop ? (double)drop[idx] : 1.0;
-      const double mean = s1 / (double)hw;
-      double var = s2 / (double)hw - mean * mean;
-      if (var < 0.0) var = 0.0;
-      const double rstd = 1.0 / sqrt(m * m * var + (double)eps);
-      const float a_ = (float)(m * rstd), b_ = (float)(-m * mean * rstd);
-      xa[idx] = a_; xb[idx] = b_;
-      scale[idx] = gamma[ch] * a_; shift[idx] = gamma[ch] * b_ + beta[ch];
-      if (ysum) ysum[idx] = (float)s1;
-    }
     return;
   }
-  // batch
   double rstd = 0.0, meanp = 0.0;
   if (training) {
     double e1 = 0.0, e2 = 0.0;
     if (ch < c)
-      for (int it = tl; it < n_img * tiles; it += 16) {
-        const int n = it / tiles;
-        const float* p = part + ((size_t)it * c + ch) * 2;
-        const double m = drop ? (double)drop[n * c + ch] : 1.0;
-        e1 += m * p[0]; e2 += m * m * p[1];
+      for (int n = tl; n < n_img; n += 16) {
+        const size_t idx = (size_t)n * c + ch;
+        const double m = drop ? (double)drop[idx] : 1.0;
+        e1 += m * xa[idx]; e2 += m * m * xb[idx];
+        if (ysum) ysum[idx] = xa[idx];
       }
     sh1[tl][cl] = e1; sh2[tl][cl] = e2;
     __syncthreads();
-    if (tl == 0 && ch < c) {
-      e1 = 0.0; e2 = 0.0;
-      for (int j = 0; j < 16; ++j) { e1 += sh1[j][cl]; e2 += sh2[j][cl]; }
-      const double cnt = (double)n_img * (double)hw;
-      meanp = e1 / cnt;
-      double var = e2 / cnt - meanp * meanp;
-      if (var < 0.0) var = 0.0;
-      rstd = 1.0 / sqrt(var + (double)eps);
-      if (running_mean) {
-        const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-        running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * meanp);
-        running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
-        if (ch == 0 && num_batches) *num_batches += 1;
-      }
-      sh1[0][cl] = meanp; sh2[0][cl] = rstd;
+    e1 = 0.0; e2 = 0.0;
+    for (int j = 0; j < 16; ++j) { e1 += sh1[j][cl]; e2 += sh2[j][cl]; }
+    const double cnt = (double)n_img * M;
+    meanp = e1 / cnt;
+    double var = e2 / cnt - meanp * meanp;
+    if (var < 0.0) var = 0.0;
+    rstd = 1.0 / sqrt(var + (double)eps);
+    if (tl == 0 && ch < c && running_mean) {
+      const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+      running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * meanp);
+      running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+      if (ch == 0 && num_batches) *num_batches += 1;
     }
-    __syncthreads();
-    meanp = sh1[0][cl]; rstd = sh2[0][cl];
-    if (ysum && ch < c)  // per-(n,c) raw sums (lanes sweep images)
-      for (int n = tl; n < n_img; n += 16) {
-        double s1 = 0.0;
-        for (int t = 0; t < tiles; ++t) s1 += part[(((size_t)n * tiles + t) * c + ch) * 2];
-        ysum[n * c + ch] = (float)s1;
-      }
+    __syncthreads();  // all lanes have read the raw sums parked in xa / xb before they are overwritten
   } else if (ch < c) {
     meanp = running_mean[ch];
     rstd = 1.0 / sqrt((double)running_var[ch] + (double)eps);
   }
   if (ch < c)
     for (int n = tl; n < n_img; n += 16) {
-      const double m = (training && drop) ? (double)drop[n * c + ch] : 1.0;
+      const size_t idx = (size_t)n * c + ch;
+      const double m = (training && drop) ? (double)drop[idx] : 1.0;
       const float a_ = (float)(m * rstd), b_ = (float)(-meanp * rstd);
-      xa[n * c + ch] = a_; xb[n * c + ch] = b_;
-      scale[n * c + ch] = gamma[ch] * a_; shift[n * c + ch] = gamma[ch] * b_ + beta[ch];
+      xa[idx] = a_; xb[idx] = b_;
+      scale[idx] = gamma[ch] * a_; shift[idx] = gamma[ch] * b_ + beta[ch];
     }
 }
 
@@ -113,11 +114,12 @@ extern "C" int mia_norm_finalize(const float* partials, int n, int tiles, int c,
   MIA_CHECK_ARG(gamma && beta && xa && xb && scale && shift && n > 0 && c > 0 && hw > 0, "mia_norm_finalize: bad arguments");
   MIA_CHECK_ARG(partials || (mode == NORM_BATCH && !training), "mia_norm_finalize: partials required");
   MIA_CHECK_ARG(mode == NORM_INSTANCE || training || (running_mean && running_var), "mia_norm_finalize: eval batch norm needs running stats");
+  hipStream_t st = static_cast<hipStream_t>(stream);
   const int cgroups = ceil_div(c, 16);
-  const int blocks = mode == NORM_INSTANCE ? n * cgroups : cgroups;
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), partials, n, tiles, c, hw,
-                     mode, training, drop_scale, gamma, beta, eps, momentum, running_mean, running_var, num_batches, xa, xb,
-                     scale, shift, (partials && training) || mode == NORM_INSTANCE ? ysum : nullptr);
+  const bool need_sums = mode == NORM_INSTANCE || training;
+  if (need_sums) hipLaunchKernelGGL(norm_fwd_sum_kernel, dim3(n, cgroups), dim3(256), 0, st, partials, tiles, c, xa, xb);
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(cgroups), dim3(256), 0, st, n, c, hw, mode, training, drop_scale, gamma, beta, eps,
+                     momentum, running_mean, running_var, num_batches, xa, xb, scale, shift, need_sums ? ysum : nullptr);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
