@@ -175,6 +175,19 @@ int mia_resize_bilinear_aa(const float* in, float* tmp, float* out, int nb, int 
 /* JointResize label path / UnetProcessor.postprocess: interpolate(nearest) */
 int mia_resize_nearest(const void* in, void* out, int elem_bytes, int64_t planes, int h, int w, int oh, int ow, void* stream);
 
+/* ------------------------------------------------------------------ validation / selection reductions */
+/* pred = output.softmax(1).argmax(1) (al_trainer.py:1430-1431) + per-(image, class) hard Dice of calculate_metric_percase
+ * (:1539-1556, medpy.metric.dc: 2|A&B|/(|A|+|B|), 0 for an empty prediction).  pred / (labels, workspace, counts[B][K1][3],
+ * dice[B][K1]) are each optional. */
+int mia_argmax_dice_workspace(int nb, int k1, int slabs); /* floats */
+int mia_argmax_dice(const float* logits, const long long* labels, long long* pred, int nb, int64_t hw, int k1, int64_t sn, int64_t sk,
+                    int64_t sp, int slabs, float* workspace, float* counts, float* dice, void* stream);
+/* scores[B][3] = (entropy, least-confidence, margin) acquisition scores of the active-learning selectors
+ * (entropy_selector.py:42-49, confidence_selector.py:42-47, margin_selector.py:42-48) */
+int mia_selector_scores_workspace(int nb, int slabs); /* floats */
+int mia_selector_scores(const float* logits, int nb, int64_t hw, int k1, int64_t sn, int64_t sk, int64_t sp, int slabs,
+                        float* workspace, float* scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -288,3 +288,40 @@ def test_optimizer_and_clip(kind):
         torch.cuda.synchronize()
         assert abs(clip[0].item() - tn.item()) / tn.item() < 1e-5
         assert relerr(pd, pr) < 2e-6, (kind, step)
+
+
+@pytest.mark.parametrize("k1,layout", [(3, "nchw"), (4, "nhwc"), (2, "nchw")])
+def test_validation_argmax_dice_and_selector_scores(k1, layout):
+    """argmax + per-class hard Dice (medpy.dc closed form) and the selectors' scores."""
+    from activelearning.scores import selector_scores
+    from metric.segmentation import predict_and_dice
+    from oracle.losses_ref import hard_dice
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    b, h, w = 3, 40, 56
+    logits = torch.randn(b, k1, h, w, generator=g) * 3
+    labels = torch.randint(0, k1, (b, h, w), generator=g)
+    labels[1][labels[1] == 1] = 0  # class 1 absent in image 1's ground truth
+    logits[2, 1] = -50.0           # class 1 never predicted in image 2 -> Dice 0 by convention
+    ld = logits.to(dev)
+    if layout == "nhwc":
+        ld = ld.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    pred, dice, counts = predict_and_dice(ld, labels.to(dev))
+    ref_pred = logits.softmax(1).argmax(1)
+    assert torch.equal(pred.cpu(), ref_pred)
+    for i in range(b):
+        for k in range(k1):
+            assert abs(dice[i, k].item() - hard_dice(ref_pred[i] == k, labels[i] == k)) < 1e-6, (i, k)
+    assert torch.equal(counts[..., 2].cpu().long(), torch.stack([(labels == k).sum((1, 2)) for k in range(k1)], 1))
+    pred_only, d2, c2 = predict_and_dice(ld)
+    assert torch.equal(pred_only.cpu(), ref_pred) and d2 is None and c2 is None
+    # selector scores (entropy_selector.py:42-49, confidence_selector.py:42-47, margin_selector.py:42-48)
+    prob = logits.softmax(1)
+    ent = torch.mean(-prob * torch.log2(prob + 1e-8), dim=1).mean(dim=[-2, -1])
+    conf = (-1 * prob.max(1)[0]).mean(dim=[-2, -1])
+    top2 = prob.topk(2, dim=1)[0]
+    marg = (-1 * (top2[:, 0] - top2[:, 1])).mean(dim=[-2, -1])
+    sc = selector_scores(ld).cpu()
+    np.testing.assert_allclose(sc[:, 0].numpy(), ent.numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(sc[:, 1].numpy(), conf.numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(sc[:, 2].numpy(), marg.numpy(), rtol=2e-5, atol=1e-6)
