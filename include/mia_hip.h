@@ -38,6 +38,8 @@ int mia_pack_weight(const float* src, void* dst, int dtype, int d0, int d1, int 
  * (replaces .to(dtype)/.contiguous() at al_trainer.py:1366-1368). */
 int mia_relayout(const void* src, int src_dtype, void* dst, int dst_dtype, int n, int c, int64_t hw,
                  int64_t ssn, int64_t ssc, int64_t ssp, int64_t dsn, int64_t dsc, int64_t dsp, void* stream);
+/* out = a + b: the residual connection of ResidualBlock (blocks.py:164) */
+int mia_add(const void* a, const void* b, void* out, int dtype, int64_t n, void* stream);
 /* out[c] (+)= sum over p rows of x[p][c]: bias gradients of Conv2d / ConvTranspose2d. */
 int mia_colsum_workspace(int64_t p, int c); /* floats */
 int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, float* out, int accumulate, void* stream);

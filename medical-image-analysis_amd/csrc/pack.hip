@@ -179,3 +179,33 @@ extern "C" int mia_colsum(const void* x, int dtype, int64_t p, int c, float* wor
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
+
+// ---- out = a + b (residual connection of ResidualBlock, reference blocks.py:164); 16-byte vectorised when aligned
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t n) {
+  constexpr int EPU = Elem<T>::EPU;
+  const int64_t nu = n / EPU;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) {
+    alignas(16) T va[EPU]; alignas(16) T vb[EPU]; alignas(16) T vo[EPU];
+    *reinterpret_cast<u32x4*>(va) = *reinterpret_cast<const u32x4*>(a + i * EPU);
+    *reinterpret_cast<u32x4*>(vb) = *reinterpret_cast<const u32x4*>(b + i * EPU);
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) vo[e] = Elem<T>::cvt(Elem<T>::ld(va + e) + Elem<T>::ld(vb + e));
+    *reinterpret_cast<u32x4*>(out + i * EPU) = *reinterpret_cast<const u32x4*>(vo);
+  }
+  for (int64_t i = nu * EPU + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    Elem<T>::st(out + i, Elem<T>::ld(a + i) + Elem<T>::ld(b + i));
+}
+
+extern "C" int mia_add(const void* a, const void* b, void* out, int dtype, int64_t n, void* stream) {
+  MIA_CHECK_ARG(a && b && out && n > 0, "mia_add: bad arguments");
+  MIA_CHECK_ARG(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "mia_add: 16-byte alignment required");
+  const int64_t w = n / (dtype == MIA_BF16 ? 8 : 4) + 1;
+  const int blocks = (int)((w + 255) / 256 < 8192 ? (w + 255) / 256 : 8192);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == MIA_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, static_cast<const bf16_t*>(a), static_cast<const bf16_t*>(b), static_cast<bf16_t*>(out), n);
+  else if (dtype == MIA_F32) hipLaunchKernelGGL(add_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(a), static_cast<const float*>(b), static_cast<float*>(out), n);
+  else { mia_set_error("mia_add: bad dtype"); return MIA_EARG; }
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}

@@ -239,7 +239,7 @@ class PlainBlockFn(torch.autograd.Function):
     inputs x1 [N,H,W,C1] (+ optional x2 [N,H,W,C2], concatenated along C: unet.py:213)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, gamma, beta, stride: int, cfg: NormCfg, out_dtype=None):
+    def forward(ctx, x1, x2, weight, bias, gamma, beta, stride: int, cfg: NormCfg, out_dtype=None, slope: float = LRELU_SLOPE):
         _need_dev(x1, x2, weight)
         x1 = x1.contiguous()
         x2 = None if x2 is None else x2.contiguous()
@@ -248,7 +248,7 @@ class PlainBlockFn(torch.autograd.Function):
         stem = (weight.shape[1] == 1 and x2 is None and stride == 1 and x1.shape[3] == 1 and not x1.requires_grad
                 and cout_ % (8 if out_dtype == torch.bfloat16 else 4) == 0 and cout_ <= 256)
         if stem:
-            return PlainBlockFn._stem_forward(ctx, x1, weight, bias, gamma, beta, cfg, out_dtype)
+            return PlainBlockFn._stem_forward(ctx, x1, weight, bias, gamma, beta, cfg, out_dtype, slope)
         if x1.dtype != out_dtype:
             x1 = cast_nhwc(x1, out_dtype)
         if x2 is not None and (x2.shape[:3] != x1.shape[:3] or x2.dtype != x1.dtype):
@@ -272,13 +272,13 @@ class PlainBlockFn(torch.autograd.Function):
              _p(coefs[3]), _p(coefs[4]), _stream())
         z = torch.empty_like(y)
         call("mia_norm_act_fwd", _p(y), _p(z), dtype, _p(coefs[2]), _p(coefs[3]), n, _c_i64(ho * wo), cout,
-             _c_float(LRELU_SLOPE), _stream())
+             _c_float(slope), _stream())
         ctx.save_for_backward(x1, x2, y, coefs, weight, gamma)
-        ctx.stride, ctx.mode, ctx.fixed, ctx.stem = stride, cfg.mode, fixed, False
+        ctx.stride, ctx.mode, ctx.fixed, ctx.stem, ctx.slope = stride, cfg.mode, fixed, False, slope
         return z
 
     @staticmethod
-    def _norm_act(ctx, y, stats, gamma, beta, cfg, n, cout, hw):
+    def _norm_act(ctx, y, stats, gamma, beta, cfg, n, cout, hw, slope=LRELU_SLOPE):
         dev = y.device
         coefs = torch.empty((5, n, cout), device=dev, dtype=torch.float32)  # xa, xb, scale, shift, sum_y
         call("mia_norm_finalize", _p(stats), n, stats.shape[1], cout, _c_i64(hw), cfg.mode, int(cfg.training),
@@ -286,12 +286,12 @@ class PlainBlockFn(torch.autograd.Function):
              _p(cfg.running_mean), _p(cfg.running_var), _p(cfg.num_batches), _p(coefs[0]), _p(coefs[1]), _p(coefs[2]),
              _p(coefs[3]), _p(coefs[4]), _stream())
         z = torch.empty_like(y)
-        call("mia_norm_act_fwd", _p(y), _p(z), _dt(y), _p(coefs[2]), _p(coefs[3]), n, _c_i64(hw), cout, _c_float(LRELU_SLOPE),
+        call("mia_norm_act_fwd", _p(y), _p(z), _dt(y), _p(coefs[2]), _p(coefs[3]), n, _c_i64(hw), cout, _c_float(slope),
              _stream())
         return z, coefs
 
     @staticmethod
-    def _stem_forward(ctx, x1, weight, bias, gamma, beta, cfg, out_dtype):
+    def _stem_forward(ctx, x1, weight, bias, gamma, beta, cfg, out_dtype, slope):
         n, h, w, _ = x1.shape
         cout = weight.shape[0]
         dev = x1.device
@@ -301,9 +301,9 @@ class PlainBlockFn(torch.autograd.Function):
         if not w2.is_contiguous():
             w2 = w2.contiguous()
         call("mia_stem_fwd", _p(x1), _dt(x1), _p(w2), _p(bias.detach()), _p(y), _dt(y), _p(stats), n, h, w, cout, _stream())
-        z, coefs = PlainBlockFn._norm_act(ctx, y, stats, gamma, beta, cfg, n, cout, h * w)
+        z, coefs = PlainBlockFn._norm_act(ctx, y, stats, gamma, beta, cfg, n, cout, h * w, slope)
         ctx.save_for_backward(x1, None, y, coefs, weight, gamma)
-        ctx.stride, ctx.mode, ctx.fixed, ctx.stem = 1, cfg.mode, cfg.mode == NORM_BATCH and not cfg.training, True
+        ctx.stride, ctx.mode, ctx.fixed, ctx.stem, ctx.slope = 1, cfg.mode, cfg.mode == NORM_BATCH and not cfg.training, True, slope
         return z
 
     @staticmethod
@@ -321,14 +321,14 @@ class PlainBlockFn(torch.autograd.Function):
         dgamma, dbeta, dbias = dgb[0], dgb[1], dgb[2]
         dy = torch.empty_like(y)
         call("mia_norm_act_bwd", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
-             _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(LRELU_SLOPE), slabs,
+             _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs,
              _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
         cin = weight.shape[1]
         if ctx.stem:
             ws = torch.empty(lib().mia_stem_wgrad_workspace(cout), device=dev, dtype=torch.float32)
             dw = torch.empty(weight.shape, device=dev, dtype=torch.float32)
             call("mia_stem_wgrad", _p(x1), _dt(x1), _p(dy), dtype, _p(ws), _p(dw), n, ho, wo, cout, 0, _stream())
-            return None, None, dw, dbias, dgamma, dbeta, None, None, None
+            return None, None, dw, dbias, dgamma, dbeta, None, None, None, None
         wmode = WGRAD_3S2 if ctx.stride == 2 else WGRAD_3S1
         dw = conv_wgrad(wmode, x1, x2, dy, weight.shape, cout, cin)
         dx1 = dx2 = None
@@ -341,7 +341,7 @@ class PlainBlockFn(torch.autograd.Function):
                                        out_split=split)
             else:
                 dx1, dx2, _ = conv_mma(CONV_G3S1, dy, None, wb, npad, kpad, True, None, cin, (ho, wo), out_split=split)
-        return dx1, dx2, dw, dbias, dgamma, dbeta, None, None, None
+        return dx1, dx2, dw, dbias, dgamma, dbeta, None, None, None, None
 
 
 # ------------------------------------------------------------------ ConvTranspose2d(k=2, s=2)
@@ -510,3 +510,127 @@ def global_avg_pool(x_nhwc: torch.Tensor) -> torch.Tensor:
     part = torch.empty((n, 1, c, 2), device=x.device, dtype=torch.float32)
     call("mia_norm_stats", _p(x), _dt(x), n, _c_i64(h * w), c, 1, _p(part), _stream())
     return part[:, 0, :, 0] / float(h * w)
+
+
+# ------------------------------------------------------------------ ResidualBlock pieces (reference blocks.py:108-164)
+class PointwiseNormFn(torch.autograd.Function):
+    """Conv2d(cin, cout, 1, stride) + Instance/BatchNorm without activation: the ``downsample_skip`` branch of the
+    reference ResidualBlock (blocks.py:147-153).  Stride 1 runs the 1x1 MFMA mode; stride 2 runs the 2x2/s2 gather with
+    only tap (0,0) populated (the other three taps are zero weights), so no extra kernels are needed."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, stride: int, cfg: NormCfg):
+        _need_dev(x, weight)
+        x = x.contiguous()
+        dtype = _dt(x)
+        n, h, w, cin = x.shape
+        cout = weight.shape[0]
+        if stride == 2 and (h % 2 or w % 2):
+            raise MiaError("ResidualBlock stride-2 skip needs even H, W on the MI355X path")
+        ho, wo = (h // 2, w // 2) if stride == 2 else (h, w)
+        w4 = PointwiseNormFn._as_taps(weight, stride)
+        wp, npad, kpad = PackCache().get(w4, dtype, n_from_d0=True)
+        y, _, stats = conv_mma(CONV_G2S2 if stride == 2 else CONV_G1, x, None, wp, npad, kpad, False, bias.detach().float(), cout,
+                               (ho, wo), want_stats=True)
+        z, coefs = PlainBlockFn._norm_act(ctx, y, stats, gamma, beta, cfg, n, cout, ho * wo, 1.0)
+        ctx.save_for_backward(x, y, coefs, weight, gamma)
+        ctx.stride, ctx.mode, ctx.fixed = stride, cfg.mode, cfg.mode == NORM_BATCH and not cfg.training
+        return z
+
+    @staticmethod
+    def _as_taps(weight, stride):
+        w = weight.detach()
+        if stride == 1:
+            return w.contiguous()
+        w4 = torch.zeros((w.shape[0], w.shape[1], 2, 2), device=w.device, dtype=w.dtype)
+        w4[:, :, 0, 0] = w[:, :, 0, 0]
+        return w4
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, y, coefs, weight, gamma = ctx.saved_tensors
+        dz = dz.contiguous()
+        dtype = _dt(y)
+        n, ho, wo, cout = y.shape
+        cin = weight.shape[1]
+        dev = y.device
+        hw = ho * wo
+        slabs = _slabs_for(hw)
+        part = torch.empty((n, slabs, cout, 2), device=dev, dtype=torch.float32)
+        cc = torch.empty((2, n, cout), device=dev, dtype=torch.float32)
+        dgb = torch.empty((3, cout), device=dev, dtype=torch.float32)
+        dy = torch.empty_like(y)
+        call("mia_norm_act_bwd", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
+             _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(1.0), slabs, _p(part),
+             _p(cc[0]), _p(cc[1]), _p(dgb[0]), _p(dgb[1]), _p(dgb[2]), 0, _stream())
+        w4 = PointwiseNormFn._as_taps(weight, ctx.stride)
+        if ctx.stride == 2:
+            g4 = conv_wgrad(WGRAD_2S2, x, None, dy, w4.shape, cout, cin)
+            dw = g4[:, :, 0:1, 0:1].contiguous()
+        else:  # 1x1 stride 1: centre tap of the 3x3 weight-gradient kernel
+            g9 = conv_wgrad(WGRAD_3S1, x, None, dy, (cout, cin, 3, 3), cout, cin)
+            dw = g9[:, :, 1:2, 1:2].contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wb, npad, kpad = PackCache().get(w4, dtype, n_from_d0=False)
+            if ctx.stride == 2:
+                dx, _, _ = conv_mma(CONV_T2S2, dy, None, wb, npad, kpad, False, None, cin, (x.shape[1], x.shape[2]))
+            else:
+                dx, _, _ = conv_mma(CONV_G1, dy, None, wb, npad, kpad, False, None, cin, (ho, wo))
+        return dx, dw, dgb[2], dgb[0], dgb[1], None, None
+
+
+class ScaleLReLUFn(torch.autograd.Function):
+    """z = LeakyReLU(m[n,c] * v): Dropout2d AFTER the norm followed by the activation (ResidualBlock order
+    conv -> norm -> dropout -> lrelu, blocks.py:141); m = None means no dropout."""
+
+    @staticmethod
+    def forward(ctx, v, m, slope: float):
+        _need_dev(v)
+        v = v.contiguous()
+        n, h, w, c = v.shape
+        coef = torch.zeros((2, n, c), device=v.device, dtype=torch.float32)
+        if m is None:
+            coef[0].fill_(1.0)
+        else:
+            coef[0].copy_(m)
+        z = torch.empty_like(v)
+        call("mia_norm_act_fwd", _p(v), _p(z), _dt(v), _p(coef[0]), _p(coef[1]), n, _c_i64(h * w), c, _c_float(slope), _stream())
+        ctx.save_for_backward(v, coef)
+        ctx.slope = slope
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        v, coef = ctx.saved_tensors
+        dz = dz.contiguous()
+        n, h, w, c = v.shape
+        dev = v.device
+        slabs = _slabs_for(h * w)
+        part = torch.empty((n, slabs, c, 2), device=dev, dtype=torch.float32)
+        cc = torch.empty((2, n, c), device=dev, dtype=torch.float32)
+        junk = torch.empty((2, c), device=dev, dtype=torch.float32)
+        dv = torch.empty_like(v)
+        # frozen statistics: dv = scale * dz * lrelu'(scale*v)
+        call("mia_norm_act_bwd", _p(dz), _p(v), _p(dv), _dt(v), _p(coef[0]), _p(coef[1]), _p(coef[0]), _p(coef[1]), None, n,
+             _c_i64(h * w), c, NORM_INSTANCE, 1, _c_float(ctx.slope), slabs, _p(part), _p(cc[0]), _p(cc[1]), _p(junk[0]), _p(junk[1]),
+             None, 0, _stream())
+        return dv, None, None
+
+
+class AddFn(torch.autograd.Function):
+    """residual + out (blocks.py:164)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_dev(a, b)
+        a, b = a.contiguous(), b.contiguous()
+        if a.shape != b.shape or a.dtype != b.dtype:
+            raise RuntimeError(f"The size of tensor a {tuple(a.shape)} must match the size of tensor b {tuple(b.shape)}")
+        out = torch.empty_like(a)
+        call("mia_add", _p(a), _p(b), _p(out), _dt(a), _c_i64(a.numel()), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g

@@ -107,10 +107,62 @@ class PlainBlock(nn.Module):
 
 
 class ResidualBlock(nn.Module):
-    """reference blocks.py:108-164.  Unreachable from ``al_train`` (it passes ``normalization=`` where this
-    class takes ``norm_key=`` -> TypeError in the reference too); SURVEY.md section 8a row 2 ranks it last."""
+    """Drop-in for the reference ResidualBlock (blocks.py:108-164): ``all = Sequential(conv, norm, dropout, nonlin)``
+    (note: norm BEFORE dropout, and the ctor takes ``norm_key=``, not ``normalization=``), optional
+    ``downsample_skip = Sequential(conv1x1(stride), norm)``, output ``residual + out`` with no activation after the add.
+    Unreachable from ``al_train`` (it passes ``normalization=`` -> TypeError, in the reference too)."""
 
     def __init__(self, dimension, input_channels, output_channels, stride=1, kernel_size=3, norm_key="instance",
                  dropout_prob=None):
         super().__init__()
-        raise NotImplementedError("ResidualBlock is not built on the MI355X path yet (unreachable from al_train)")
+        _only_2d(dimension)
+        if kernel_size != 3:
+            raise NotImplementedError("MI355X ResidualBlock implements kernel_size=3")
+        if stride not in (1, 2):
+            raise NotImplementedError("stride must be 1 or 2")
+        conv = conv_dict[dimension](input_channels, output_channels, kernel_size, stride=stride,
+                                    padding=(kernel_size - 1) // 2, bias=True)
+        norm = norm_dict[norm_key][dimension](output_channels, eps=1e-5, affine=True)
+        do = Identity() if dropout_prob is None else dropout_dict[dimension](p=dropout_prob, inplace=True)
+        nonlin = nn.LeakyReLU(inplace=True)
+        self.all = nn.Sequential(conv, norm, do, nonlin)
+        if (input_channels != output_channels) or (stride != 1):
+            self.downsample_skip = nn.Sequential(conv_dict[dimension](input_channels, output_channels, 1, stride, bias=True),
+                                                 norm_dict[norm_key][dimension](output_channels, eps=1e-5, affine=True))
+        else:
+            self.downsample_skip = None
+        self.stride, self.normalization, self.dropout_prob = stride, norm_key, dropout_prob
+        self.drop_mask_override = None
+
+    def _cfg(self, norm):
+        if self.normalization == "batch":
+            return ops.NormCfg(NORM_BATCH, self.training, norm.eps, norm.momentum, norm.running_mean, norm.running_var,
+                               norm.num_batches_tracked, None)
+        return ops.NormCfg(NORM_INSTANCE, self.training, norm.eps, 0.1, None, None, None, None)
+
+    def forward_nhwc(self, x1, x2=None, out_dtype=None):
+        if out_dtype is not None and x1.dtype != out_dtype:
+            x1 = ops.cast_nhwc(x1, out_dtype)
+        if x2 is not None:  # decoder: the reference concatenates; keep the two-source read for the 3x3 conv only
+            x_cat = torch.cat([x1, x2], dim=3)
+        else:
+            x_cat = x1
+        conv, norm = self.all[0], self.all[1]
+        n1 = ops.PlainBlockFn.apply(x1, x2, conv.weight, conv.bias, norm.weight, norm.bias, self.stride, self._cfg(norm), None, 1.0)
+        m = None
+        if self.drop_mask_override is not None:
+            m = self.drop_mask_override.to(device=x1.device, dtype=torch.float32)
+        elif self.dropout_prob is not None and self.training and self.dropout_prob > 0:
+            keep = 1.0 - float(self.dropout_prob)
+            m = torch.empty((x1.shape[0], norm.num_features), device=x1.device, dtype=torch.float32).bernoulli_(keep).div_(keep)
+        out = ops.ScaleLReLUFn.apply(n1, m, ops.LRELU_SLOPE)
+        if self.downsample_skip is not None:
+            sc, sn = self.downsample_skip[0], self.downsample_skip[1]
+            residual = ops.PointwiseNormFn.apply(x_cat, sc.weight, sc.bias, sn.weight, sn.bias, self.stride, self._cfg(sn))
+        else:
+            residual = x_cat
+        return ops.AddFn.apply(residual, out)
+
+    def forward(self, x):
+        dt = x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        return ops.nhwc_as_nchw(self.forward_nhwc(ops.to_nhwc(x, dt)))
