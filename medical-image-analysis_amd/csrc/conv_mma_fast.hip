@@ -139,19 +139,45 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
     commit();
     __syncthreads();
     if (c0 + KB < ctot) fetch(c0 + KB);
-    for (int ta = 0; ta < nth; ++ta) {
-      for (int tb = 0; tb < ntw; ++tb) {
-        const int tl = ta * ntw + tb;
-        const int toff = tap_off(ta, tb);
-        u32x4 bf[NT], af[MT];
+    if constexpr (MODE == MODE_T3S2) {  // run-time tap count (depends on the output parity)
+      for (int ta = 0; ta < nth; ++ta) {
+        for (int tb = 0; tb < ntw; ++tb) {
+          const int tl = ta * ntw + tb;
+          const int toff = tap_off(ta, tb);
+          u32x4 bf[NT], af[MT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bf[n] = ldsB[(tl * 4 + q) * NPB + n * 16 + pr];
+          for (int n = 0; n < NT; ++n) bf[n] = ldsB[(tl * 4 + q) * NPB + n * 16 + pr];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) af[m] = ldsA[q * NPA + S * (wave * MT + m) * PITCH + toff + pr];
+          for (int m = 0; m < MT; ++m) af[m] = ldsA[q * NPA + S * (wave * MT + m) * PITCH + toff + pr];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = Mma<T>::run(af[m], bf[n], acc[m][n]);
+        }
+      }
+    } else {
+      // compile-time taps: fragments are double buffered in registers -- tap t+1's ds_read_b128s are issued before
+      // tap t's MT*NT MFMAs, so the LDS latency hides behind a full tap of matrix work
+      constexpr int KSW = (MODE == MODE_G3S1 || MODE == MODE_G3S2) ? 3 : MODE == MODE_G2S2 ? 2 : 1;
+      constexpr int NTAPS = KSW * KSW;
+      u32x4 bf[2][NT], af[2][MT];
+      auto load_tap = [&](int tl, u32x4* bfr, u32x4* afr) {
+        const int toff = tap_off(tl / KSW, tl % KSW);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bfr[n] = ldsB[(tl * 4 + q) * NPB + n * 16 + pr];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) afr[m] = ldsA[q * NPA + S * (wave * MT + m) * PITCH + toff + pr];
+      };
+      load_tap(0, bf[0], af[0]);
+#pragma unroll
+      for (int tl = 0; tl < NTAPS; ++tl) {
+        const int cur = tl & 1;
+        if (tl + 1 < NTAPS) load_tap(tl + 1, bf[cur ^ 1], af[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tap's MFMAs (the scheduler would sink it)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[m][n] = Mma<T>::run(af[m], bf[n], acc[m][n]);
+          for (int n = 0; n < NT; ++n) acc[m][n] = Mma<T>::run(af[cur][m], bf[cur][n], acc[m][n]);
       }
     }
     __syncthreads();
