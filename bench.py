@@ -54,9 +54,29 @@ def synth_batch(b, s, seed, k1=3):
     return img, lab
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box exposes all host
+    cores but grants a share; oversubscribing PyTorch's intra-op pool makes the CPU baseline slower, not faster)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(channels, size, budget_s=25.0):
     """Oracle train step (port of al_trainer.py:1350-1381) on the host cores, bounded sample."""
     from oracle import train_ref, unet_ref
+    torch.set_num_threads(usable_cores())
     torch.manual_seed(1337)
     p = unet_ref.init_params(1, 3, channels, "instance")
     opt = train_ref.make_optimizer(p, "adam", weight_decay=5e-4)
@@ -73,6 +93,29 @@ def cpu_baseline(channels, size, budget_s=25.0):
     dt = (time.time() - t0) / steps
     return {"value": bs / dt, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{steps} timed train steps (+1 warm-up) of the same UNet at {size}x{size}, batch {bs}, fp32, PyTorch-CPU"}
+
+
+def parity_gate(dev):
+    """BASELINE.json configs[0] ("UNet-tiny 16 base ch, 3 levels, 128x128, bs 4, reference CPU path"): the HIP fp32
+    forward + Dice/CE against the oracle on identical weights and inputs.  Reported, not timed."""
+    from losses.compound_losses import DiceAndCELoss
+    from models.unet import UNet
+    from oracle import losses_ref, unet_ref
+    torch.manual_seed(1337)
+    model = UNet(2, 1, 3, [16, 32, 64], normalization="instance", dropout_prob=None)
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).eval()
+    img, lab = synth_batch(4, 128, 1337)
+    with torch.no_grad():
+        out = model(img.to(dev))
+        loss = DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True))(out, lab.to(dev)).item()
+        ref = unet_ref.unet_forward(params, img, "instance", False)
+        ref_loss = losses_ref.dice_and_ce(ref, lab, 2).item()
+    out = out.float().cpu()
+    pg, pc = out.softmax(1).argmax(1), ref.softmax(1).argmax(1)
+    dices = [losses_ref.hard_dice(pg == k, pc == k) if (pc == k).any() else 1.0 for k in range(3)]
+    return {"config": "UNet [16,32,64] 128x128 bs4 fp32 (BASELINE configs[0]) vs CPU oracle", "max_abs_logit_diff": float((out - ref).abs().max()),
+            "loss_diff": abs(loss - ref_loss), "label_map_mismatch_px": int((pg != pc).sum()), "hard_dice_gpu_vs_cpu_labelmaps": min(dices)}
 
 
 def main():
@@ -175,6 +218,7 @@ def main():
                "final_loss": round(loss_v, 6), "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(channels, size)
+            out["parity"] = parity_gate(dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
