@@ -412,6 +412,114 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgArgs a) {
       }
 }
 
+// ---------------------------------------------------------------- fp32 fast path (same contract as the bf16 one)
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
+  using G = WGeo<MODE>;
+  constexpr int KS = G::KS, S = G::S, PAD = G::PAD, TAPS = G::TAPS;
+  constexpr int TH = (S == 1) ? 4 : 2;
+  constexpr int XH = (TH - 1) * S + KS, XW = 15 * S + KS;
+  constexpr int PS = 80;  // LDS pixel stride in dwords (64 channels + 16 pad): conflict-free b32 fragment reads
+  constexpr int X_IT = (XH * XW + 15) / 16, D_IT = TH * 16 / 16;  // 16 pixels x 16 four-channel units per iteration
+  __shared__ __attribute__((aligned(16))) float smem[(X_IT * 16 + TH * 16) * PS];
+  float* xs = smem;
+  float* ds = smem + X_IT * 16 * PS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, i16 = lane & 15;
+  const int ch4 = tid & 15, p16 = tid >> 4;
+  const int nkb = a.kpad / 64;
+  const int kblk = blockIdx.x % nkb, nblk = blockIdx.x / nkb;
+  const int n0 = nblk * 64, k0 = kblk * 64;
+  const bool second = k0 >= a.c1;
+  const float* xsrc = static_cast<const float*>(second ? a.x2 : a.x1);
+  const int cs = second ? a.c2 : a.c1, kloc = second ? k0 - a.c1 : k0;
+  const float* dy = static_cast<const float*>(a.dy);
+  const size_t xpix = (size_t)a.Hx * a.Wx, ypix = (size_t)a.Hy * a.Wy;
+
+  int x_iy[X_IT], x_ix[X_IT];
+#pragma unroll
+  for (int i = 0; i < X_IT; ++i) {
+    const int pix = p16 + 16 * i;
+    x_iy[i] = pix < XH * XW ? pix / XW : -100000;
+    x_ix[i] = pix - (pix / XW) * XW;
+  }
+  f32x4 acc[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 px[X_IT], pd[D_IT];
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  auto fetch = [&](int tile) {
+    int tt = tile;
+    const int tx = tt % a.tiles_x; tt /= a.tiles_x;
+    const int ty = tt % a.tiles_y; tt /= a.tiles_y;
+    const int img = tt;
+    const int oy0 = ty * TH, ox0 = tx * 16;
+    const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
+    const wrsrc_t rx = wmake_rsrc(xsrc + (size_t)img * xpix * cs, (unsigned)(xpix * cs * 4));
+    const wrsrc_t rd = wmake_rsrc(dy + (size_t)img * ypix * a.cdy, (unsigned)(ypix * a.cdy * 4));
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int gy = iy0 + x_iy[i], gx = ix0 + x_ix[i];
+      const bool ok = gy >= 0 && gy < a.Hx && gx >= 0 && gx < a.Wx;
+      const unsigned voff = ok ? (unsigned)(((gy * a.Wx + gx) * cs + kloc + ch4 * 4) * 4) : WSENT;
+      px[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < D_IT; ++i) {
+      const int pix = p16 + 16 * i;
+      const int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
+      const bool ok = gy < a.Hy && gx < a.Wy;
+      const unsigned voff = ok ? (unsigned)(((gy * a.Wy + gx) * a.cdy + n0 + ch4 * 4) * 4) : WSENT;
+      pd[i] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)voff, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.y;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += a.ksplit) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) *reinterpret_cast<u32x4*>(xs + (p16 + 16 * i) * PS + ch4 * 4) = px[i];
+#pragma unroll
+    for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(ds + (p16 + 16 * i) * PS + ch4 * 4) = pd[i];
+    __syncthreads();
+    if (tile + a.ksplit < ntiles) fetch(tile + a.ksplit);
+#pragma unroll
+    for (int y = 0; y < TH; ++y) {
+#pragma unroll
+      for (int xq = 0; xq < 4; ++xq) {
+        const int xx = xq * 4 + q;
+        float af[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) af[c] = ds[(y * 16 + xx) * PS + c * 16 + i16];
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) {
+            const float b = xs[((y * S + kh) * XW + xx * S + kw) * PS + wave * 16 + i16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              acc[kh * KS + kw][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c], b, acc[kh * KS + kw][c], 0, 0, 0);
+          }
+      }
+    }
+  }
+  float* slab = a.slabs + (size_t)blockIdx.y * TAPS * a.npad * a.kpad;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + c * 16 + 4 * q + r, k = k0 + wave * 16 + i16;
+        slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+      }
+}
+
 // ---------------------------------------------------------------- slab reduce -> native parameter layout
 // layout 0: conv   grad[n][k][kh][kw]  (OIHW, n = Cout, k = Cin)
 // layout 1: convT  grad[n][k][kh][kw] where the parameter is [Cin_T][Cout_T][2][2] and the GEMM ran with
@@ -478,6 +586,11 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
     else if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 8>), grid, dim3(256), 0, st, a);
     else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S2, 4>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W2S2, 4>), grid, dim3(256), 0, st, a);
+  } else if (dtype == MIA_F32 && a.vec_x && a.vec_dy && c1 % 64 == 0 && c2 % 64 == 0 && cdy % 64 == 0 &&
+             (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 4 < lim && (size_t)hy * wy * cdy * 4 < lim) {
+    if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W3S1>, grid, dim3(256), 0, st, a);
+    else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W3S2>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W2S2>, grid, dim3(256), 0, st, a);
   } else if (dtype == MIA_BF16) {
     if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W3S1>, grid, dim3(256), 0, st, a);
     else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W3S2>, grid, dim3(256), 0, st, a);
