@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgs a) {
 // global -> VGPR while the current tile's MFMAs run (the generic kernel idles the matrix pipe for the
 // whole staging phase: rocprofv3 SQ_WAIT_ANY = 63 % of wave cycles), and (b) every access is a raw
 // buffer load against a per-image descriptor, so borders are out-of-range offsets -> zeros, no branches.
-// Contract: c1 % 64 == 0, c2 % 64 == 0, cdy % 64 == 0, 16-byte aligned, per-image tensors < 2 GiB.
+// Contract: channel counts multiples of the 16-byte unit, a two-source input split on a 64-channel boundary,
+// 16-byte aligned, per-image tensors < 2 GiB (channel tails are zero-filled like the image border).
 typedef __amdgpu_buffer_rsrc_t wrsrc_t;
 #define WSENT 0xFFFFFFF0u
 __device__ __forceinline__ wrsrc_t wmake_rsrc(const void* p, unsigned bytes) {
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
     for (int i = 0; i < X_IT; ++i) {
       const int gy = iy0 + x_iy[i], gx = ix0 + x_ix[i];
       const bool ok = gy >= 0 && gy < a.Hx && gx >= 0 && gx < a.Wx;
-      const unsigned voff = ok ? (unsigned)(((gy * a.Wx + gx) * cs + kloc + ch8 * 8) * 2) : WSENT;
+      const unsigned voff = (ok && kloc + ch8 * 8 < cs) ? (unsigned)(((gy * a.Wx + gx) * cs + kloc + ch8 * 8) * 2) : WSENT;
       px[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, 0, 0);
     }
 #pragma unroll
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
       const int pix = p8 + 32 * i;
       const int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
       const bool ok = gy < a.Hy && gx < a.Wy;
-      const unsigned voff = ok ? (unsigned)(((gy * a.Wy + gx) * a.cdy + n0 + ch8 * 8) * 2) : WSENT;
+      const unsigned voff = (ok && n0 + ch8 * 8 < a.cdy) ? (unsigned)(((gy * a.Wy + gx) * a.cdy + n0 + ch8 * 8) * 2) : WSENT;
       pd[i] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)voff, 0, 0);
     }
   };
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
     for (int i = 0; i < X_IT; ++i) {
       const int gy = iy0 + x_iy[i], gx = ix0 + x_ix[i];
       const bool ok = gy >= 0 && gy < a.Hx && gx >= 0 && gx < a.Wx;
-      const unsigned voff = ok ? (unsigned)(((gy * a.Wx + gx) * cs + kloc + ch4 * 4) * 4) : WSENT;
+      const unsigned voff = (ok && kloc + ch4 * 4 < cs) ? (unsigned)(((gy * a.Wx + gx) * cs + kloc + ch4 * 4) * 4) : WSENT;
       px[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, 0, 0);
     }
 #pragma unroll
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
       const int pix = p16 + 16 * i;
       const int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
       const bool ok = gy < a.Hy && gx < a.Wy;
-      const unsigned voff = ok ? (unsigned)(((gy * a.Wy + gx) * a.cdy + n0 + ch4 * 4) * 4) : WSENT;
+      const unsigned voff = (ok && n0 + ch4 * 4 < a.cdy) ? (unsigned)(((gy * a.Wy + gx) * a.cdy + n0 + ch4 * 4) * 4) : WSENT;
       pd[i] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)voff, 0, 0);
     }
   };
@@ -576,8 +577,10 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   dim3 grid((npad / 64) * (kpad / 64), ksplit);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t lim = (size_t)1 << 31;
-  const bool fast = dtype == MIA_BF16 && a.vec_x && a.vec_dy && c1 % 64 == 0 && c2 % 64 == 0 && cdy % 64 == 0 &&
-                    (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 2 < lim && (size_t)hy * wy * cdy * 2 < lim;
+  // channel tails are zero-filled through out-of-range offsets; a two-source input must split on a 64-channel boundary
+  const bool chan_ok = a.vec_x && a.vec_dy && (c2 == 0 || c1 % 64 == 0);
+  const bool fast = dtype == MIA_BF16 && chan_ok && (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 2 < lim &&
+                    (size_t)hy * wy * cdy * 2 < lim;
   const int th = wgrad_tile_h(mode, dtype, hy, fast);
   a.tiles_y = ceil_div(hy, th);
   a.tiles_x = ceil_div(wy, 16);
@@ -586,8 +589,8 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
     else if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 8>), grid, dim3(256), 0, st, a);
     else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S2, 4>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W2S2, 4>), grid, dim3(256), 0, st, a);
-  } else if (dtype == MIA_F32 && a.vec_x && a.vec_dy && c1 % 64 == 0 && c2 % 64 == 0 && cdy % 64 == 0 &&
-             (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 4 < lim && (size_t)hy * wy * cdy * 4 < lim) {
+  } else if (dtype == MIA_F32 && chan_ok && (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 4 < lim &&
+             (size_t)hy * wy * cdy * 4 < lim) {
     if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W3S1>, grid, dim3(256), 0, st, a);
     else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W3S2>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W2S2>, grid, dim3(256), 0, st, a);
