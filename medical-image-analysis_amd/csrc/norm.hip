@@ -148,10 +148,10 @@ __global__ __launch_bounds__(256) void colreduce_vec_kernel(const T* __restrict_
       sc[e] = scale[o]; sf[e] = shift[o]; ka[e] = xa[o]; kb[e] = xb[o];
     }
   }
-  for (int64_t r = r0 + pl; r < r1; r += LANES) {
+  auto body = [&](const u32x4& r0v, const u32x4& r1v) {
     alignas(16) T v0[EPU]; alignas(16) T v1[EPU];
-    *reinterpret_cast<u32x4*>(v0) = *reinterpret_cast<const u32x4*>(a0 + base + r * c);
-    if (BWD) *reinterpret_cast<u32x4*>(v1) = *reinterpret_cast<const u32x4*>(a1 + base + r * c);
+    *reinterpret_cast<u32x4*>(v0) = r0v;
+    *reinterpret_cast<u32x4*>(v1) = r1v;
 #pragma unroll
     for (int e = 0; e < EPU; ++e) {
       if (BWD) {  // a0 = dz, a1 = y
@@ -164,7 +164,18 @@ __global__ __launch_bounds__(256) void colreduce_vec_kernel(const T* __restrict_
         s1[e] += v; s2[e] += v * v;
       }
     }
+  };
+  const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
+  int64_t r = r0 + pl;
+  for (; r + LANES < r1; r += 2 * LANES) {  // two rows (up to four 16-byte loads) in flight per thread
+    const u32x4 p0 = *reinterpret_cast<const u32x4*>(a0 + base + r * c);
+    const u32x4 q0 = BWD ? *reinterpret_cast<const u32x4*>(a1 + base + r * c) : zero;
+    const u32x4 p1 = *reinterpret_cast<const u32x4*>(a0 + base + (r + LANES) * c);
+    const u32x4 q1 = BWD ? *reinterpret_cast<const u32x4*>(a1 + base + (r + LANES) * c) : zero;
+    body(p0, q0); body(p1, q1);
   }
+  for (; r < r1; r += LANES)
+    body(*reinterpret_cast<const u32x4*>(a0 + base + r * c), BWD ? *reinterpret_cast<const u32x4*>(a1 + base + r * c) : zero);
 #pragma unroll
   for (int e = 0; e < EPU; ++e) { sh[0][pl][u * EPU + e] = s1[e]; sh[1][pl][u * EPU + e] = s2[e]; }
   __syncthreads();
@@ -241,16 +252,25 @@ __global__ __launch_bounds__(256) void norm_act_fwd_stream_kernel(const T* __res
 #pragma unroll
   for (int e = 0; e < EPU; ++e) { sc[e] = scale[(size_t)n * c + u * EPU + e]; sf[e] = shift[(size_t)n * c + u * EPU + e]; }
   const size_t base = (size_t)n * hw * c + (size_t)u * EPU;
-  for (int64_t r = r0 + pl; r < r1; r += lanes) {
+  auto body = [&](const u32x4& raw, int64_t r) {
     alignas(16) T in[EPU]; alignas(16) T out[EPU];
-    *reinterpret_cast<u32x4*>(in) = *reinterpret_cast<const u32x4*>(y + base + r * c);
+    *reinterpret_cast<u32x4*>(in) = raw;
 #pragma unroll
     for (int e = 0; e < EPU; ++e) {
       const float v = sc[e] * Elem<T>::ld(in + e) + sf[e];
       out[e] = Elem<T>::cvt(v > 0.f ? v : v * slope);
     }
     *reinterpret_cast<u32x4*>(z + base + r * c) = *reinterpret_cast<const u32x4*>(out);
+  };
+  int64_t r = r0 + pl;
+  for (; r + 3 * lanes < r1; r += 4 * lanes) {  // four independent 16-byte loads in flight per thread
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(y + base + r * c);
+    const u32x4 a1 = *reinterpret_cast<const u32x4*>(y + base + (r + lanes) * c);
+    const u32x4 a2 = *reinterpret_cast<const u32x4*>(y + base + (r + 2 * lanes) * c);
+    const u32x4 a3 = *reinterpret_cast<const u32x4*>(y + base + (r + 3 * lanes) * c);
+    body(a0, r); body(a1, r + lanes); body(a2, r + 2 * lanes); body(a3, r + 3 * lanes);
   }
+  for (; r < r1; r += lanes) body(*reinterpret_cast<const u32x4*>(y + base + r * c), r);
 }
 
 // dy = scale*(g - c1 - xhat*c2) = scale*g + ka*y + kb  with ka = -scale*c2*xa, kb = -scale*(c1 + c2*xb)
@@ -275,10 +295,10 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stream_kernel(const T* __res
     kb[e] = -sc[e] * (c1[o] + c2[o] * xb[o]);
   }
   const size_t base = (size_t)n * hw * c + (size_t)u * EPU;
-  for (int64_t r = r0 + pl; r < r1; r += lanes) {
+  auto body = [&](const u32x4& graw, const u32x4& yraw, int64_t r) {
     alignas(16) T gin[EPU]; alignas(16) T yin[EPU]; alignas(16) T out[EPU];
-    *reinterpret_cast<u32x4*>(gin) = *reinterpret_cast<const u32x4*>(dz + base + r * c);
-    *reinterpret_cast<u32x4*>(yin) = *reinterpret_cast<const u32x4*>(y + base + r * c);
+    *reinterpret_cast<u32x4*>(gin) = graw;
+    *reinterpret_cast<u32x4*>(yin) = yraw;
 #pragma unroll
     for (int e = 0; e < EPU; ++e) {
       const float yv = Elem<T>::ld(yin + e);
@@ -287,7 +307,17 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stream_kernel(const T* __res
       out[e] = Elem<T>::cvt(sc[e] * g + ka[e] * yv + kb[e]);
     }
     *reinterpret_cast<u32x4*>(dy + base + r * c) = *reinterpret_cast<const u32x4*>(out);
+  };
+  int64_t r = r0 + pl;
+  for (; r + lanes < r1; r += 2 * lanes) {  // four independent 16-byte loads in flight per thread
+    const u32x4 g0 = *reinterpret_cast<const u32x4*>(dz + base + r * c);
+    const u32x4 y0 = *reinterpret_cast<const u32x4*>(y + base + r * c);
+    const u32x4 g1 = *reinterpret_cast<const u32x4*>(dz + base + (r + lanes) * c);
+    const u32x4 y1 = *reinterpret_cast<const u32x4*>(y + base + (r + lanes) * c);
+    body(g0, y0, r); body(g1, y1, r + lanes);
   }
+  for (; r < r1; r += lanes)
+    body(*reinterpret_cast<const u32x4*>(dz + base + r * c), *reinterpret_cast<const u32x4*>(y + base + r * c), r);
 }
 
 static void stream_geometry(int n, int64_t hw, int c, int epu, int* slabs, int* upb, int* gy) {
