@@ -106,6 +106,29 @@ int mia_norm_act_bwd(const void* dz, const void* y, void* dy, int dtype, const f
                      int fixed_stats, float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma,
                      float* dbeta, float* dbias, int accumulate, void* stream);
 
+/* Synchronised batch norm for data-parallel runs (build-side addition; SURVEY.md 8e: "a second, small collective"):
+ * the caller moves 3*C floats (forward, all-gather) and 2*C floats (backward, all-reduce sum) per layer over RCCL and
+ * these entry points do the device work on either side of it, so N ranks x bs reproduce one process at N*bs
+ * (BatchNorm2d batch statistics, blocks.py:98).
+ *   mia_bn_sync_local_stats : conv-epilogue partials -> per-(n,c) sums parked in xa/xb + local[3][C] = mean, M2, count
+ *   mia_norm_finalize_sync  : gathered[world][3][C] -> coefficients / running statistics as mia_norm_finalize(training)
+ *   mia_norm_act_bwd_reduce : per-(n,c) sums in c1/c2 + tot[3][C] = local (sum g, sum g*xhat, pixel count)
+ *   mia_norm_act_bwd_apply_sync : group_tot[3][C] = the all-reduced (summed) totals; dgamma, dbeta and dbias stay
+ *                             LOCAL sums (the gradient all-reduce adds them up). */
+int mia_bn_sync_local_stats(const float* partials, int n, int tiles, int c, int64_t hw, const float* drop_scale, float* xa,
+                            float* xb, float* local, void* stream);
+int mia_norm_finalize_sync(const float* gathered, int world, int n, int c, int64_t hw, const float* drop_scale,
+                           const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                           float* running_var, long long* num_batches, float* xa, float* xb, float* scale, float* shift,
+                           float* ysum, void* stream);
+int mia_norm_act_bwd_reduce(const void* dz, const void* y, int dtype, const float* scale, const float* shift, const float* xa,
+                            const float* xb, int n, int64_t hw, int c, float slope, int slabs, float* partials, float* c1,
+                            float* c2, float* tot, void* stream);
+int mia_norm_act_bwd_apply_sync(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
+                                const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, float slope,
+                                float* c1, float* c2, const float* group_tot, float* dgamma, float* dbeta, float* dbias,
+                                int accumulate, void* stream);
+
 /* ------------------------------------------------------------------ 1x1 head + Dice/CE loss */
 /* seg_output = Conv2d(c0, K1, 1) (unet.py:176), K1 <= 8.  Logits are fp32 with element strides (osn, osk, osp). */
 int mia_head_fwd(const void* x, int dtype, const float* w, const float* b, float* logits, int n, int64_t hw, int c0, int k1,

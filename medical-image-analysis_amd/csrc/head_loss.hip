@@ -285,6 +285,7 @@ extern "C" int mia_head_bwd(const float* dlogits, const void* x, int dtype, cons
 #define LF_DO_BG 2
 #define LF_BATCH 4
 #define LF_SQUARED 8
+#define LF_DENSE 16  // `labels` points at a contiguous fp32 [B][K1][HW] target (already one-hot / soft; dice_loss.py:40-41 skips the encoder)
 
 struct LossGeom { int64_t sn, sk, sp; };  // element strides of the logits tensor: image, class, pixel
 
@@ -305,7 +306,8 @@ __global__ void dice_ce_fwd_kernel(const float* __restrict__ logits, const long 
 #pragma unroll
     for (int k = 0; k < MAXK; ++k)
       if (k < k1) { v[k] = base[p * g.sp + k * g.sk]; mx = fmaxf(mx, v[k]); }
-    const long long lab = labels[(int64_t)b * hw + p];
+    const float* dense = reinterpret_cast<const float*>(labels) + (int64_t)b * k1 * hw + p;
+    const long long lab = (flags & LF_DENSE) ? 0 : labels[(int64_t)b * hw + p];
     if (lab < 0 || lab >= k1) { *bad_label = 1; continue; }
     float pr[MAXK];
     float se = 0.f;
@@ -318,11 +320,11 @@ __global__ void dice_ce_fwd_kernel(const float* __restrict__ logits, const long 
     for (int k = 0; k < MAXK; ++k)
       if (k < k1) {
         const float pk = (flags & LF_SOFTMAX) ? pr[k] * inv : v[k];
-        const float t = (k == (int)lab) ? 1.f : 0.f;
+        const float t = (flags & LF_DENSE) ? dense[k * hw] : ((k == (int)lab) ? 1.f : 0.f);
         si[k] += pk * t;
         sp[k] += (flags & LF_SQUARED) ? pk * pk : pk;
-        st[k] += t;
-        if (k == (int)lab) ce += lse - v[k];
+        st[k] += (flags & LF_SQUARED) ? t * t : t;
+        ce += t * (lse - v[k]);
       }
   }
   for (int k = 0; k < k1; ++k) {
@@ -417,16 +419,19 @@ __global__ void dice_ce_bwd_kernel(const float* __restrict__ logits, const long 
     for (int k = 0; k < MAXK; ++k)
       if (k < k1) { pr[k] = __expf(v[k] - mx); se += pr[k]; }
     const float inv = 1.f / se;
-    const int lab = (int)labels[i];
+    const float* dense = reinterpret_cast<const float*>(labels) + (int64_t)b * k1 * hw + p;
+    const int lab = (flags & LF_DENSE) ? 0 : (int)labels[i];
     // dL/dp_k for the dice part
-    float gk[MAXK], dot = 0.f;
+    float gk[MAXK], tk[MAXK], dot = 0.f, tsum = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXK; ++k)
       if (k < k1) {
         const float sm = pr[k] * inv;
         const float pk = (flags & LF_SOFTMAX) ? sm : v[k];
         const float al = coef[((size_t)b * k1 + k) * 2], be = coef[((size_t)b * k1 + k) * 2 + 1];
-        float gg = al * (k == lab ? 1.f : 0.f) + be * ((flags & LF_SQUARED) ? 2.f * pk : 1.f);
+        tk[k] = (flags & LF_DENSE) ? dense[k * hw] : (k == lab ? 1.f : 0.f);
+        tsum += tk[k];
+        float gg = al * tk[k] + be * ((flags & LF_SQUARED) ? 2.f * pk : 1.f);
         gk[k] = gg * dice_w;
         pr[k] = sm;
         dot += gk[k] * sm;
@@ -436,7 +441,7 @@ __global__ void dice_ce_bwd_kernel(const float* __restrict__ logits, const long 
     for (int k = 0; k < MAXK; ++k)
       if (k < k1) {
         const float dd = (flags & LF_SOFTMAX) ? pr[k] * (gk[k] - dot) : gk[k];
-        const float dc = cew * (pr[k] - (k == lab ? 1.f : 0.f));
+        const float dc = cew * (tsum * pr[k] - tk[k]);  // d/dv_k of sum_j t_j (lse - v_j)
         dst[k * go.sk] = go_s * (dd + dc);
       }
   }

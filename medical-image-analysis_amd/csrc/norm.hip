@@ -44,7 +44,7 @@ __global__ void norm_finalize_kernel(int n_img, int c, int64_t hw, int mode, int
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                      float* running_mean, float* running_var, long long* num_batches, float* __restrict__ xa,
                                      float* __restrict__ xb, float* __restrict__ scale, float* __restrict__ shift,
-                                     float* __restrict__ ysum) {
+                                     float* __restrict__ ysum, const float* __restrict__ group, int world) {
   __shared__ double sh1[16][17], sh2[16][17];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cl;
@@ -80,9 +80,21 @@ __global__ void norm_finalize_kernel(int n_img, int c, int64_t hw, int mode, int
     __syncthreads();
     e1 = 0.0; e2 = 0.0;
     for (int j = 0; j < 16; ++j) { e1 += sh1[j][cl]; e2 += sh2[j][cl]; }
-    const double cnt = (double)n_img * M;
+    double cnt = (double)n_img * M;
     meanp = e1 / cnt;
     double var = e2 / cnt - meanp * meanp;
+    if (group && ch < c) {
+      // synchronised batch norm: combine every rank's (mean, M2, count) with the pairwise update of Chan et al.
+      double gm = 0.0, gm2 = 0.0, gc = 0.0;
+      for (int r = 0; r < world; ++r) {
+        const float* g = group + (size_t)r * 3 * c;
+        const double rm = g[ch], rm2 = g[c + ch], rc = g[2 * c + ch];
+        const double d = rm - gm, tot = gc + rc;
+        if (tot > 0.0) { gm += d * rc / tot; gm2 += rm2 + d * d * gc * rc / tot; }
+        gc = tot;
+      }
+      cnt = gc; meanp = gm; var = gm2 / gc;
+    }
     if (var < 0.0) var = 0.0;
     rstd = 1.0 / sqrt(var + (double)eps);
     if (tl == 0 && ch < c && running_mean) {
@@ -119,7 +131,60 @@ extern "C" int mia_norm_finalize(const float* partials, int n, int tiles, int c,
   const bool need_sums = mode == NORM_INSTANCE || training;
   if (need_sums) hipLaunchKernelGGL(norm_fwd_sum_kernel, dim3(n, cgroups), dim3(256), 0, st, partials, tiles, c, xa, xb);
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(cgroups), dim3(256), 0, st, n, c, hw, mode, training, drop_scale, gamma, beta, eps,
-                     momentum, running_mean, running_var, num_batches, xa, xb, scale, shift, need_sums ? ysum : nullptr);
+                     momentum, running_mean, running_var, num_batches, xa, xb, scale, shift, need_sums ? ysum : nullptr, nullptr, 0);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------- synchronised batch norm (data-parallel exactness)
+// One process per GPU, each with its shard of the minibatch: the batch statistics must cover every rank's shard to
+// reproduce a single-process run.  Forward: local (mean, M2, count) per channel -> all-gather
+// (3*C floats per rank, done by the caller over RCCL) -> mia_norm_finalize_sync.  Backward: local (sum g, sum g*xhat)
+// -> all-reduce (2*C floats) -> mia_norm_act_bwd_apply_sync.
+__global__ void bn_local_stats_kernel(int n_img, int c, int64_t hw, const float* __restrict__ drop, const float* __restrict__ xa,
+                                      const float* __restrict__ xb, float* __restrict__ local) {
+  __shared__ double sh1[16][17], sh2[16][17];
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double e1 = 0.0, e2 = 0.0;
+  if (ch < c)
+    for (int n = tl; n < n_img; n += 16) {
+      const size_t idx = (size_t)n * c + ch;
+      const double m = drop ? (double)drop[idx] : 1.0;
+      e1 += m * xa[idx]; e2 += m * m * xb[idx];
+    }
+  sh1[tl][cl] = e1; sh2[tl][cl] = e2;
+  __syncthreads();
+  if (tl == 0 && ch < c) {
+    e1 = 0.0; e2 = 0.0;
+    for (int j = 0; j < 16; ++j) { e1 += sh1[j][cl]; e2 += sh2[j][cl]; }
+    const double cnt = (double)n_img * (double)hw, mean = e1 / cnt;
+    double m2 = e2 - cnt * mean * mean;
+    if (m2 < 0.0) m2 = 0.0;
+    local[ch] = (float)mean; local[c + ch] = (float)m2; local[2 * c + ch] = (float)cnt;
+  }
+}
+
+extern "C" int mia_bn_sync_local_stats(const float* partials, int n, int tiles, int c, int64_t hw, const float* drop_scale,
+                                       float* xa, float* xb, float* local, void* stream) {
+  MIA_CHECK_ARG(partials && xa && xb && local && n > 0 && tiles > 0 && c > 0 && hw > 0, "mia_bn_sync_local_stats: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int cgroups = ceil_div(c, 16);
+  hipLaunchKernelGGL(norm_fwd_sum_kernel, dim3(n, cgroups), dim3(256), 0, st, partials, tiles, c, xa, xb);
+  hipLaunchKernelGGL(bn_local_stats_kernel, dim3(cgroups), dim3(256), 0, st, n, c, hw, drop_scale, xa, xb, local);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+extern "C" int mia_norm_finalize_sync(const float* gathered, int world, int n, int c, int64_t hw, const float* drop_scale,
+                                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                      float* running_var, long long* num_batches, float* xa, float* xb, float* scale,
+                                      float* shift, float* ysum, void* stream) {
+  MIA_CHECK_ARG(gathered && world > 0 && gamma && beta && xa && xb && scale && shift && n > 0 && c > 0 && hw > 0,
+                "mia_norm_finalize_sync: bad arguments");
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, static_cast<hipStream_t>(stream), n, c, hw,
+                     NORM_BATCH, 1, drop_scale, gamma, beta, eps, momentum, running_mean, running_var, num_batches, xa, xb, scale,
+                     shift, ysum, gathered, world);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -460,7 +525,8 @@ __global__ void norm_bwd_sum_kernel(const float* __restrict__ part, int slabs, i
 __global__ void norm_bwd_finalize_kernel(int n_img, int c, int64_t hw, int mode, int fixed_stats, const float* __restrict__ scale,
                                          const float* __restrict__ xa, const float* __restrict__ xb, const float* __restrict__ ysum,
                                          float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ dgamma,
-                                         float* __restrict__ dbeta, float* __restrict__ dbias, int accumulate) {
+                                         float* __restrict__ dbeta, float* __restrict__ dbias, int accumulate,
+                                         const float* __restrict__ group_tot) {
   __shared__ double sh1[16][17], sh2[16][17], sh3[16][17];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cl;
@@ -482,6 +548,7 @@ __global__ void norm_bwd_finalize_kernel(int n_img, int c, int64_t hw, int mode,
       double m1 = 0.0, m2 = 0.0;
       if (!fixed_stats) {
         if (mode == NORM_INSTANCE) { m1 = sg / M; m2 = sgx / M; }
+        else if (group_tot) { const double gc = group_tot[2 * c + ch]; m1 = (double)group_tot[ch] / gc; m2 = (double)group_tot[c + ch] / gc; }
         else { m1 = tg / cnt; m2 = tgx / cnt; }
       }
       c1[idx] = (float)m1; c2[idx] = (float)m2;
@@ -533,35 +600,41 @@ __global__ void norm_act_bwd_apply_kernel(const T* __restrict__ dz, const T* __r
   }
 }
 
-extern "C" int mia_norm_act_bwd(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
-                                const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
-                                int fixed_stats, float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma,
-                                float* dbeta, float* dbias, int accumulate, void* stream) {
-  MIA_CHECK_ARG(dz && y && dy && scale && shift && xa && xb && partials && c1 && c2 && dgamma && dbeta,
-                "mia_norm_act_bwd: null pointer");
-  MIA_CHECK_ARG(n > 0 && hw > 0 && c > 0 && slabs > 0, "mia_norm_act_bwd: bad shape");
-  hipStream_t st = static_cast<hipStream_t>(stream);
+static bool bwd_vec_ok(const void* dz, const void* y, const void* dy, int dtype, int c) {
   const int epu = dtype == MIA_BF16 ? 8 : 4;
-  const bool vec = (c % epu == 0) &&
-                   ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
-  const int64_t units = (int64_t)n * hw * (vec ? c / epu : c);
-  const int blocks = (int)((units + 255) / 256 < 16384 ? (units + 255) / 256 : 16384);
+  return (c % epu == 0) &&
+         ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+}
+
+// pass 1: slab partials of (sum g, sum g*xhat), then per-(n,c) sums parked in c1 / c2
+static void bwd_reduce_launch(const void* dz, const void* y, int dtype, const float* scale, const float* shift, const float* xa,
+                              const float* xb, int n, int64_t hw, int c, float slope, int slabs, float* partials, float* c1,
+                              float* c2, hipStream_t st) {
+  const bool vec = bwd_vec_ok(dz, y, nullptr, dtype, c);
 #define RD(T) hipLaunchKernelGGL(norm_act_bwd_reduce_kernel<T>, dim3(n * slabs, ceil_div(c, 256)), dim3(256), 512 * sizeof(float), st,   \
                                  static_cast<const T*>(dz), static_cast<const T*>(y), scale, shift, xa, xb, hw, c, slabs, \
                                  slope, partials)
-#define AP(T, V) hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, V>), dim3(blocks), dim3(256), 0, st,                   \
-                                    static_cast<const T*>(dz), static_cast<const T*>(y), static_cast<T*>(dy), scale, shift, \
-                                    xa, xb, c1, c2, hw, c, units, slope)
-  if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_norm_act_bwd: bad dtype"); return MIA_EARG; }
   if (vec && c % 64 == 0) {
     if (dtype == MIA_BF16)
       hipLaunchKernelGGL((colreduce_vec_kernel<bf16_t, true>), dim3(n * slabs, c / 64), dim3(256), 0, st, static_cast<const bf16_t*>(dz), static_cast<const bf16_t*>(y), scale, shift, xa, xb, hw, c, slabs, slope, partials);
     else
       hipLaunchKernelGGL((colreduce_vec_kernel<float, true>), dim3(n * slabs, c / 64), dim3(256), 0, st, static_cast<const float*>(dz), static_cast<const float*>(y), scale, shift, xa, xb, hw, c, slabs, slope, partials);
   } else if (dtype == MIA_BF16) RD(bf16_t); else RD(float);
+#undef RD
   hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3(n, ceil_div(c, 16)), dim3(256), 0, st, partials, slabs, c, c1, c2);
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, mode, fixed_stats, scale, xa,
-                     xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate);
+}
+
+// pass 2: dy from the finalized group means
+static void bwd_apply_launch(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
+                             const float* xa, const float* xb, const float* c1, const float* c2, int n, int64_t hw, int c,
+                             float slope, hipStream_t st) {
+  const int epu = dtype == MIA_BF16 ? 8 : 4;
+  const bool vec = bwd_vec_ok(dz, y, dy, dtype, c);
+  const int64_t units = (int64_t)n * hw * (vec ? c / epu : c);
+  const int blocks = (int)((units + 255) / 256 < 16384 ? (units + 255) / 256 : 16384);
+#define AP(T, V) hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, V>), dim3(blocks), dim3(256), 0, st,                   \
+                                    static_cast<const T*>(dz), static_cast<const T*>(y), static_cast<T*>(dy), scale, shift, \
+                                    xa, xb, c1, c2, hw, c, units, slope)
   if (vec) {
     int sl, upb, gy;
     stream_geometry(n, hw, c, epu, &sl, &upb, &gy);
@@ -571,8 +644,69 @@ extern "C" int mia_norm_act_bwd(const void* dz, const void* y, void* dy, int dty
       hipLaunchKernelGGL(norm_act_bwd_stream_kernel<float>, dim3(n * sl, gy), dim3(256), 0, st, static_cast<const float*>(dz), static_cast<const float*>(y), static_cast<float*>(dy), scale, shift, xa, xb, c1, c2, hw, c, sl, upb, slope);
   } else if (dtype == MIA_BF16) AP(bf16_t, false);
   else AP(float, false);
-#undef RD
 #undef AP
+}
+
+extern "C" int mia_norm_act_bwd(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
+                                const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
+                                int fixed_stats, float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma,
+                                float* dbeta, float* dbias, int accumulate, void* stream) {
+  MIA_CHECK_ARG(dz && y && dy && scale && shift && xa && xb && partials && c1 && c2 && dgamma && dbeta,
+                "mia_norm_act_bwd: null pointer");
+  MIA_CHECK_ARG(n > 0 && hw > 0 && c > 0 && slabs > 0, "mia_norm_act_bwd: bad shape");
+  if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_norm_act_bwd: bad dtype"); return MIA_EARG; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  bwd_reduce_launch(dz, y, dtype, scale, shift, xa, xb, n, hw, c, slope, slabs, partials, c1, c2, st);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, mode, fixed_stats, scale, xa,
+                     xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate, nullptr);
+  bwd_apply_launch(dz, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// local batch totals tot[3][C] = (sum g, sum g*xhat, pixel count) over this rank's images, from the per-(n,c) sums in c1 / c2
+__global__ void bn_bwd_local_tot_kernel(int n_img, int c, int64_t hw, const float* __restrict__ c1, const float* __restrict__ c2,
+                                        float* __restrict__ tot) {
+  __shared__ double sh1[16][17], sh2[16][17];
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double tg = 0.0, tgx = 0.0;
+  if (ch < c)
+    for (int n = tl; n < n_img; n += 16) { tg += c1[(size_t)n * c + ch]; tgx += c2[(size_t)n * c + ch]; }
+  sh1[tl][cl] = tg; sh2[tl][cl] = tgx;
+  __syncthreads();
+  if (tl == 0 && ch < c) {
+    tg = 0.0; tgx = 0.0;
+    for (int j = 0; j < 16; ++j) { tg += sh1[j][cl]; tgx += sh2[j][cl]; }
+    tot[ch] = (float)tg; tot[c + ch] = (float)tgx; tot[2 * c + ch] = (float)((double)n_img * (double)hw);
+  }
+}
+
+extern "C" int mia_norm_act_bwd_reduce(const void* dz, const void* y, int dtype, const float* scale, const float* shift,
+                                       const float* xa, const float* xb, int n, int64_t hw, int c, float slope, int slabs,
+                                       float* partials, float* c1, float* c2, float* tot, void* stream) {
+  MIA_CHECK_ARG(dz && y && scale && shift && xa && xb && partials && c1 && c2 && tot, "mia_norm_act_bwd_reduce: null pointer");
+  MIA_CHECK_ARG(n > 0 && hw > 0 && c > 0 && slabs > 0, "mia_norm_act_bwd_reduce: bad shape");
+  if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_norm_act_bwd_reduce: bad dtype"); return MIA_EARG; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  bwd_reduce_launch(dz, y, dtype, scale, shift, xa, xb, n, hw, c, slope, slabs, partials, c1, c2, st);
+  hipLaunchKernelGGL(bn_bwd_local_tot_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, c1, c2, tot);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+extern "C" int mia_norm_act_bwd_apply_sync(const void* dz, const void* y, void* dy, int dtype, const float* scale,
+                                           const float* shift, const float* xa, const float* xb, const float* ysum, int n,
+                                           int64_t hw, int c, float slope, float* c1, float* c2, const float* group_tot,
+                                           float* dgamma, float* dbeta, float* dbias, int accumulate, void* stream) {
+  MIA_CHECK_ARG(dz && y && dy && scale && shift && xa && xb && c1 && c2 && group_tot && dgamma && dbeta,
+                "mia_norm_act_bwd_apply_sync: null pointer");
+  MIA_CHECK_ARG(n > 0 && hw > 0 && c > 0, "mia_norm_act_bwd_apply_sync: bad shape");
+  if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_norm_act_bwd_apply_sync: bad dtype"); return MIA_EARG; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, NORM_BATCH, 0, scale, xa, xb,
+                     ysum, c1, c2, dgamma, dbeta, dbias, accumulate, group_tot);
+  bwd_apply_launch(dz, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

@@ -15,7 +15,7 @@ class RobustCrossEntropyLoss(nn.CrossEntropyLoss):
         if target.ndim == input.ndim:
             assert target.shape[1] == 1
             target = target[:, 0]
-        return hip_cross_entropy(self, input, target.long())
+        return hip_cross_entropy(self, input, target)
 
 
 def hip_cross_entropy(module, input: Tensor, target: Tensor) -> Tensor:
@@ -23,4 +23,6 @@ def hip_cross_entropy(module, input: Tensor, target: Tensor) -> Tensor:
             getattr(module, "reduction", "mean") != "mean":
         raise NotImplementedError("HIP cross-entropy implements the al_train configuration: no class weights, "
                                   "no label smoothing, reduction='mean'")
+    if target.shape != input.shape:
+        target = target.long()
     return ops.DiceCEFn.apply(input, target, ops.loss_flags(True, True, False, False), 1e-5, 0.0, 1.0, 0)

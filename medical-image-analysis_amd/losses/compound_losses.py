@@ -45,6 +45,7 @@ class DiceAndCELoss(nn.Module):
 
     def get_ce_loss(self, outputs: torch.Tensor, targets: torch.Tensor):
         if isinstance(self.ce_loss, nn.CrossEntropyLoss):
-            t = targets[:, 0] if targets.ndim == outputs.ndim else targets
-            return hip_cross_entropy(self.ce_loss, outputs, t.long())
+            if targets.ndim == outputs.ndim and targets.shape[1] == 1 and outputs.shape[1] > 1:
+                targets = targets[:, 0]
+            return hip_cross_entropy(self.ce_loss, outputs, targets)
         return self.ce_loss(outputs, targets)

@@ -26,8 +26,8 @@ class DiceLoss(nn.Module):
     def _check(self, outputs, targets):
         if outputs.ndim != 4:
             raise NotImplementedError("MI355X DiceLoss implements 2-D inputs [B, K, H, W]")
-        if targets.shape == outputs.shape:
-            raise NotImplementedError("dense (already one-hot / soft) targets are not built; pass a label map [B,H,W]")
+        if targets.shape == outputs.shape and outputs.shape[1] > 1:
+            return  # dense (one-hot / soft) target, used as is (reference dice_loss.py:40-41)
         assert outputs.shape[1] == self.num_classes, "inputs {} & num_classes+1 {} do not match".format(
             tuple(outputs.shape), self.num_classes)
         assert targets.numel() == outputs.shape[0] * outputs.shape[2] * outputs.shape[3], \

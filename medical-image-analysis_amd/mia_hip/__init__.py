@@ -20,7 +20,7 @@ F32, BF16 = 0, 1
 CONV_G3S1, CONV_G3S2, CONV_G2S2, CONV_T3S2, CONV_T2S2, CONV_G1 = range(6)
 WGRAD_3S1, WGRAD_3S2, WGRAD_2S2 = range(3)
 NORM_INSTANCE, NORM_BATCH = 0, 1
-LOSS_SOFTMAX, LOSS_DO_BG, LOSS_BATCH, LOSS_SQUARED = 1, 2, 4, 8
+LOSS_SOFTMAX, LOSS_DO_BG, LOSS_BATCH, LOSS_SQUARED, LOSS_DENSE = 1, 2, 4, 8, 16
 OPT_ADAM, OPT_ADAMW, OPT_SGD = 0, 1, 2
 
 
@@ -29,7 +29,7 @@ class MiaError(RuntimeError):
 
 
 _CTYPES = {
-    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "float": ctypes.c_float,
+    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "float": ctypes.c_float, "double": ctypes.c_double,
 }
 
 

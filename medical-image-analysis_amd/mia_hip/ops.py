@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import (BF16, CONV_G1, CONV_G2S2, CONV_G3S1, CONV_G3S2, CONV_T2S2, CONV_T3S2, F32, LOSS_BATCH, LOSS_DO_BG,
-               LOSS_SOFTMAX, LOSS_SQUARED, NORM_BATCH, NORM_INSTANCE, WGRAD_2S2, WGRAD_3S1, WGRAD_3S2, MiaError, call, lib)
+               LOSS_DENSE, LOSS_SOFTMAX, LOSS_SQUARED, NORM_BATCH, NORM_INSTANCE, WGRAD_2S2, WGRAD_3S1, WGRAD_3S2, MiaError, call, lib)
 
 LRELU_SLOPE = 0.01
 _c_int, _c_float, _c_i64 = ctypes.c_int, ctypes.c_float, ctypes.c_int64
@@ -225,12 +225,50 @@ def _slabs_for(hw: int) -> int:
 
 # ------------------------------------------------------------------ PlainBlock: conv3x3 -> dropout2d -> norm -> lrelu
 class NormCfg:
-    __slots__ = ("mode", "training", "eps", "momentum", "running_mean", "running_var", "num_batches", "drop_scale")
+    __slots__ = ("mode", "training", "eps", "momentum", "running_mean", "running_var", "num_batches", "drop_scale", "sync")
 
     def __init__(self, mode, training, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, num_batches=None,
-                 drop_scale=None):
+                 drop_scale=None, sync=None):
         self.mode, self.training, self.eps, self.momentum = mode, training, eps, momentum
         self.running_mean, self.running_var, self.num_batches, self.drop_scale = running_mean, running_var, num_batches, drop_scale
+        self.sync = sync  # BatchSync or None
+
+
+class BatchSync:
+    """Process group for synchronised batch-norm statistics (one process per GPU)."""
+
+    def __init__(self, process_group=None):
+        import torch.distributed as dist
+        self.dist, self.pg = dist, process_group
+        self.world = dist.get_world_size(process_group)
+
+    def all_gather(self, local: torch.Tensor) -> torch.Tensor:
+        out = torch.empty((self.world,) + tuple(local.shape), device=local.device, dtype=local.dtype)
+        self.dist.all_gather([out[r] for r in range(self.world)], local, group=self.pg)  # works on gloo and RCCL
+        return out
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.pg)
+        return t
+
+
+def _norm_finalize(cfg: NormCfg, stats, gamma, beta, n, cout, hw, coefs):
+    """Per-(n,c) coefficients from the conv-epilogue partials; batch statistics cover every rank when cfg.sync is set."""
+    sync = cfg.sync if (cfg.sync is not None and cfg.mode == NORM_BATCH and cfg.training and cfg.sync.world > 1) else None
+    if sync is None:
+        call("mia_norm_finalize", _p(stats), n, stats.shape[1], cout, _c_i64(hw), cfg.mode, int(cfg.training),
+             _p(cfg.drop_scale), _p(gamma.detach()), _p(beta.detach()), _c_float(cfg.eps), _c_float(cfg.momentum),
+             _p(cfg.running_mean), _p(cfg.running_var), _p(cfg.num_batches), _p(coefs[0]), _p(coefs[1]), _p(coefs[2]),
+             _p(coefs[3]), _p(coefs[4]), _stream())
+        return None
+    local = torch.empty((3, cout), device=stats.device, dtype=torch.float32)
+    call("mia_bn_sync_local_stats", _p(stats), n, stats.shape[1], cout, _c_i64(hw), _p(cfg.drop_scale), _p(coefs[0]),
+         _p(coefs[1]), _p(local), _stream())
+    gathered = sync.all_gather(local)
+    call("mia_norm_finalize_sync", _p(gathered), sync.world, n, cout, _c_i64(hw), _p(cfg.drop_scale), _p(gamma.detach()),
+         _p(beta.detach()), _c_float(cfg.eps), _c_float(cfg.momentum), _p(cfg.running_mean), _p(cfg.running_var),
+         _p(cfg.num_batches), _p(coefs[0]), _p(coefs[1]), _p(coefs[2]), _p(coefs[3]), _p(coefs[4]), _stream())
+    return sync
 
 
 class PlainBlockFn(torch.autograd.Function):
@@ -266,10 +304,7 @@ class PlainBlockFn(torch.autograd.Function):
         dev = x1.device
         coefs = torch.empty((5, n, cout), device=dev, dtype=torch.float32)  # xa, xb, scale, shift, sum_y
         fixed = cfg.mode == NORM_BATCH and not cfg.training
-        call("mia_norm_finalize", _p(stats), n, stats.shape[1], cout, _c_i64(ho * wo), cfg.mode, int(cfg.training),
-             _p(cfg.drop_scale), _p(gamma.detach()), _p(beta.detach()), _c_float(cfg.eps), _c_float(cfg.momentum),
-             _p(cfg.running_mean), _p(cfg.running_var), _p(cfg.num_batches), _p(coefs[0]), _p(coefs[1]), _p(coefs[2]),
-             _p(coefs[3]), _p(coefs[4]), _stream())
+        ctx.sync = _norm_finalize(cfg, stats, gamma, beta, n, cout, ho * wo, coefs)
         z = torch.empty_like(y)
         call("mia_norm_act_fwd", _p(y), _p(z), dtype, _p(coefs[2]), _p(coefs[3]), n, _c_i64(ho * wo), cout,
              _c_float(slope), _stream())
@@ -281,10 +316,7 @@ class PlainBlockFn(torch.autograd.Function):
     def _norm_act(ctx, y, stats, gamma, beta, cfg, n, cout, hw, slope=LRELU_SLOPE):
         dev = y.device
         coefs = torch.empty((5, n, cout), device=dev, dtype=torch.float32)  # xa, xb, scale, shift, sum_y
-        call("mia_norm_finalize", _p(stats), n, stats.shape[1], cout, _c_i64(hw), cfg.mode, int(cfg.training),
-             _p(cfg.drop_scale), _p(gamma.detach()), _p(beta.detach()), _c_float(cfg.eps), _c_float(cfg.momentum),
-             _p(cfg.running_mean), _p(cfg.running_var), _p(cfg.num_batches), _p(coefs[0]), _p(coefs[1]), _p(coefs[2]),
-             _p(coefs[3]), _p(coefs[4]), _stream())
+        ctx.sync = _norm_finalize(cfg, stats, gamma, beta, n, cout, hw, coefs)
         z = torch.empty_like(y)
         call("mia_norm_act_fwd", _p(y), _p(z), _dt(y), _p(coefs[2]), _p(coefs[3]), n, _c_i64(hw), cout, _c_float(slope),
              _stream())
@@ -320,9 +352,18 @@ class PlainBlockFn(torch.autograd.Function):
         dgb = torch.empty((3, cout), device=dev, dtype=torch.float32)
         dgamma, dbeta, dbias = dgb[0], dgb[1], dgb[2]
         dy = torch.empty_like(y)
-        call("mia_norm_act_bwd", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
-             _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs,
-             _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
+        if ctx.sync is None:
+            call("mia_norm_act_bwd", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
+                 _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs,
+                 _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
+        else:  # synchronised batch norm: the group means of g and g*xhat cover every rank's shard
+            tot = torch.empty((3, cout), device=dev, dtype=torch.float32)
+            call("mia_norm_act_bwd_reduce", _p(dz), _p(y), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]), n,
+                 _c_i64(hw), cout, _c_float(ctx.slope), slabs, _p(part), _p(cc[0]), _p(cc[1]), _p(tot), _stream())
+            ctx.sync.all_reduce_sum(tot)
+            call("mia_norm_act_bwd_apply_sync", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]),
+                 _p(coefs[1]), _p(coefs[4]), n, _c_i64(hw), cout, _c_float(ctx.slope), _p(cc[0]), _p(cc[1]), _p(tot),
+                 _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
         cin = weight.shape[1]
         if ctx.stem:
             ws = torch.empty(lib().mia_stem_wgrad_workspace(cout), device=dev, dtype=torch.float32)
@@ -444,10 +485,16 @@ class DiceCEFn(torch.autograd.Function):
             logits = logits.contiguous()
             st = _pix_strides(logits)
         b, k1, h, w = logits.shape
-        labels = labels.reshape(b, h, w)
-        if labels.dtype != torch.long:
-            labels = labels.long()
-        labels = labels.contiguous()
+        if labels.shape == logits.shape and k1 > 1:
+            # dense (already one-hot / soft) target: the reference skips its encoder (dice_loss.py:40-41) and
+            # torch's CrossEntropyLoss treats it as class probabilities
+            flags |= LOSS_DENSE
+            labels = labels.to(torch.float32).contiguous()
+        else:
+            labels = labels.reshape(b, h, w)
+            if labels.dtype != torch.long:
+                labels = labels.long()
+            labels = labels.contiguous()
         hw = h * w
         slabs = max(1, min(256, hw // 2048))
         dev = logits.device

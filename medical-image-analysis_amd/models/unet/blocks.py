@@ -82,6 +82,7 @@ class PlainBlock(nn.Module):
         self.normalization = normalization
         self.dropout_prob = dropout_prob
         self.drop_mask_override = None  # [N, Cout] tensor of {0, 1/(1-p)} for parity runs
+        self.batch_sync = None  # ops.BatchSync: batch-norm statistics over every data-parallel rank (convert_sync_batchnorm)
 
     def _cfg(self, n: int, device) -> ops.NormCfg:
         norm = self.all[2]
@@ -93,7 +94,7 @@ class PlainBlock(nn.Module):
             drop = torch.empty((n, norm.num_features), device=device, dtype=torch.float32).bernoulli_(keep).div_(keep)
         if self.normalization == "batch":
             return ops.NormCfg(NORM_BATCH, self.training, norm.eps, norm.momentum, norm.running_mean, norm.running_var,
-                               norm.num_batches_tracked, drop)
+                               norm.num_batches_tracked, drop, sync=self.batch_sync)
         return ops.NormCfg(NORM_INSTANCE, self.training, norm.eps, 0.1, None, None, None, drop)
 
     def forward_nhwc(self, x1, x2=None, out_dtype=None):
@@ -166,3 +167,16 @@ class ResidualBlock(nn.Module):
     def forward(self, x):
         dt = x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
         return ops.nhwc_as_nchw(self.forward_nhwc(ops.to_nhwc(x, dt)))
+
+
+def convert_sync_batchnorm(model: nn.Module, process_group=None) -> nn.Module:
+    """Make every batch-norm PlainBlock of `model` take its batch statistics over all ranks of `process_group`
+    (one process per GPU), so N ranks x bs reproduce one process at N*bs (the reference is
+    single-process, blocks.py:98).  Needs an initialised torch.distributed group; a no-op for instance norm."""
+    sync = ops.BatchSync(process_group)
+    for m in model.modules():
+        if isinstance(m, PlainBlock) and m.normalization == "batch":
+            m.batch_sync = sync
+        elif isinstance(m, ResidualBlock) and m.normalization == "batch":
+            raise NotImplementedError("synchronised batch norm is built for PlainBlock (the block al_train uses)")
+    return model

@@ -13,7 +13,9 @@ clip_grad_norm_(10), optimizer step -- but with
   the flat gradient buffer, issued from autograd hooks while backward is still running (RCCL runs it
   on its own HIP stream), joined before the global-norm clip; gradients are averaged by folding
   1/world into the optimizer launch.  Buckets are laid out in REVERSE forward order so the first
-  gradients produced fill the first bucket.
+  gradients produced fill the first bucket.  ``sync_batchnorm=True`` adds the second, small
+  collective SURVEY 8e names (per-channel batch statistics, 3*C + 2*C floats per layer) so batch-norm models are
+  exact under sharding too.
 """
 from __future__ import annotations
 
@@ -162,8 +164,12 @@ class TrainEngine:
 
     def __init__(self, model, loss_fn, optimizer_name: str = "adam", optimizer_kwargs: Optional[dict] = None,
                  start_lr: float = 1e-3, num_iters: int = 4000, lr_warmup_iter: int = 250, lr_interval: int = 1,
-                 lr_scheduler_name: str = "poly", grad_norm: float = 10.0, process_group=None, bucket_bytes: int = 32 << 20):
+                 lr_scheduler_name: str = "poly", grad_norm: float = 10.0, process_group=None, bucket_bytes: int = 32 << 20,
+                 sync_batchnorm: bool = False):
         self.model = model
+        if sync_batchnorm and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            from models.unet.blocks import convert_sync_batchnorm
+            convert_sync_batchnorm(model, process_group)
         self.loss_fn = loss_fn
         kw = dict(optimizer_kwargs or {})
         self.optimizer = FlatOptimizer(model, optimizer_name, bucket_bytes=bucket_bytes, **kw)

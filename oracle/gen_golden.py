@@ -118,6 +118,21 @@ def gen_losses(ref):
     d["dice_ce_w"] = _np(v)
     d["dice_ce_w_grad"] = _np(li.grad)
     d["dice_ce_zero_weight_quirk"] = _np(comp(logits, labels, dice_weight=0.0, ce_weight=None))
+    # dense (soft) targets with the logits' shape: the reference skips its one-hot encoder (dice_loss.py:40-41)
+    soft = torch.softmax(torch.randn(b, k1, h, w, generator=gen) * 3, dim=1)
+    d["soft_targets"] = _np(soft)
+    for squared in (False, True):
+        li = logits.clone().requires_grad_(True)
+        v = ref.dice_loss.DiceLoss(k1 - 1, do_bg=False, squared=squared)(li, soft)
+        v.backward()
+        d[f"dense_dice_s{int(squared)}"] = _np(v)
+        d[f"dense_dice_s{int(squared)}_grad"] = _np(li.grad)
+    li = logits.clone().requires_grad_(True)
+    comp_t = ref.compound.DiceAndCELoss(dice_kwargs=dict(num_classes=k1 - 1, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss)
+    v = comp_t(li, soft)
+    v.backward()
+    d["dense_dice_ce"] = _np(v)
+    d["dense_dice_ce_grad"] = _np(li.grad)
     # known-answer tests
     lab = torch.tensor([[[0, 1], [2, 2]]])
     uni = torch.zeros(1, 3, 2, 2)

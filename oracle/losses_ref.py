@@ -43,7 +43,10 @@ def dice_loss(outputs: torch.Tensor, targets: torch.Tensor, num_classes: int, sm
 
 
 def ce_loss(outputs: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
-    """ce_loss.py:12-16 / torch.nn.CrossEntropyLoss(): mean over all pixels."""
+    """ce_loss.py:12-16 / torch.nn.CrossEntropyLoss(): mean over all pixels.  A target with the logits' shape is a
+    class-probability target (torch.nn.CrossEntropyLoss semantics; reached through DiceAndCELoss with dense targets)."""
+    if targets.shape == outputs.shape and outputs.shape[1] > 1:
+        return F.cross_entropy(outputs, targets.float())
     if targets.ndim == outputs.ndim:
         assert targets.shape[1] == 1
         targets = targets[:, 0]

@@ -32,7 +32,7 @@ def _data():
     return x, y
 
 
-def _make_engine(dev, bucket_bytes=32 << 20):
+def _make_engine(dev, bucket_bytes=32 << 20, norm="instance", sync_bn=False):
     for p in (ROOT, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -40,22 +40,23 @@ def _make_engine(dev, bucket_bytes=32 << 20):
     from models.unet import UNet
     from training.engine import TrainEngine
     torch.manual_seed(1337)
-    m = UNet(2, 1, 3, [8, 16, 32], normalization="instance", dropout_prob=None).to(dev)
+    m = UNet(2, 1, 3, [8, 16, 32], normalization=norm, dropout_prob=None).to(dev)
     return TrainEngine(m, DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True)), "adam", {"weight_decay": 5e-4},
-                       start_lr=1e-2, num_iters=100, lr_warmup_iter=2, bucket_bytes=bucket_bytes)
+                       start_lr=1e-2, num_iters=100, lr_warmup_iter=2, bucket_bytes=bucket_bytes, sync_batchnorm=sync_bn)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, norm="instance", sync_bn=False, shards=((0, 2), (2, 4))):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
-    eng = _make_engine(dev, bucket_bytes=4096)  # several buckets
+    eng = _make_engine(dev, bucket_bytes=4096, norm=norm, sync_bn=sync_bn)  # several buckets
     assert eng.reducer.world == world and len(eng.optimizer.buckets) > 2
     x, y = _data()
-    lo, hi = rank * 2, rank * 2 + 2
+    lo, hi = shards[rank]
     losses = [eng.train_step({"image": x[lo:hi], "label": y[lo:hi]}).item() for _ in range(2)]
     torch.cuda.synchronize()
-    q.put((rank, losses, eng.optimizer.flat_param.cpu().numpy()))
+    bn = [b.detach().cpu().numpy() for k, b in eng.model.named_buffers() if "running" in k]
+    q.put((rank, losses, eng.optimizer.flat_param.cpu().numpy(), bn))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,5 +82,35 @@ def test_two_rank_engine_equals_single_process_full_batch():
     np.testing.assert_array_equal(res[0][2], res[1][2])  # replicas stay bit-identical
     np.testing.assert_allclose(res[0][2], ref, atol=2e-5)
     # the full-batch loss is the mean of the two shard losses (equal shard sizes)
+    for i in range(2):
+        assert abs(0.5 * (res[0][1][i] + res[1][1][i]) - ref_losses[i]) < 1e-5
+
+
+def test_two_rank_sync_batchnorm_equals_single_process_full_batch():
+    """Batch norm (the al_train default) is exact under sharding only with the statistics collective: forward all-gather of
+    (mean, M2, count), backward all-reduce of (sum g, sum g*xhat, count).  Parameters and running statistics after two
+    steps on 2 x bs 2 must equal one process at bs 4."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "batch", True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    eng = _make_engine(torch.device("cuda:0"), norm="batch")
+    x, y = _data()
+    ref_losses = [eng.train_step({"image": x, "label": y}).item() for _ in range(2)]
+    ref = eng.optimizer.flat_param.cpu().numpy()
+    ref_bn = [b.detach().cpu().numpy() for k, b in eng.model.named_buffers() if "running" in k]
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    np.testing.assert_allclose(res[0][2], ref, atol=3e-5)
+    assert len(ref_bn) == len(res[0][3]) > 0
+    for a, b in zip(res[0][3], ref_bn):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6)
     for i in range(2):
         assert abs(0.5 * (res[0][1][i] + res[1][1][i]) - ref_losses[i]) < 1e-5

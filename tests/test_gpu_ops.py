@@ -241,6 +241,19 @@ def test_losses_golden(golden_dir):
     assert abs(v.item() - float(d["dice_ce_w"])) < 2e-6
     np.testing.assert_allclose(li.grad.cpu().numpy(), d["dice_ce_w_grad"], atol=2e-7)
     assert abs(comp(logits, labels, dice_weight=0.0, ce_weight=None).item() - float(d["dice_ce_zero_weight_quirk"])) < 2e-6
+    # dense (soft) targets of the logits' shape (dice_loss.py:40-41; torch CE with class probabilities)
+    soft = torch.from_numpy(d["soft_targets"]).to(dev)
+    for squared in (False, True):
+        li = logits.clone().requires_grad_(True)
+        v = DiceLoss(3, do_bg=False, squared=squared)(li, soft)
+        v.backward()
+        assert abs(v.item() - float(d[f"dense_dice_s{int(squared)}"])) < 2e-6
+        np.testing.assert_allclose(li.grad.cpu().numpy(), d[f"dense_dice_s{int(squared)}_grad"], atol=2e-7)
+    li = logits.clone().requires_grad_(True)
+    v = DiceAndCELoss(dice_kwargs=dict(num_classes=3, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss)(li, soft)
+    v.backward()
+    assert abs(v.item() - float(d["dense_dice_ce"])) < 2e-6
+    np.testing.assert_allclose(li.grad.cpu().numpy(), d["dense_dice_ce_grad"], atol=2e-7)
     # known answers
     lab = torch.tensor([[[0, 1], [2, 2]]], device=dev)
     fn = DiceLoss(2, do_bg=True)

@@ -108,6 +108,14 @@ def test_losses():
     np.testing.assert_allclose(losses_ref.dice_and_ce(logits, labels, 3, 0.7, 0.3).item(), d["dice_ce_w"], atol=1e-6)
     np.testing.assert_allclose(losses_ref.dice_and_ce(logits, labels, 3, 0.0, None).item(),
                                d["dice_ce_zero_weight_quirk"], atol=1e-6)
+    soft = torch.from_numpy(d["soft_targets"])
+    for squared in (False, True):
+        li = logits.clone().requires_grad_(True)
+        v = losses_ref.dice_loss(li, soft, 3, do_bg=False, squared=squared)
+        v.backward()
+        np.testing.assert_allclose(v.item(), d[f"dense_dice_s{int(squared)}"], atol=1e-6)
+        np.testing.assert_allclose(li.grad.numpy(), d[f"dense_dice_s{int(squared)}_grad"], atol=1e-7)
+    np.testing.assert_allclose(losses_ref.dice_and_ce(logits, soft, 3).item(), d["dense_dice_ce"], atol=1e-6)
     # known answers
     lab = torch.tensor([[[0, 1], [2, 2]]])
     assert abs(losses_ref.dice_loss(torch.zeros(1, 3, 2, 2), lab, 2, do_bg=True).item() - 0.6761878354) < 1e-6
