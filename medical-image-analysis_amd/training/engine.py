@@ -201,6 +201,16 @@ class TrainEngine:
         self.current_iter += 1
         return loss.detach()
 
+    def save_state_dict(self, save_path, save_training_state: bool = False, **extra) -> None:
+        """model.pth (+ training_state.pth) in the reference's layout (al_trainer.py:1719-1733)."""
+        from training import checkpoint
+        checkpoint.save_state_dict(self, save_path, save_training_state, **extra)
+
+    def load_state_dict(self, save_path) -> dict:
+        """al_trainer.py:1704-1717."""
+        from training import checkpoint
+        return checkpoint.load_state_dict(self, save_path)
+
     @torch.no_grad()
     def predict(self, image: torch.Tensor) -> torch.Tensor:
         """valid_slices core (al_trainer.py:1428-1431): eval forward -> softmax -> argmax."""
