@@ -208,9 +208,10 @@ int mia_argmax_dice_workspace(int nb, int k1, int slabs); /* floats */
 int mia_argmax_dice(const float* logits, const long long* labels, long long* pred, int nb, int64_t hw, int k1, int64_t sn, int64_t sk,
                     int64_t sp, int slabs, float* workspace, float* counts, float* dice, void* stream);
 /* scores[B][3] = (entropy, least-confidence, margin) acquisition scores of the active-learning selectors
- * (entropy_selector.py:42-49, confidence_selector.py:42-47, margin_selector.py:42-48) */
+ * (entropy_selector.py:42-49, confidence_selector.py:42-47, margin_selector.py:42-48); smooth = the entropy selector's
+ * log2(p + smooth) guard (1e-8 in al_train) */
 int mia_selector_scores_workspace(int nb, int slabs); /* floats */
-int mia_selector_scores(const float* logits, int nb, int64_t hw, int k1, int64_t sn, int64_t sk, int64_t sp, int slabs,
+int mia_selector_scores(const float* logits, int nb, int64_t hw, int k1, int64_t sn, int64_t sk, int64_t sp, float smooth, int slabs,
                         float* workspace, float* scores, void* stream);
 
 #ifdef __cplusplus

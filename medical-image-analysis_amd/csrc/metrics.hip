@@ -5,7 +5,7 @@
 //   prediction is empty) as one pass: label map out + per-(image, class) counts |P&G|, |P|, |G|.  softmax is monotone,
 //   so argmax is taken on the logits (first maximum wins, like torch.argmax).
 // * mia_selector_scores: the per-image acquisition scores of the active-learning selectors, fused softmax + reduction:
-//   entropy    mean_{c,h,w}( -p * log2(p + 1e-8) )     (src/activelearning/entropy_selector.py:42-49)
+//   entropy    mean_{c,h,w}( -p * log2(p + smooth) )     (src/activelearning/entropy_selector.py:42-49)
 //   confidence mean_{h,w}( -max_c p )                    (confidence_selector.py:42-47)
 //   margin     mean_{h,w}( -(p_top1 - p_top2) )          (margin_selector.py:42-48)
 // Both read K1 logits (+ one label) per pixel once; wave-shuffle + LDS block reductions, no float atomics.
@@ -83,7 +83,7 @@ extern "C" int mia_argmax_dice(const float* logits, const long long* labels, lon
 }
 
 // scores partials: part[b][slab][3] = (sum entropy terms, sum -max p, sum -(p1 - p2))
-__global__ void selector_scores_kernel(const float* __restrict__ logits, int64_t hw, int k1, MGeom g, int slabs, float* __restrict__ part) {
+__global__ void selector_scores_kernel(const float* __restrict__ logits, int64_t hw, int k1, MGeom g, int slabs, float smooth, float* __restrict__ part) {
   __shared__ float red[16];
   const int b = blockIdx.x / slabs, s = blockIdx.x % slabs;
   const int64_t per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
@@ -103,7 +103,7 @@ __global__ void selector_scores_kernel(const float* __restrict__ logits, int64_t
     for (int k = 0; k < MAXK; ++k)
       if (k < k1) {
         const float pk = v[k] * inv;
-        se += -pk * log2f(pk + 1e-8f);
+        se += -pk * log2f(pk + smooth);
         if (pk > p1) { p2 = p1; p1 = pk; } else if (pk > p2) p2 = pk;
       }
     sc += -p1;
@@ -128,13 +128,13 @@ __global__ void selector_finalize_kernel(const float* __restrict__ part, int nb,
 
 extern "C" int mia_selector_scores_workspace(int nb, int slabs) { return nb * slabs * 3; }
 
-extern "C" int mia_selector_scores(const float* logits, int nb, int64_t hw, int k1, int64_t sn, int64_t sk, int64_t sp, int slabs,
+extern "C" int mia_selector_scores(const float* logits, int nb, int64_t hw, int k1, int64_t sn, int64_t sk, int64_t sp, float smooth, int slabs,
                                    float* workspace, float* scores, void* stream) {
   MIA_CHECK_ARG(logits && workspace && scores && nb > 0 && hw > 0 && slabs > 0, "mia_selector_scores: bad arguments");
   MIA_CHECK_ARG(k1 >= 2 && k1 <= MAXK, "mia_selector_scores: k1=%d not in [2,%d]", k1, MAXK);
   hipStream_t st = static_cast<hipStream_t>(stream);
   MGeom g{sn, sk, sp};
-  hipLaunchKernelGGL(selector_scores_kernel, dim3(nb * slabs), dim3(256), 0, st, logits, hw, k1, g, slabs, workspace);
+  hipLaunchKernelGGL(selector_scores_kernel, dim3(nb * slabs), dim3(256), 0, st, logits, hw, k1, g, slabs, smooth, workspace);
   hipLaunchKernelGGL(selector_finalize_kernel, dim3(ceil_div(nb, 64)), dim3(64), 0, st, workspace, nb, slabs, k1, hw, scores);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
