@@ -155,6 +155,37 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
             for (int n = 0; n < NT; ++n) acc[m][n] = Mma<T>::run(af[m], bf[n], acc[m][n]);
         }
       }
+    } else if constexpr (MODE == MODE_G3S1) {
+      // stride-1 3x3: the A fragment of (row m, tap (ta, tb)) is the 16-pixel run of image row m + ta shifted by tb,
+      // i.e. it depends on (m + ta, tb) only -- so per tb the wave reads its MT + 2 rows ONCE and slides the 3 vertical
+      // taps over them in registers: 3 * (MT + 2) A reads per chunk instead of 9 * MT (18 vs 36 at MT = 4; the LDS pipe
+      // is as busy as the matrix pipe at 72 reads per 144 MFMAs).  B fragments and the next tb's rows are fetched one
+      // step ahead, spread over the three steps of a tb so every step issues the same number of ds_read_b128.
+      constexpr int ROWS = MT + 2, RPS = (ROWS + 2) / 3;
+      u32x4 fr[2][ROWS], bf[2][NT];
+      auto load_row = [&](int j, int tb, u32x4* f) { f[j] = ldsA[q * NPA + (wave * MT + j) * PITCH + tb + pr]; };
+      auto load_b = [&](int tl, u32x4* b) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[n] = ldsB[(tl * 4 + q) * NPB + n * 16 + pr];
+      };
+#pragma unroll
+      for (int j = 0; j < ROWS; ++j) load_row(j, 0, fr[0]);
+      load_b(0, bf[0]);
+#pragma unroll
+      for (int step = 0; step < 9; ++step) {
+        const int tb = step / 3, ta = step % 3;
+        const int cf = tb & 1, cb = step & 1;
+        if (step + 1 < 9) load_b(((step + 1) % 3) * 3 + (step + 1) / 3, bf[cb ^ 1]);
+        if (tb < 2) {
+#pragma unroll
+          for (int j = ta * RPS; j < (ta + 1) * RPS && j < ROWS; ++j) load_row(j, tb + 1, fr[cf ^ 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = Mma<T>::run(fr[cf][m + ta], bf[cb][n], acc[m][n]);
+      }
     } else {
       // compile-time taps: fragments are double buffered in registers -- tap t+1's ds_read_b128s are issued before
       // tap t's MT*NT MFMAs, so the LDS latency hides behind a full tap of matrix work
