@@ -112,6 +112,15 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the bias is loaded up front: at the top of the epilogue it would expose a full memory round trip per block
+  const int nout = a.o1 + a.o2;
+  float bv[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    int bi = n0 + n * 16 + pr;
+    bi = bi < nout ? bi : nout - 1;
+    bv[n] = a.bias ? a.bias[bi] : 0.f;
+  }
 
   u32x4 pa[A_IT], pb[B_IT];
   auto fetch = [&](int c0) {
@@ -217,14 +226,6 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
   // ---- epilogue
   const int hd = TMODE ? (a.Hout - ph + 1) / 2 : a.Hout;
   const int wd = TMODE ? (a.Wout - pw + 1) / 2 : a.Wout;
-  const int nout = a.o1 + a.o2;
-  float bv[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    int bi = n0 + n * 16 + pr;
-    bi = bi < nout ? bi : nout - 1;
-    bv[n] = a.bias ? a.bias[bi] : 0.f;
-  }
   int rowoff[4];
   float cmask[4];
 #pragma unroll
@@ -267,7 +268,9 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
     const float t1 = ldsR[0 * BN + tid] + ldsR[1 * BN + tid] + ldsR[2 * BN + tid] + ldsR[3 * BN + tid];
     const float t2 = ldsR[4 * BN + tid] + ldsR[5 * BN + tid] + ldsR[6 * BN + tid] + ldsR[7 * BN + tid];
     const size_t tile = (size_t)img * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx;
-    float* dst = a.stats + (tile * nout + n0 + tid) * 2;
+    // global (not flat) store: a flat access makes the compiler drain every outstanding memory operation around it
+    typedef __attribute__((address_space(1))) float gfloat;
+    gfloat* dst = (gfloat*)(a.stats + (tile * nout + n0 + tid) * 2);
     dst[0] = t1; dst[1] = t2;
   }
   // coalesced 16-byte stores; the block's channel range lies in exactly one destination
