@@ -58,6 +58,182 @@ __global__ void head_fwd_kernel(const T* __restrict__ x, const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------- specialised head kernels
+// K1 (logits) and UPP (16-byte units per pixel = threads per pixel, 4 / 8 / 16) are compile-time: a thread owns one
+// channel unit for its whole life, so its K1 x EPU weights sit in registers, there is no per-element index arithmetic
+// (32-bit pixel counters, pointers advanced by a constant stride) and the cross-lane sums are DPP butterflies instead
+// of LDS permutes.  Contract: c0 == UPP * EPU, pixel-linear logits (sn == hw * sp), n * hw * c0 < 2^31.
+__device__ __forceinline__ float dpp_add(float v, int ctrl_sel) {
+  const int iv = __builtin_bit_cast(int, v);
+  int r;
+  if (ctrl_sel == 0) r = __builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]: lane ^ 1
+  else if (ctrl_sel == 1) r = __builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]: lane ^ 2
+  else if (ctrl_sel == 2) r = __builtin_amdgcn_update_dpp(iv, iv, 0x141, 0xF, 0xF, false);  // row_half_mirror: other quad of 8
+  else r = __builtin_amdgcn_update_dpp(iv, iv, 0x140, 0xF, 0xF, false);                     // row_mirror: other half of 16
+  return v + __builtin_bit_cast(float, r);
+}
+template <int UPP> __device__ __forceinline__ float group_sum(float v) {  // every lane of the UPP group gets the sum
+  v = dpp_add(v, 0); v = dpp_add(v, 1);
+  if (UPP >= 8) v = dpp_add(v, 2);
+  if (UPP >= 16) v = dpp_add(v, 3);
+  return v;
+}
+
+template <typename T, int K1, int UPP>
+__global__ __launch_bounds__(256) void head_fwd_fast_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ out, int npix,
+                                                            int64_t osp, int64_t osk) {
+  constexpr int EPU = Elem<T>::EPU, C0 = UPP * EPU, LANES = 256 / UPP;
+  const int u = threadIdx.x % UPP, pl = threadIdx.x / UPP;
+  float wr[K1][EPU];
+#pragma unroll
+  for (int k = 0; k < K1; ++k)
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) wr[k][e] = w[k * C0 + u * EPU + e];
+  float bu = 0.f;
+#pragma unroll
+  for (int k = 0; k < K1; ++k) bu = (u == k) ? b[k] : bu;
+  const int stride = gridDim.x * LANES;
+  auto body = [&](const u32x4& raw, int p) {
+    alignas(16) T v[EPU];
+    *reinterpret_cast<u32x4*>(v) = raw;
+    float acc[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) {
+      const float xv = Elem<T>::ld(v + e);
+#pragma unroll
+      for (int k = 0; k < K1; ++k) acc[k] += xv * wr[k][e];
+    }
+    float mine = 0.f;  // lane u < K1 of the group writes logit u: one store instruction, K1 adjacent floats per pixel
+#pragma unroll
+    for (int k = 0; k < K1; ++k) { const float t = group_sum<UPP>(acc[k]); mine = (u == k) ? t : mine; }
+    if (u < K1) out[(int64_t)p * osp + u * osk] = mine + bu;
+  };
+  int p = blockIdx.x * LANES + pl;
+  for (; p + stride < npix; p += 2 * stride) {  // two independent 16-byte loads in flight
+    const u32x4 r0 = *reinterpret_cast<const u32x4*>(x + (size_t)p * C0 + u * EPU);
+    const u32x4 r1 = *reinterpret_cast<const u32x4*>(x + (size_t)(p + stride) * C0 + u * EPU);
+    body(r0, p); body(r1, p + stride);
+  }
+  if (p < npix) body(*reinterpret_cast<const u32x4*>(x + (size_t)p * C0 + u * EPU), p);
+}
+
+template <typename T, int K1, int UPP>
+__global__ __launch_bounds__(256) void head_bwd_input_fast_kernel(const float* __restrict__ dl, const float* __restrict__ w,
+                                                                  T* __restrict__ dx, int npix, int64_t gsp, int64_t gsk) {
+  constexpr int EPU = Elem<T>::EPU, C0 = UPP * EPU, LANES = 256 / UPP;
+  const int u = threadIdx.x % UPP, pl = threadIdx.x / UPP;
+  float wr[K1][EPU];
+#pragma unroll
+  for (int k = 0; k < K1; ++k)
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) wr[k][e] = w[k * C0 + u * EPU + e];
+  const int stride = gridDim.x * LANES;
+  for (int p = blockIdx.x * LANES + pl; p < npix; p += stride) {
+    const float* g = dl + (int64_t)p * gsp;
+    float gv[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) gv[k] = g[k * gsk];
+    alignas(16) T o[EPU];
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < K1; ++k) a += gv[k] * wr[k][e];
+      o[e] = Elem<T>::cvt(a);
+    }
+    *reinterpret_cast<u32x4*>(dx + (size_t)p * C0 + u * EPU) = *reinterpret_cast<const u32x4*>(o);
+  }
+}
+
+// part: [gridDim.x][K1][C0 + 1] (last column = bias partial), same layout as the generic kernels
+template <typename T, int K1, int UPP>
+__global__ __launch_bounds__(256) void head_bwd_weight_fast_kernel(const float* __restrict__ dl, const T* __restrict__ x,
+                                                                   float* __restrict__ part, int npix, int64_t gsp, int64_t gsk) {
+  constexpr int EPU = Elem<T>::EPU, C0 = UPP * EPU, LANES = 256 / UPP, SHS = C0 + 1;
+  __shared__ float shd[LANES * SHS];
+  const int u = threadIdx.x % UPP, pl = threadIdx.x / UPP;
+  const int per = (npix + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = r0 + per < npix ? r0 + per : npix;
+  float acc[K1][EPU], bacc[K1];
+#pragma unroll
+  for (int k = 0; k < K1; ++k) {
+    bacc[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) acc[k][e] = 0.f;
+  }
+  auto body = [&](const u32x4& raw, const float* gv) {
+    alignas(16) T v[EPU];
+    *reinterpret_cast<u32x4*>(v) = raw;
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) {
+      const float xv = Elem<T>::ld(v + e);
+#pragma unroll
+      for (int k = 0; k < K1; ++k) acc[k][e] += gv[k] * xv;
+    }
+#pragma unroll
+    for (int k = 0; k < K1; ++k) bacc[k] += gv[k];
+  };
+  int p = r0 + pl;
+  for (; p + LANES < r1; p += 2 * LANES) {
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(x + (size_t)p * C0 + u * EPU);
+    const u32x4 a1 = *reinterpret_cast<const u32x4*>(x + (size_t)(p + LANES) * C0 + u * EPU);
+    float g0[K1], g1[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) { g0[k] = dl[(int64_t)p * gsp + k * gsk]; g1[k] = dl[(int64_t)(p + LANES) * gsp + k * gsk]; }
+    body(a0, g0); body(a1, g1);
+  }
+  if (p < r1) {
+    float g0[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) g0[k] = dl[(int64_t)p * gsp + k * gsk];
+    body(*reinterpret_cast<const u32x4*>(x + (size_t)p * C0 + u * EPU), g0);
+  }
+#pragma unroll
+  for (int k = 0; k < K1; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) shd[pl * SHS + u * EPU + e] = acc[k][e];
+    if (u == 0) shd[pl * SHS + C0] = bacc[k];
+    __syncthreads();
+    if (threadIdx.x <= C0) {
+      float t = 0.f;
+      for (int j = 0; j < LANES; ++j) t += shd[j * SHS + threadIdx.x];
+      part[((size_t)blockIdx.x * K1 + k) * (C0 + 1) + threadIdx.x] = t;
+    }
+  }
+}
+
+// 0 = not eligible; otherwise UPP
+static int head_fast_upp(int dtype, int c0, int k1, int64_t npix, int64_t sn, int64_t sp, int64_t hw, const void* x) {
+  const int epu = dtype == MIA_BF16 ? 8 : 4;
+  if (dtype != MIA_BF16 && dtype != MIA_F32) return 0;
+  if (c0 % epu != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return 0;
+  const int upp = c0 / epu;
+  if (upp != 4 && upp != 8 && upp != 16) return 0;
+  if (k1 < 2 || k1 > 4) return 0;
+  if (sn != hw * sp || npix * c0 >= ((int64_t)1 << 31)) return 0;
+  return upp;
+}
+#define HEAD_DISPATCH(KERNEL, T, grid, ...)                                                                           \
+  do {                                                                                                                \
+    if (upp == 4) {                                                                                                   \
+      if (k1 == 2) hipLaunchKernelGGL((KERNEL<T, 2, 4>), grid, dim3(256), 0, st, __VA_ARGS__);                        \
+      else if (k1 == 3) hipLaunchKernelGGL((KERNEL<T, 3, 4>), grid, dim3(256), 0, st, __VA_ARGS__);                   \
+      else hipLaunchKernelGGL((KERNEL<T, 4, 4>), grid, dim3(256), 0, st, __VA_ARGS__);                                \
+    } else if (upp == 8) {                                                                                            \
+      if (k1 == 2) hipLaunchKernelGGL((KERNEL<T, 2, 8>), grid, dim3(256), 0, st, __VA_ARGS__);                        \
+      else if (k1 == 3) hipLaunchKernelGGL((KERNEL<T, 3, 8>), grid, dim3(256), 0, st, __VA_ARGS__);                   \
+      else hipLaunchKernelGGL((KERNEL<T, 4, 8>), grid, dim3(256), 0, st, __VA_ARGS__);                                \
+    } else {                                                                                                          \
+      if (k1 == 2) hipLaunchKernelGGL((KERNEL<T, 2, 16>), grid, dim3(256), 0, st, __VA_ARGS__);                       \
+      else if (k1 == 3) hipLaunchKernelGGL((KERNEL<T, 3, 16>), grid, dim3(256), 0, st, __VA_ARGS__);                  \
+      else hipLaunchKernelGGL((KERNEL<T, 4, 16>), grid, dim3(256), 0, st, __VA_ARGS__);                               \
+    }                                                                                                                 \
+  } while (0)
+
+
 extern "C" int mia_head_fwd(const void* x, int dtype, const float* w, const float* b, float* logits, int n, int64_t hw,
                             int c0, int k1, int64_t osn, int64_t osk, int64_t osp, void* stream) {
   MIA_CHECK_ARG(x && w && b && logits && n > 0 && hw > 0 && c0 > 0, "mia_head_fwd: bad arguments");
@@ -66,6 +242,14 @@ extern "C" int mia_head_fwd(const void* x, int dtype, const float* w, const floa
   const int64_t npix = (int64_t)n * hw;
   const int blocks = (int)((npix * 8 + 255) / 256 < 8192 ? (npix * 8 + 255) / 256 : 8192);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (const int upp = head_fast_upp(dtype, c0, k1, npix, osn, osp, hw, x)) {
+    const int lanes = 256 / upp;
+    const int fblocks = (int)((npix + 2 * lanes - 1) / (2 * lanes) < 16384 ? (npix + 2 * lanes - 1) / (2 * lanes) : 16384);
+    if (dtype == MIA_BF16) HEAD_DISPATCH(head_fwd_fast_kernel, bf16_t, dim3(fblocks), static_cast<const bf16_t*>(x), w, b, logits, (int)npix, osp, osk);
+    else HEAD_DISPATCH(head_fwd_fast_kernel, float, dim3(fblocks), static_cast<const float*>(x), w, b, logits, (int)npix, osp, osk);
+    MIA_LAUNCH_CHECK();
+    return MIA_OK;
+  }
   if (dtype == MIA_BF16)
     hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), k1 * c0 * 4, st, static_cast<const bf16_t*>(x), w, b, logits, npix, c0, k1, osp, osk, osn, hw);
   else if (dtype == MIA_F32)
@@ -257,7 +441,18 @@ extern "C" int mia_head_bwd(const float* dlogits, const void* x, int dtype, cons
   const int epu = dtype == MIA_BF16 ? 8 : 4;
   const bool vec = (c0 % epu == 0) && c0 <= 255 && c0 / epu <= 128 && (256 / (c0 / epu)) <= 128 &&
                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
-  if (vec && (dtype == MIA_BF16 || dtype == MIA_F32)) {
+  const int upp = ((reinterpret_cast<uintptr_t>(dx) & 15) == 0) ? head_fast_upp(dtype, c0, k1, npix, gsn, gsp, hw, x) : 0;
+  if (upp) {
+    const int lanes = 256 / upp;
+    const int iblocks = (int)((npix + lanes - 1) / lanes < 16384 ? (npix + lanes - 1) / lanes : 16384);
+    if (dtype == MIA_BF16) {
+      if (dx) HEAD_DISPATCH(head_bwd_input_fast_kernel, bf16_t, dim3(iblocks), dlogits, w, static_cast<bf16_t*>(dx), (int)npix, gsp, gsk);
+      HEAD_DISPATCH(head_bwd_weight_fast_kernel, bf16_t, dim3(wblocks), dlogits, static_cast<const bf16_t*>(x), workspace, (int)npix, gsp, gsk);
+    } else {
+      if (dx) HEAD_DISPATCH(head_bwd_input_fast_kernel, float, dim3(iblocks), dlogits, w, static_cast<float*>(dx), (int)npix, gsp, gsk);
+      HEAD_DISPATCH(head_bwd_weight_fast_kernel, float, dim3(wblocks), dlogits, static_cast<const float*>(x), workspace, (int)npix, gsp, gsk);
+    }
+  } else if (vec && (dtype == MIA_BF16 || dtype == MIA_F32)) {
     const int64_t units = npix * (c0 / epu);
     const int vblocks = (int)((units + 255) / 256 < 16384 ? (units + 255) / 256 : 16384);
     if (dtype == MIA_BF16) {

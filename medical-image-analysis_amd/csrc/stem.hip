@@ -14,42 +14,49 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const TI* __restrict__ x,
                                                        const float* __restrict__ bias, T* __restrict__ y, int h, int wd, int c0,
                                                        int slabs, float* __restrict__ stats /*[N][slabs][C0][2]*/) {
   constexpr int EPU = Elem<T>::EPU;
-  extern __shared__ float sh[];  // w: [9][c0] | bias [c0] | red [2][lanes][c0]
-  float* wsh = sh;
-  float* bsh = sh + 9 * c0;
-  float* red = bsh + c0;
-  for (int i = threadIdx.x; i < 9 * c0; i += 256) wsh[(i % 9) * c0 + i / 9] = w[i];
-  for (int i = threadIdx.x; i < c0; i += 256) bsh[i] = bias ? bias[i] : 0.f;
-  __syncthreads();
+  extern __shared__ float red[];  // [2][lanes][c0]
   const int upp = c0 / EPU, lanes = 256 / upp;
   const int u = threadIdx.x % upp, pl = threadIdx.x / upp;
   const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
-  const int64_t hw = (int64_t)h * wd, per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  const int hw = h * wd, per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
   const TI* img = x + (size_t)n * hw;
+  // a thread owns one 16-byte channel unit for its whole life: its 9 x EPU weights and EPU biases live in registers
+  float wr[9][EPU], br[EPU];
+#pragma unroll
+  for (int e = 0; e < EPU; ++e) {
+    const int co = u * EPU + e;
+    br[e] = bias ? bias[co] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t][e] = w[co * 9 + t];
+  }
   float s1[EPU], s2[EPU];
 #pragma unroll
   for (int e = 0; e < EPU; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  if (pl < lanes)
-    for (int64_t p = r0 + pl; p < r1; p += lanes) {
-      const int py = (int)(p / wd), px = (int)(p - (int64_t)py * wd);
+  if (pl < lanes && r0 + pl < r1) {
+    int p = r0 + pl;
+    int py = p / wd, px = p - py * wd;  // one division per thread; the walk below is incremental
+    T* yrow = y + ((size_t)n * hw) * c0 + u * EPU;
+    for (; p < r1; p += lanes) {
       float xv[9];
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-        xv[t] = (yy >= 0 && yy < h && xx >= 0 && xx < wd) ? Elem<TI>::ld(img + (int64_t)yy * wd + xx) : 0.f;
+        xv[t] = ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)wd) ? Elem<TI>::ld(img + yy * wd + xx) : 0.f;
       }
       alignas(16) T out[EPU];
 #pragma unroll
       for (int e = 0; e < EPU; ++e) {
-        const int co = u * EPU + e;
-        float a = bsh[co];
+        float a = br[e];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) a += xv[t] * wsh[t * c0 + co];
+        for (int t = 0; t < 9; ++t) a += xv[t] * wr[t][e];
         s1[e] += a; s2[e] += a * a;
         out[e] = Elem<T>::cvt(a);
       }
-      *reinterpret_cast<u32x4*>(y + ((size_t)n * hw + p) * c0 + u * EPU) = *reinterpret_cast<const u32x4*>(out);
+      *reinterpret_cast<u32x4*>(yrow + (size_t)p * c0) = *reinterpret_cast<const u32x4*>(out);
+      px += lanes;
+      while (px >= wd) { px -= wd; ++py; }
     }
+  }
   if (stats != nullptr) {
     if (pl < lanes)
 #pragma unroll
@@ -67,36 +74,40 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const TI* __restrict__ x,
 // partial[blk][9][c0] = sum over the block's pixels of x[p + t] * dy[p][co]
 template <typename T, typename TI>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TI* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
-                                                         int nimg, int h, int wd, int c0) {
+                                                         int slabs, int h, int wd, int c0) {
   constexpr int EPU = Elem<T>::EPU;
   extern __shared__ float red[];  // [lanes][c0 + 1]
   const int upp = c0 / EPU, lanes = 256 / upp;
   const int u = threadIdx.x % upp, pl = threadIdx.x / upp;
-  const int64_t hw = (int64_t)h * wd, npix = (int64_t)nimg * hw;
-  const int64_t per = (npix + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = r0 + per < npix ? r0 + per : npix;
+  const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;  // block = one pixel slab of one image
+  const int hw = h * wd, per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
   float acc[9][EPU];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int e = 0; e < EPU; ++e) acc[t][e] = 0.f;
-  if (pl < lanes)
-    for (int64_t p = r0 + pl; p < r1; p += lanes) {
-      const int64_t n = p / hw, q = p - n * hw;
-      const int py = (int)(q / wd), px = (int)(q - (int64_t)py * wd);
-      const TI* img = x + n * hw;
+  if (pl < lanes && r0 + pl < r1) {
+    const TI* img = x + (size_t)n * hw;
+    const T* grow = dy + ((size_t)n * hw) * c0 + u * EPU;
+    int p = r0 + pl;
+    int py = p / wd, px = p - py * wd;  // one division per thread; the walk below is incremental
+    for (; p < r1; p += lanes) {
       alignas(16) T g[EPU];
-      *reinterpret_cast<u32x4*>(g) = *reinterpret_cast<const u32x4*>(dy + p * c0 + u * EPU);
+      *reinterpret_cast<u32x4*>(g) = *reinterpret_cast<const u32x4*>(grow + (size_t)p * c0);
       float gf[EPU];
 #pragma unroll
       for (int e = 0; e < EPU; ++e) gf[e] = Elem<T>::ld(g + e);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-        const float xv = (yy >= 0 && yy < h && xx >= 0 && xx < wd) ? Elem<TI>::ld(img + (int64_t)yy * wd + xx) : 0.f;
+        const float xv = ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)wd) ? Elem<TI>::ld(img + yy * wd + xx) : 0.f;
 #pragma unroll
         for (int e = 0; e < EPU; ++e) acc[t][e] += xv * gf[e];
       }
+      px += lanes;
+      while (px >= wd) { px -= wd; ++py; }
     }
+  }
   const int shs = c0 + 1;
   for (int t = 0; t < 9; ++t) {
     __syncthreads();
@@ -105,9 +116,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TI* __restrict__ 
       for (int e = 0; e < EPU; ++e) red[pl * shs + u * EPU + e] = acc[t][e];
     __syncthreads();
     if (threadIdx.x < c0) {
-      float s = 0.f;
-      for (int j = 0; j < lanes; ++j) s += red[j * shs + threadIdx.x];
-      part[((size_t)blockIdx.x * 9 + t) * c0 + threadIdx.x] = s;
+      float sm = 0.f;
+      for (int j = 0; j < lanes; ++j) sm += red[j * shs + threadIdx.x];
+      part[((size_t)blockIdx.x * 9 + t) * c0 + threadIdx.x] = sm;
     }
   }
 }
@@ -146,7 +157,8 @@ extern "C" int mia_stem_fwd(const void* x, int x_dtype, const float* w, const fl
   MIA_CHECK_ARG((dtype == MIA_BF16 || dtype == MIA_F32) && (x_dtype == MIA_BF16 || x_dtype == MIA_F32), "mia_stem_fwd: bad dtype");
   MIA_CHECK_ARG(stem_ok(dtype, c0), "mia_stem_fwd: c0=%d must be a multiple of the 16-byte unit and <= 256", c0);
   const int epu = dtype == MIA_BF16 ? 8 : 4, lanes = 256 / (c0 / epu);
-  const size_t shb = (size_t)(10 * c0 + 2 * lanes * c0) * 4;
+  MIA_CHECK_ARG((int64_t)h * wd < ((int64_t)1 << 31), "mia_stem_fwd: image too large");
+  const size_t shb = (size_t)(2 * lanes * c0) * 4;
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(n * STEM_SLABS);
 #define SF(T, TI) hipLaunchKernelGGL((stem_fwd_kernel<T, TI>), grid, dim3(256), shb, st, static_cast<const TI*>(x), w, bias, static_cast<T*>(y), h, wd, c0, STEM_SLABS, stat_partials)
@@ -165,11 +177,16 @@ extern "C" int mia_stem_wgrad(const void* x, int x_dtype, const void* dy, int dt
   MIA_CHECK_ARG((dtype == MIA_BF16 || dtype == MIA_F32) && (x_dtype == MIA_BF16 || x_dtype == MIA_F32), "mia_stem_wgrad: bad dtype");
   MIA_CHECK_ARG(stem_ok(dtype, c0), "mia_stem_wgrad: c0=%d must be a multiple of the 16-byte unit and <= 256", c0);
   const int epu = dtype == MIA_BF16 ? 8 : 4, lanes = 256 / (c0 / epu);
-  const int64_t npix = (int64_t)n * h * wd;
-  const int blocks = (int)(npix / 256 < 1 ? 1 : (npix / 256 > STEM_WBLOCKS ? STEM_WBLOCKS : npix / 256));
+  MIA_CHECK_ARG((int64_t)h * wd < ((int64_t)1 << 31) && n <= STEM_WBLOCKS, "mia_stem_wgrad: image or batch too large");
+  // one block = one pixel slab of one image (n * slabs <= STEM_WBLOCKS partial rows in the workspace)
+  const int64_t hw = (int64_t)h * wd;
+  int slabs = STEM_WBLOCKS / n;
+  if (slabs > (int)((hw + 255) / 256)) slabs = (int)((hw + 255) / 256);
+  if (slabs < 1) slabs = 1;
+  const int blocks = n * slabs;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t shb = (size_t)lanes * (c0 + 1) * 4;
-#define SW(T, TI) hipLaunchKernelGGL((stem_wgrad_kernel<T, TI>), dim3(blocks), dim3(256), shb, st, static_cast<const TI*>(x), static_cast<const T*>(dy), workspace, n, h, wd, c0)
+#define SW(T, TI) hipLaunchKernelGGL((stem_wgrad_kernel<T, TI>), dim3(blocks), dim3(256), shb, st, static_cast<const TI*>(x), static_cast<const T*>(dy), workspace, slabs, h, wd, c0)
   if (dtype == MIA_BF16 && x_dtype == MIA_F32) SW(bf16_t, float);
   else if (dtype == MIA_BF16) SW(bf16_t, bf16_t);
   else if (x_dtype == MIA_F32) SW(float, float);

@@ -182,7 +182,7 @@ def test_plain_block_fwd_bwd(norm, stride, c2, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("k1,c0", [(3, 16), (4, 64), (2, 12), (8, 32)])
+@pytest.mark.parametrize("k1,c0", [(3, 16), (4, 64), (2, 12), (8, 32), (3, 64), (3, 128), (2, 32), (4, 32)])
 def test_head(k1, c0, dtype):
     from mia_hip import ops
     dev = _dev()
