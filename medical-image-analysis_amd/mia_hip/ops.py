@@ -219,6 +219,24 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# Column sums that a producer kernel already had for free (conv epilogue statistics), keyed by the tensor they describe;
+# consumed by the next backward node that would otherwise re-read that tensor just to sum it.
+_COLSUM_HINT = {}
+
+
+def _hint_colsum(t: torch.Tensor, sums: torch.Tensor) -> None:
+    if len(_COLSUM_HINT) > 16:
+        _COLSUM_HINT.clear()
+    _COLSUM_HINT[t.data_ptr()] = (tuple(t.shape), t._version, sums)
+
+
+def _take_colsum(t: torch.Tensor) -> Optional[torch.Tensor]:
+    hit = _COLSUM_HINT.pop(t.data_ptr(), None)
+    if hit is not None and hit[0] == tuple(t.shape) and hit[1] == t._version:
+        return hit[2]
+    return None
+
+
 def _slabs_for(hw: int) -> int:
     return max(1, min(64, hw // 1024))
 
@@ -381,7 +399,14 @@ class PlainBlockFn(torch.autograd.Function):
                 dx1, dx2, _ = conv_mma(CONV_T3S2, dy, None, wb, npad, kpad, False, None, cin, (x1.shape[1], x1.shape[2]),
                                        out_split=split)
             else:
-                dx1, dx2, _ = conv_mma(CONV_G3S1, dy, None, wb, npad, kpad, True, None, cin, (ho, wo), out_split=split)
+                # decoder block behind a ConvTranspose2d: dx2 is that layer's output gradient and its per-channel sum is
+                # the transposed conv's bias gradient -- the epilogue statistics deliver it without another pass over dx2
+                want = x2 is not None and ctx.needs_input_grad[1]
+                dx1, dx2, st = conv_mma(CONV_G3S1, dy, None, wb, npad, kpad, True, None, cin, (ho, wo), want_stats=want,
+                                        out_split=split)
+                if want:
+                    sums = colsum(st.view(-1, 2 * cin)).view(cin, 2)[c1:, 0]
+                    _hint_colsum(dx2, sums)
         return dx1, dx2, dw, dbias, dgamma, dbeta, None, None, None, None
 
 
@@ -408,7 +433,9 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         dtype = _dt(x)
         n, h, w, cin = x.shape
         cout = weight.shape[1]
-        dbias = colsum(dout)
+        dbias = _take_colsum(dout)
+        if dbias is None:
+            dbias = colsum(dout)
         dw = conv_wgrad(WGRAD_2S2, dout, None, x, weight.shape, cin, cout)
         dx = None
         if ctx.needs_input_grad[0]:
