@@ -46,6 +46,11 @@ CONV_CASES = [
     (1, 12, 20, 40, 9, 13),
     (1, 128, 0, 80, 8, 8),
     (3, 5, 0, 7, 7, 5),
+    # branch-free fast path with ragged tiles, two sources, several output-channel blocks, odd sizes
+    (2, 64, 64, 64, 40, 72),
+    (1, 128, 0, 256, 24, 40),
+    (1, 256, 0, 128, 17, 33),
+    (2, 32, 0, 96, 30, 18),
 ]
 
 
