@@ -6,8 +6,8 @@
 // tile tail become an out-of-range offset that the hardware turns into a zero (loads) or a dropped write
 // (stores); channel chunks never straddle a source; all staging addresses are "thread constant +
 // compile-time immediate"; the epilogue writes LDS at immediate offsets.  Contract (checked on the host,
-// otherwise the generic kernel runs): c1 % KB == 0, c2 % KB == 0, o1 % EPU == 0, o1 % BN == 0 when the
-// output is split, 16-byte aligned pointers, per-image tensors < 2 GiB.
+// otherwise the generic kernel runs): c1 % KB == 0, c2 % KB == 0, o1 % EPU == 0, o2 % EPU == 0, 16-byte aligned
+// pointers, per-image tensors < 2 GiB.
 #include "conv_common.h"
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -273,26 +273,33 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
     gfloat* dst = (gfloat*)(a.stats + (tile * nout + n0 + tid) * 2);
     dst[0] = t1; dst[1] = t2;
   }
-  // coalesced 16-byte stores; the block's channel range lies in exactly one destination
+  // coalesced 16-byte stores.  A block's channel range normally lies in one destination; when the split point o1 is not
+  // a multiple of BN the straddling block issues every store twice, once per destination, each masked to its own lanes.
   constexpr int UPP = BN / EPU, PPI = 256 / UPP, O_IT = TH * 16 / PPI;
-  const bool second = n0 >= a.o1;
-  const int cn = second ? a.o2 : a.o1;
-  T* obase = second ? static_cast<T*>(a.out2) : static_cast<T*>(a.out1);
   const size_t opix = (size_t)a.Hout * a.Wout;
-  const rsrc_t rso = make_rsrc(obase + (size_t)img * opix * cn, (unsigned)(opix * cn * ES));
   const int cu = tid % UPP, pl0 = tid / UPP;
   const int y0 = pl0 >> 4, px = pl0 & 15;
-  const int nloc = (second ? n0 - a.o1 : n0) + cu * EPU;
-  const bool colok = (ox0 + px < wd) && (n0 + cu * EPU < nout);
   const int ox = TMODE ? 2 * (ox0 + px) + pw : ox0 + px;
+  const int ch = n0 + cu * EPU;
+  const bool pixok = (ox0 + px < wd) && (ch < nout);
+  auto store_to = [&](bool second) {
+    const int cn = second ? a.o2 : a.o1;
+    T* obase = second ? static_cast<T*>(a.out2) : static_cast<T*>(a.out1);
+    const rsrc_t rso = make_rsrc(obase + (size_t)img * opix * cn, (unsigned)(opix * cn * ES));
+    const int nloc = second ? ch - a.o1 : ch;
+    const bool colok = pixok && ((ch >= a.o1) == second);
 #pragma unroll
-  for (int i = 0; i < O_IT; ++i) {
-    const int y = y0 + i * (PPI / 16);
-    const int oy = TMODE ? 2 * (oy0 + y) + ph : oy0 + y;
-    const unsigned voff = (colok && oy0 + y < hd) ? (unsigned)((((size_t)oy * a.Wout + ox) * cn + nloc) * ES) : SENT;
-    const u32x4 d = *reinterpret_cast<const u32x4*>(ldsO + (pl0 + i * PPI) * OSTR + cu * EPU);
-    __builtin_amdgcn_raw_buffer_store_b128(d, rso, (int)voff, 0, 0);
-  }
+    for (int i = 0; i < O_IT; ++i) {
+      const int y = y0 + i * (PPI / 16);
+      const int oy = TMODE ? 2 * (oy0 + y) + ph : oy0 + y;
+      const unsigned voff = (colok && oy0 + y < hd) ? (unsigned)((((size_t)oy * a.Wout + ox) * cn + nloc) * ES) : SENT;
+      const u32x4 d = *reinterpret_cast<const u32x4*>(ldsO + (pl0 + i * PPI) * OSTR + cu * EPU);
+      __builtin_amdgcn_raw_buffer_store_b128(d, rso, (int)voff, 0, 0);
+    }
+  };
+  const bool first_part = n0 < a.o1, second_part = a.o2 > 0 && n0 + BN > a.o1;  // uniform
+  if (first_part) store_to(false);
+  if (second_part) store_to(true);
 }
 
 template <typename T, int MODE, int MT, int NT>
@@ -336,7 +343,6 @@ bool conv_mma_fast_eligible(int dtype, const ConvArgs& a, int nt) {
   const int epu = dtype == MIA_BF16 ? 8 : 4, kb = 4 * epu, es = dtype == MIA_BF16 ? 2 : 4, bn = 16 * nt;
   if (!a.vec_in || !a.vec_out) return false;
   if (a.c1 % kb != 0 || a.c2 % kb != 0) return false;
-  if (a.o2 != 0 && (a.o1 % bn != 0)) return false;
   const size_t lim = (size_t)1 << 31;
   const size_t ipix = (size_t)a.Hin * a.Win, opix = (size_t)a.Hout * a.Wout;
   if (ipix * (a.c1 > a.c2 ? a.c1 : a.c2) * es >= lim) return false;

@@ -201,12 +201,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = lane >> 4, i16 = lane & 15, qp = i16 >> 2, pp = i16 & 3;
   const int ch8 = tid & 7, p8 = tid >> 3;
-  const int nkb = a.kpad / 64;
+  // 64-channel input blocks are cut per SOURCE (ceil(c1/64) + ceil(c2/64) of them), so a block never straddles the
+  // two tensors of a concatenated input whatever c1 is; a source's last block may be partial (lanes beyond cs read
+  // zeros and do not store)
+  const int kb1 = (a.c1 + 63) / 64, nkb = kb1 + (a.c2 + 63) / 64;
   const int kblk = blockIdx.x % nkb, nblk = blockIdx.x / nkb;
-  const int n0 = nblk * 64, k0 = kblk * 64;
-  const bool second = k0 >= a.c1;
+  const bool second = kblk >= kb1;
+  const int cs = second ? a.c2 : a.c1, kloc = (second ? kblk - kb1 : kblk) * 64;
+  const int n0 = nblk * 64, k0 = (second ? a.c1 : 0) + kloc;
   const bf16_t* xsrc = static_cast<const bf16_t*>(second ? a.x2 : a.x1);
-  const int cs = second ? a.c2 : a.c1, kloc = second ? k0 - a.c1 : k0;
   const bf16_t* dy = static_cast<const bf16_t*>(a.dy);
   const size_t xpix = (size_t)a.Hx * a.Wx, ypix = (size_t)a.Hy * a.Wy;
 
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + c * 16 + 4 * grp + r, k = k0 + wave * 16 + i16;
-        slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+        if (kloc + wave * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
       }
 }
 
@@ -429,12 +432,15 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, i16 = lane & 15;
   const int ch4 = tid & 15, p16 = tid >> 4;
-  const int nkb = a.kpad / 64;
+  // 64-channel input blocks are cut per SOURCE (ceil(c1/64) + ceil(c2/64) of them), so a block never straddles the
+  // two tensors of a concatenated input whatever c1 is; a source's last block may be partial (lanes beyond cs read
+  // zeros and do not store)
+  const int kb1 = (a.c1 + 63) / 64, nkb = kb1 + (a.c2 + 63) / 64;
   const int kblk = blockIdx.x % nkb, nblk = blockIdx.x / nkb;
-  const int n0 = nblk * 64, k0 = kblk * 64;
-  const bool second = k0 >= a.c1;
+  const bool second = kblk >= kb1;
+  const int cs = second ? a.c2 : a.c1, kloc = (second ? kblk - kb1 : kblk) * 64;
+  const int n0 = nblk * 64, k0 = (second ? a.c1 : 0) + kloc;
   const float* xsrc = static_cast<const float*>(second ? a.x2 : a.x1);
-  const int cs = second ? a.c2 : a.c1, kloc = second ? k0 - a.c1 : k0;
   const float* dy = static_cast<const float*>(a.dy);
   const size_t xpix = (size_t)a.Hx * a.Wx, ypix = (size_t)a.Hy * a.Wy;
 
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + c * 16 + 4 * q + r, k = k0 + wave * 16 + i16;
-        slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+        if (kloc + wave * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
       }
 }
 
@@ -577,23 +583,24 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   dim3 grid((npad / 64) * (kpad / 64), ksplit);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t lim = (size_t)1 << 31;
-  // channel tails are zero-filled through out-of-range offsets; a two-source input must split on a 64-channel boundary
-  const bool chan_ok = a.vec_x && a.vec_dy && (c2 == 0 || c1 % 64 == 0);
+  // fast paths: channel tails are zero-filled through out-of-range offsets and input-channel blocks are cut per source
+  const bool chan_ok = a.vec_x && a.vec_dy;
+  const dim3 fgrid((npad / 64) * (ceil_div(c1, 64) + ceil_div(c2, 64)), ksplit);
   const bool fast = dtype == MIA_BF16 && chan_ok && (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 2 < lim &&
                     (size_t)hy * wy * cdy * 2 < lim;
   const int th = wgrad_tile_h(mode, dtype, hy, fast);
   a.tiles_y = ceil_div(hy, th);
   a.tiles_x = ceil_div(wy, 16);
   if (fast) {
-    if (mode == MODE_W3S1 && th == 16) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 16>), grid, dim3(256), 0, st, a);
-    else if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 8>), grid, dim3(256), 0, st, a);
-    else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S2, 4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W2S2, 4>), grid, dim3(256), 0, st, a);
+    if (mode == MODE_W3S1 && th == 16) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 16>), fgrid, dim3(256), 0, st, a);
+    else if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 8>), fgrid, dim3(256), 0, st, a);
+    else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S2, 4>), fgrid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W2S2, 4>), fgrid, dim3(256), 0, st, a);
   } else if (dtype == MIA_F32 && chan_ok && (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 4 < lim &&
              (size_t)hy * wy * cdy * 4 < lim) {
-    if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W3S1>, grid, dim3(256), 0, st, a);
-    else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W3S2>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W2S2>, grid, dim3(256), 0, st, a);
+    if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W3S1>, fgrid, dim3(256), 0, st, a);
+    else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W3S2>, fgrid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W2S2>, fgrid, dim3(256), 0, st, a);
   } else if (dtype == MIA_BF16) {
     if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W3S1>, grid, dim3(256), 0, st, a);
     else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W3S2>, grid, dim3(256), 0, st, a);

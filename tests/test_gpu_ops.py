@@ -51,6 +51,10 @@ CONV_CASES = [
     (1, 128, 0, 256, 24, 40),
     (1, 256, 0, 128, 17, 33),
     (2, 32, 0, 96, 30, 18),
+    # concatenated inputs / split gradients whose boundary is not a multiple of the 64-channel block
+    (1, 96, 96, 96, 24, 40),
+    (2, 40, 24, 64, 20, 36),
+    (1, 32, 96, 128, 16, 48),
 ]
 
 
