@@ -192,16 +192,16 @@ extern "C" int mia_norm_finalize_sync(const float* gathered, int world, int n, i
 // ---------------------------------------------------------------- vectorised per-channel reductions (C % 64 == 0)
 // block = (64 channels = UPB 16-byte units) x (256/UPB pixel lanes); grid = (n*slabs, C/64).  Each thread streams
 // 16-byte units of its slab, keeps EPU x 2 running sums in registers, lanes are combined through LDS.
-template <typename T, bool BWD>
+template <typename T, bool BWD, int CG>
 __global__ __launch_bounds__(256) void colreduce_vec_kernel(const T* __restrict__ a0, const T* __restrict__ a1,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ xa, const float* __restrict__ xb,
                                                             int64_t hw, int c, int slabs, float slope, float* __restrict__ part) {
-  constexpr int EPU = Elem<T>::EPU, UPB = 64 / EPU, LANES = 256 / UPB;
-  __shared__ float sh[2][LANES][64 + 1];
+  constexpr int EPU = Elem<T>::EPU, UPB = CG / EPU, LANES = 256 / UPB;  // CG = channels per block (64, or 32 when c % 64 != 0)
+  __shared__ float sh[2][LANES][CG + 1];
   const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
   const int u = threadIdx.x % UPB, pl = threadIdx.x / UPB;
-  const int ch0 = blockIdx.y * 64 + u * EPU;
+  const int ch0 = blockIdx.y * CG + u * EPU;
   const int64_t per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
   const size_t base = (size_t)n * hw * c + ch0;
   float s1[EPU], s2[EPU], sc[EPU], sf[EPU], ka[EPU], kb[EPU];
@@ -244,12 +244,12 @@ __global__ __launch_bounds__(256) void colreduce_vec_kernel(const T* __restrict_
 #pragma unroll
   for (int e = 0; e < EPU; ++e) { sh[0][pl][u * EPU + e] = s1[e]; sh[1][pl][u * EPU + e] = s2[e]; }
   __syncthreads();
-  if (threadIdx.x < 128) {
-    const int k = threadIdx.x >> 6, chl = threadIdx.x & 63;
+  if (threadIdx.x < 2 * CG) {
+    const int k = threadIdx.x / CG, chl = threadIdx.x % CG;
     float t = 0.f;
 #pragma unroll 8
     for (int j = 0; j < LANES; ++j) t += sh[k][j][chl];
-    part[(((size_t)n * slabs + s) * c + blockIdx.y * 64 + chl) * 2 + k] = t;
+    part[(((size_t)n * slabs + s) * c + blockIdx.y * CG + chl) * 2 + k] = t;
   }
 }
 
@@ -280,14 +280,25 @@ __global__ void norm_stats_kernel(const T* __restrict__ y, int64_t hw, int c, in
   }
 }
 
+// launch helper: 64-channel blocks, or 32-channel blocks when c is only a multiple of 32 (e.g. 96-channel layers)
+#define CRV(T, BWDF, A0, A1, SC, SF, XA, XB, SLOPE)                                                                       \
+  do {                                                                                                                    \
+    if (c % 64 == 0)                                                                                                      \
+      hipLaunchKernelGGL((colreduce_vec_kernel<T, BWDF, 64>), dim3(n * slabs, c / 64), dim3(256), 0, st, A0, A1, SC, SF, XA, \
+                         XB, hw, c, slabs, SLOPE, partials);                                                              \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((colreduce_vec_kernel<T, BWDF, 32>), dim3(n * slabs, c / 32), dim3(256), 0, st, A0, A1, SC, SF, XA, \
+                         XB, hw, c, slabs, SLOPE, partials);                                                              \
+  } while (0)
+
 extern "C" int mia_norm_stats(const void* y, int dtype, int n, int64_t hw, int c, int slabs, float* partials, void* stream) {
   MIA_CHECK_ARG(y && partials && n > 0 && hw > 0 && c > 0 && slabs > 0, "mia_norm_stats: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (c % 64 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (dtype == MIA_BF16 || dtype == MIA_F32)) {
+  if (c % 32 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (dtype == MIA_BF16 || dtype == MIA_F32)) {
     if (dtype == MIA_BF16)
-      hipLaunchKernelGGL((colreduce_vec_kernel<bf16_t, false>), dim3(n * slabs, c / 64), dim3(256), 0, st, static_cast<const bf16_t*>(y), static_cast<const bf16_t*>(nullptr), nullptr, nullptr, nullptr, nullptr, hw, c, slabs, 0.f, partials);
+      CRV(bf16_t, false, static_cast<const bf16_t*>(y), static_cast<const bf16_t*>(nullptr), nullptr, nullptr, nullptr, nullptr, 0.f);
     else
-      hipLaunchKernelGGL((colreduce_vec_kernel<float, false>), dim3(n * slabs, c / 64), dim3(256), 0, st, static_cast<const float*>(y), static_cast<const float*>(nullptr), nullptr, nullptr, nullptr, nullptr, hw, c, slabs, 0.f, partials);
+      CRV(float, false, static_cast<const float*>(y), static_cast<const float*>(nullptr), nullptr, nullptr, nullptr, nullptr, 0.f);
     MIA_LAUNCH_CHECK();
     return MIA_OK;
   }
@@ -614,11 +625,11 @@ static void bwd_reduce_launch(const void* dz, const void* y, int dtype, const fl
 #define RD(T) hipLaunchKernelGGL(norm_act_bwd_reduce_kernel<T>, dim3(n * slabs, ceil_div(c, 256)), dim3(256), 512 * sizeof(float), st,   \
                                  static_cast<const T*>(dz), static_cast<const T*>(y), scale, shift, xa, xb, hw, c, slabs, \
                                  slope, partials)
-  if (vec && c % 64 == 0) {
+  if (vec && c % 32 == 0) {
     if (dtype == MIA_BF16)
-      hipLaunchKernelGGL((colreduce_vec_kernel<bf16_t, true>), dim3(n * slabs, c / 64), dim3(256), 0, st, static_cast<const bf16_t*>(dz), static_cast<const bf16_t*>(y), scale, shift, xa, xb, hw, c, slabs, slope, partials);
+      CRV(bf16_t, true, static_cast<const bf16_t*>(dz), static_cast<const bf16_t*>(y), scale, shift, xa, xb, slope);
     else
-      hipLaunchKernelGGL((colreduce_vec_kernel<float, true>), dim3(n * slabs, c / 64), dim3(256), 0, st, static_cast<const float*>(dz), static_cast<const float*>(y), scale, shift, xa, xb, hw, c, slabs, slope, partials);
+      CRV(float, true, static_cast<const float*>(dz), static_cast<const float*>(y), scale, shift, xa, xb, slope);
   } else if (dtype == MIA_BF16) RD(bf16_t); else RD(float);
 #undef RD
   hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3(n, ceil_div(c, 16)), dim3(256), 0, st, partials, slabs, c, c1, c2);

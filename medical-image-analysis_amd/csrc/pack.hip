@@ -33,20 +33,65 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict_
   }
 }
 
+// Tiled variant: a block stages a [TA][TB][taps] brick of the source through LDS -- its rows are contiguous runs of
+// TB * taps floats -- and writes the taps planes with k fastest (64 k per (tap, n) row = 128 bytes in bf16).  The k
+// dimension always gets the 64-wide side of the brick: (TA, TB) = (16, 64) when k indexes D1, (64, 16) when k indexes D0.
+template <typename T, int TA, int TB>
+__global__ __launch_bounds__(256) void pack_weight_tiled_kernel(const float* __restrict__ src, T* __restrict__ dst, int d0, int d1,
+                                                                int taps, int npad, int kpad) {
+  constexpr bool N_FROM_D0 = (TB == 64);  // k = D1 index
+  extern __shared__ float tile[];        // [TA][TB * taps + 1]
+  const int pitch = TB * taps + 1;
+  const int a0 = blockIdx.y * TA, b0 = blockIdx.x * TB;
+  const int run = TB * taps;
+  for (int i = threadIdx.x; i < TA * run; i += 256) {
+    const int a = i / run, r = i - a * run;  // r = b * taps + t
+    const int b = r / taps;
+    float v = 0.f;
+    if (a0 + a < d0 && b0 + b < d1) v = src[((size_t)(a0 + a) * d1 + b0) * taps + r];
+    tile[a * pitch + r] = v;
+  }
+  __syncthreads();
+  constexpr int NK = 64, NN = 16;  // brick extent along k and n
+  for (int i = threadIdx.x; i < taps * NN * NK; i += 256) {
+    const int k = i % NK, n = (i / NK) % NN, t = i / (NK * NN);
+    const int a = N_FROM_D0 ? n : k, b = N_FROM_D0 ? k : n;
+    const int gn = (N_FROM_D0 ? a0 : b0) + n, gk = (N_FROM_D0 ? b0 : a0) + k;
+    if (gn < npad && gk < kpad) dst[((size_t)t * npad + gn) * kpad + gk] = Elem<T>::cvt(tile[a * pitch + b * taps + t]);
+  }
+}
+
 extern "C" int mia_pack_weight(const float* src, void* dst, int dtype, int d0, int d1, int taps, int npad, int kpad,
                                int n_from_d0, void* stream) {
   MIA_CHECK_ARG(src && dst && d0 > 0 && d1 > 0 && taps > 0, "mia_pack_weight: bad arguments");
   MIA_CHECK_ARG(npad >= (n_from_d0 ? d0 : d1) && kpad >= (n_from_d0 ? d1 : d0), "mia_pack_weight: padding too small");
+  if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_pack_weight: bad dtype"); return MIA_EARG; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (taps <= 16 && (int64_t)npad * kpad >= 64 * 64) {
+    // bricks cover the PADDED destination so the zero padding is written too
+    const int pa = n_from_d0 ? npad : kpad, pb = n_from_d0 ? kpad : npad;  // padded extents along D0 / D1
+    if (n_from_d0) {
+      const dim3 grid(ceil_div(pb, 64), ceil_div(pa, 16));
+      const size_t shb = (size_t)16 * (64 * taps + 1) * 4;
+      if (dtype == MIA_BF16) hipLaunchKernelGGL((pack_weight_tiled_kernel<bf16_t, 16, 64>), grid, dim3(256), shb, st, src, static_cast<bf16_t*>(dst), d0, d1, taps, npad, kpad);
+      else hipLaunchKernelGGL((pack_weight_tiled_kernel<float, 16, 64>), grid, dim3(256), shb, st, src, static_cast<float*>(dst), d0, d1, taps, npad, kpad);
+    } else {
+      const dim3 grid(ceil_div(pb, 16), ceil_div(pa, 64));
+      const size_t shb = (size_t)64 * (16 * taps + 1) * 4;
+      if (dtype == MIA_BF16) hipLaunchKernelGGL((pack_weight_tiled_kernel<bf16_t, 64, 16>), grid, dim3(256), shb, st, src, static_cast<bf16_t*>(dst), d0, d1, taps, npad, kpad);
+      else hipLaunchKernelGGL((pack_weight_tiled_kernel<float, 64, 16>), grid, dim3(256), shb, st, src, static_cast<float*>(dst), d0, d1, taps, npad, kpad);
+    }
+    MIA_LAUNCH_CHECK();
+    return MIA_OK;
+  }
   const int64_t total = (int64_t)taps * npad * kpad;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == MIA_BF16)
     hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, src, static_cast<bf16_t*>(dst), d0, d1,
                        taps, npad, kpad, n_from_d0);
-  else if (dtype == MIA_F32)
+  else
     hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, st, src, static_cast<float*>(dst), d0, d1, taps,
                        npad, kpad, n_from_d0);
-  else { mia_set_error("mia_pack_weight: bad dtype"); return MIA_EARG; }
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
