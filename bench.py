@@ -205,7 +205,7 @@ def main():
             traffic = 2.0 * 588160.0 * 1024 + 1064960.0 * 1024 if (args.config == "cfg3" and batch == 32 and dt == "bf16") else None
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS[dt], "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_MFMA_TFLOPS[dt], 4), "traffic": traffic,
-                    "kernel": f"conv_mma_kernel<{dt},G3S1,MT4,NT4> {c0}->{c0} 3x3 @{size}x{size} x{batch} (encoder.levels.0.1)",
+                    "kernel": f"conv_mma_fast_kernel<{dt},G3S1,MT4,NT4> {c0}->{c0} 3x3 @{size}x{size} x{batch} (encoder.levels.0.1)",
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(kt), "flops_per_launch": flops,
                     "algorithmic_bytes_per_launch": abytes,
                     "hbm_frac_of_block_bytes": round(abytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
