@@ -34,6 +34,13 @@ const char* mia_last_error(void);
  * (src/models/unet/blocks.py:83-90, unet.py:142).  n_from_d0: n indexes D0 (else D1). */
 int mia_pack_weight(const float* src, void* dst, int dtype, int d0, int d1, int taps, int npad, int kpad,
                     int n_from_d0, void* stream);
+/* The same for every weight of a model in ONE launch (the optimizer rewrites all parameters each step).  descs_dev: device
+ * array of `count` records of mia_pack_desc_bytes() bytes each:
+ *   { const float* src; void* dst; int d0, d1, taps, npad, kpad, n_from_d0; int brick_begin, bricks_x; }
+ * a brick is 16 x 64 (n_from_d0) or 64 x 16 (D0 x D1) source elements; brick_begin = running brick count, bricks_x =
+ * bricks along D1; total_bricks = sum over records; bricks cover the PADDED extents. */
+int mia_pack_desc_bytes(void);
+int mia_pack_weight_batch(const void* descs_dev, int count, int total_bricks, int max_taps, int dtype, void* stream);
 /* generic strided (n, c, p) copy with dtype conversion: NCHW <-> NHWC, fp32 <-> bf16
  * (replaces .to(dtype)/.contiguous() at al_trainer.py:1366-1368). */
 int mia_relayout(const void* src, int src_dtype, void* dst, int dst_dtype, int n, int c, int64_t hw,

@@ -531,18 +531,55 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
 // layout 0: conv   grad[n][k][kh][kw]  (OIHW, n = Cout, k = Cin)
 // layout 1: convT  grad[n][k][kh][kw] where the parameter is [Cin_T][Cout_T][2][2] and the GEMM ran with
 //           n := Cin_T (coarse-side channels, "dy" operand) and k := Cout_T (fine-side channels, "x" operand)
-__global__ void wgrad_reduce_kernel(const float* slabs, int ksplit, int taps, int npad, int kpad, float* grad, int nn,
-                                    int kk, int accumulate) {
-  const int64_t total = (int64_t)nn * kk * taps;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int t = (int)(i % taps);
-    const int k = (int)((i / taps) % kk);
-    const int n = (int)(i / ((int64_t)taps * kk));
-    const size_t off = ((size_t)t * npad + n) * kpad + k;
-    const size_t sstride = (size_t)taps * npad * kpad;
-    float s = 0.f;
-    for (int z = 0; z < ksplit; ++z) s += slabs[z * sstride + off];
-    grad[i] = accumulate ? grad[i] + s : s;
+// Small gradients (few (n, k) pairs, many split-K slabs): 32 elements x 8 slab lanes per block -- every thread sums an
+// eighth of the slabs for one element (elements ordered k-fastest so the slab reads coalesce), LDS combines the lanes in
+// a fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __restrict__ slabs, int ksplit, int taps, int npad,
+                                                                 int kpad, float* __restrict__ grad, int nn, int kk, int accumulate) {
+  __shared__ float sh[8][33];
+  const int e = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int total = nn * kk * taps;
+  const int i = blockIdx.x * 32 + e;  // (t, n, k), k fastest
+  const size_t sstride = (size_t)taps * npad * kpad;
+  float s = 0.f;
+  int t = 0, n = 0, k = 0;
+  if (i < total) {
+    k = i % kk; n = (i / kk) % nn; t = i / (kk * nn);
+    const float* src = slabs + ((size_t)t * npad + n) * kpad + k;
+    for (int z = zl; z < ksplit; z += 8) s += src[z * sstride];
+  }
+  sh[zl][e] = s;
+  __syncthreads();
+  if (zl == 0 && i < total) {
+    float r = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r += sh[j][e];
+    float* dst = grad + ((size_t)n * kk + k) * taps + t;
+    *dst = accumulate ? *dst + r : r;
+  }
+}
+
+// One thread per (n, k): consecutive lanes walk consecutive k, so every slab read is a coalesced row segment; the taps
+// of one (n, k) are adjacent in the parameter layout [n][k][taps], so a wave's stores tile a contiguous span.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit, int taps, int npad,
+                                                           int kpad, float* __restrict__ grad, int nn, int kk, int accumulate) {
+  const int total = nn * kk;
+  const size_t plane = (size_t)npad * kpad, sstride = (size_t)taps * plane;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int n = i / kk, k = i - n * kk;
+    const float* src = slabs + (size_t)n * kpad + k;
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] = 0.f;
+    for (int z = 0; z < ksplit; ++z) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if (t < taps) s[t] += src[z * sstride + t * plane];
+    }
+    float* dst = grad + (size_t)i * taps;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      if (t < taps) dst[t] = accumulate ? dst[t] + s[t] : s[t];
   }
 }
 
@@ -618,10 +655,17 @@ extern "C" int mia_wgrad_reduce(const float* slabs, int ksplit, int taps, int np
                                 int kk, int accumulate, void* stream) {
   MIA_CHECK_ARG(slabs && grad && ksplit >= 1 && taps >= 1 && nn >= 1 && kk >= 1 && nn <= npad && kk <= kpad,
                 "mia_wgrad_reduce: bad arguments");
-  const int64_t total = (int64_t)nn * kk * taps;
-  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs, ksplit,
-                     taps, npad, kpad, grad, nn, kk, accumulate);
+  MIA_CHECK_ARG(taps <= 9 && (int64_t)nn * kk < ((int64_t)1 << 31), "mia_wgrad_reduce: taps > 9 or gradient too large");
+  const int64_t total = (int64_t)nn * kk;
+  if (total < 32768 && total * taps < ((int64_t)1 << 31)) {
+    const int blocks = (int)((total * taps + 31) / 32);
+    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs, ksplit,
+                       taps, npad, kpad, grad, nn, kk, accumulate);
+  } else {
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs, ksplit,
+                       taps, npad, kpad, grad, nn, kk, accumulate);
+  }
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

@@ -96,6 +96,62 @@ extern "C" int mia_pack_weight(const float* src, void* dst, int dtype, int d0, i
   return MIA_OK;
 }
 
+// Batched form: ONE launch re-packs every weight of a model (the optimizer rewrites all of them each step, and a
+// per-tensor launch costs more than the copy for most layers).  `descs` lives in device memory; a block finds its
+// descriptor from the running brick counts, then does the same LDS-tiled brick copy as above with run-time orientation.
+struct MiaPackDesc {
+  const float* src; void* dst;
+  int d0, d1, taps, npad, kpad, n_from_d0;
+  int brick_begin, bricks_x;  // first brick of this tensor in the launch; bricks along D1
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const MiaPackDesc* __restrict__ descs, int count) {
+  extern __shared__ float tile[];
+  __shared__ int which;
+  if (threadIdx.x == 0) {
+    int lo = 0;
+    for (int i = 1; i < count; ++i)
+      if ((int)blockIdx.x >= descs[i].brick_begin) lo = i;
+    which = lo;
+  }
+  __syncthreads();
+  const MiaPackDesc d = descs[which];
+  const int brick = blockIdx.x - d.brick_begin;
+  const int TA = d.n_from_d0 ? 16 : 64, TB = d.n_from_d0 ? 64 : 16;
+  const int taps = d.taps, pitch = TB * taps + 1, run = TB * taps;
+  const int a0 = (brick / d.bricks_x) * TA, b0 = (brick % d.bricks_x) * TB;
+  for (int i = threadIdx.x; i < TA * run; i += 256) {
+    const int a = i / run, r = i - a * run;
+    const int b = r / taps;
+    float v = 0.f;
+    if (a0 + a < d.d0 && b0 + b < d.d1) v = d.src[((size_t)(a0 + a) * d.d1 + b0) * taps + r];
+    tile[a * pitch + r] = v;
+  }
+  __syncthreads();
+  T* dst = static_cast<T*>(d.dst);
+  for (int i = threadIdx.x; i < taps * 16 * 64; i += 256) {
+    const int k = i % 64, n = (i / 64) % 16, t = i / (64 * 16);
+    const int a = d.n_from_d0 ? n : k, b = d.n_from_d0 ? k : n;
+    const int gn = (d.n_from_d0 ? a0 : b0) + n, gk = (d.n_from_d0 ? b0 : a0) + k;
+    if (gn < d.npad && gk < d.kpad) dst[((size_t)t * d.npad + gn) * d.kpad + gk] = Elem<T>::cvt(tile[a * pitch + b * taps + t]);
+  }
+}
+
+extern "C" int mia_pack_desc_bytes(void) { return (int)sizeof(MiaPackDesc); }
+
+extern "C" int mia_pack_weight_batch(const void* descs_dev, int count, int total_bricks, int max_taps, int dtype, void* stream) {
+  MIA_CHECK_ARG(descs_dev && count > 0 && total_bricks > 0 && max_taps > 0 && max_taps <= 16, "mia_pack_weight_batch: bad arguments");
+  if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_pack_weight_batch: bad dtype"); return MIA_EARG; }
+  const size_t shb = (size_t)64 * (16 * max_taps + 1) * 4;  // the larger of the two brick orientations
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const MiaPackDesc* d = static_cast<const MiaPackDesc*>(descs_dev);
+  if (dtype == MIA_BF16) hipLaunchKernelGGL(pack_weight_batch_kernel<bf16_t>, dim3(total_bricks), dim3(256), shb, st, d, count);
+  else hipLaunchKernelGGL(pack_weight_batch_kernel<float>, dim3(total_bricks), dim3(256), shb, st, d, count);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
 // ---- layout / dtype conversion.  src element (n, c, p) lives at n*sn + c*sc + p*sp (element strides), dst likewise.
 template <typename TS, typename TD>
 __global__ void relayout_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int n, int c, int64_t hw, int64_t ssn,

@@ -78,13 +78,64 @@ class PackCache:
         taps = w.shape[2] * w.shape[3]
         nn, kk = (d0, d1) if n_from_d0 else (d1, d0)
         npad, kpad = _pad(nn, 64), _pad(kk, _kb(dtype))
-        buf = torch.empty((taps, npad, kpad), device=w.device, dtype=torch.bfloat16 if dtype == BF16 else torch.float32)
+        buf = hit[1] if hit is not None else \
+            torch.empty((taps, npad, kpad), device=w.device, dtype=torch.bfloat16 if dtype == BF16 else torch.float32)
         wc = w.detach()
         if not wc.is_contiguous():
             wc = wc.contiguous()
         call("mia_pack_weight", _p(wc), _p(buf), dtype, d0, d1, taps, npad, kpad, int(n_from_d0), _stream())
         self._store[key] = (ver, buf, npad, kpad)
         return buf, npad, kpad
+
+
+class PackPlan:
+    """All packed copies a model's step needs, refreshed by ONE `mia_pack_weight_batch` launch after the optimizer has
+    rewritten the parameters (instead of one launch per tensor and orientation on first use).  Built from the packs the
+    first steps left in the parameters' PackCaches; the results are planted into each parameter's PackCache with the current version key, so a
+    parameter changed behind the plan's back (load_state_dict, in-place edits) simply misses and re-packs itself."""
+
+    def __init__(self, params, dtype: int):
+        import ctypes as C
+        ents = []
+        for w in params:
+            c = _caches.get(id(w))
+            if c is None or c[0]() is not w or not w.is_cuda or not w.is_contiguous() or w.ndim != 4:
+                continue
+            for (dt, n_from_d0) in c[1]._store:
+                if dt == dtype:
+                    ents.append(((id(w), dt, n_from_d0), (w, c[1])))
+        if not ents:
+            raise MiaError("PackPlan: no packed weights were requested yet (run a step first)")
+
+        class Desc(C.Structure):
+            _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("d0", C.c_int), ("d1", C.c_int), ("taps", C.c_int),
+                        ("npad", C.c_int), ("kpad", C.c_int), ("n_from_d0", C.c_int), ("brick_begin", C.c_int), ("bricks_x", C.c_int)]
+
+        assert C.sizeof(Desc) == lib().mia_pack_desc_bytes()
+        arr = (Desc * len(ents))()
+        self.entries, self.dtype, bricks, self.max_taps = [], dtype, 0, 1
+        for i, ((_, _, n_from_d0), (w, pc)) in enumerate(ents):
+            key = (dtype, n_from_d0)
+            _, buf, npad, kpad = pc._store[key]
+            d0, d1, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+            pa, pb = (npad, kpad) if n_from_d0 else (kpad, npad)  # padded extents along D0 / D1
+            ta, tb = (16, 64) if n_from_d0 else (64, 16)
+            bx, by = -(-pb // tb), -(-pa // ta)
+            arr[i] = Desc(w.data_ptr(), buf.data_ptr(), d0, d1, taps, npad, kpad, int(n_from_d0), bricks, bx)
+            bricks += bx * by
+            self.max_taps = max(self.max_taps, taps)
+            self.entries.append((w, pc, key, buf, npad, kpad, w.data_ptr()))
+        self.total_bricks = bricks
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.descs = host.to(self.entries[0][0].device)
+
+    def valid(self) -> bool:
+        return all(w.data_ptr() == ptr for w, _, _, _, _, _, ptr in self.entries)
+
+    def repack(self) -> None:
+        call("mia_pack_weight_batch", _p(self.descs), len(self.entries), self.total_bricks, self.max_taps, self.dtype, _stream())
+        for w, pc, key, buf, npad, kpad, _ in self.entries:
+            pc._store[key] = ((w._version, w.data_ptr(), PARAM_EPOCH), buf, npad, kpad)
 
 
 _caches = {}

@@ -63,6 +63,7 @@ class FlatOptimizer:
         self.param_groups = [dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps, momentum=momentum)]
         self.step_count = 0
         self.last_norm: Optional[torch.Tensor] = None
+        self._pack_plan = None
         # bucket table for data parallelism
         nb = max(1, bucket_bytes // 4)
         self.buckets: List[tuple] = []
@@ -101,6 +102,22 @@ class FlatOptimizer:
         ops.optim_step(self.kind, self.flat_param, self.flat_grad, self.m, self.v, float(g["lr"]), b1, b2, g["eps"],
                        float(g["weight_decay"]), self.step_count, clip, grad_scale)
         ops.bump_param_epoch()  # the kernel bypasses tensor version counters: packed weights must be rebuilt
+        self._repack()
+
+    def _repack(self):
+        """Rebuild every packed weight copy in one launch (ops.PackPlan) once the first steps have shown which are used."""
+        if self.step_count < 2 or not self.flat_param.is_cuda:
+            return
+        if self._pack_plan is None or not self._pack_plan.valid():
+            dts = set()
+            for p in self.params:
+                c = ops._caches.get(id(p))
+                if c is not None and c[0]() is p:
+                    dts.update(dt for dt, _ in c[1]._store)
+            if len(dts) != 1:  # nothing packed yet, or mixed compute dtypes: keep the per-tensor path
+                return
+            self._pack_plan = ops.PackPlan(self.params, dts.pop())
+        self._pack_plan.repack()
 
     def state_dict(self) -> Dict[str, object]:
         return {"step": self.step_count, "m": self.m, "v": self.v, "param_groups": self.param_groups, "name": self.name}
