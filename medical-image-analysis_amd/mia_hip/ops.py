@@ -240,8 +240,9 @@ def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: tor
 WGRAD_TARGET_BLOCKS = int(__import__('os').environ.get('MIA_WGRAD_BLOCKS', '256'))
 
 
-def conv_wgrad(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], dy: torch.Tensor, grad_shape, nn: int, kk: int) -> torch.Tensor:
-    """Weight gradient in the parameter's native layout (fp32)."""
+def conv_wgrad(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], dy: torch.Tensor, grad_shape, nn: int, kk: int,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weight gradient in the parameter's native layout (fp32), written into `out` when given."""
     n, hx, wx, c1 = x1.shape
     c2 = 0 if x2 is None else x2.shape[3]
     _, hy, wy, cdy = dy.shape
@@ -256,7 +257,7 @@ def conv_wgrad(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], dy: torc
     slabs = torch.empty((ksplit, taps, npad, kpad), device=x1.device, dtype=torch.float32)
     call("mia_conv_wgrad", mode, dtype, _p(x1), c1, _p(x2), c2, _p(dy), cdy, _p(slabs), ksplit, npad, kpad, n, hx, wx, hy,
          wy, _stream())
-    grad = torch.empty(grad_shape, device=x1.device, dtype=torch.float32)
+    grad = out if out is not None else torch.empty(grad_shape, device=x1.device, dtype=torch.float32)
     call("mia_wgrad_reduce", _p(slabs), ksplit, taps, npad, kpad, _p(grad), nn, kk, 0, _stream())
     return grad
 
@@ -268,6 +269,34 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty(c, device=x.device, dtype=torch.float32)
     call("mia_colsum", _p(x), _dt(x), _c_i64(p), c, _p(ws), _p(out), 0, _stream())
     return out
+
+
+# Gradient destinations: a flat optimizer registers, per parameter, the slice of its flat gradient buffer; backward nodes
+# then let their kernels write the parameter gradient THERE and return that view, which autograd adopts as .grad without a
+# copy or an accumulation kernel (82 tiny `add` launches per step otherwise).  Unregistered parameters get fresh tensors.
+_GRAD_DEST = {}
+
+
+def register_grad_dest(param: torch.Tensor, flat: torch.Tensor, offset: int) -> None:
+    _GRAD_DEST[id(param)] = (__import__("weakref").ref(param), flat, offset, param.numel(), tuple(param.shape))
+
+
+def unregister_grad_dest(param: torch.Tensor) -> None:
+    _GRAD_DEST.pop(id(param), None)
+
+
+def grad_dest(param: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """A FRESH view of the registered slice (autograd only adopts a gradient nobody else references)."""
+    if param is None:
+        return None
+    hit = _GRAD_DEST.get(id(param))
+    if hit is None:
+        return None
+    if hit[0]() is not param:
+        _GRAD_DEST.pop(id(param), None)
+        return None
+    _, flat, off, n, shape = hit
+    return flat[off:off + n].view(shape)
 
 
 # Column sums that a producer kernel already had for free (conv epilogue statistics), keyed by the tensor they describe;
@@ -379,6 +408,7 @@ class PlainBlockFn(torch.autograd.Function):
              _c_float(slope), _stream())
         ctx.save_for_backward(x1, x2, y, coefs, weight, gamma)
         ctx.stride, ctx.mode, ctx.fixed, ctx.stem, ctx.slope = stride, cfg.mode, fixed, False, slope
+        ctx.small = (bias, beta)  # identities only (gradient destinations); values are not needed in backward
         return z
 
     @staticmethod
@@ -405,6 +435,7 @@ class PlainBlockFn(torch.autograd.Function):
         z, coefs = PlainBlockFn._norm_act(ctx, y, stats, gamma, beta, cfg, n, cout, h * w, slope)
         ctx.save_for_backward(x1, None, y, coefs, weight, gamma)
         ctx.stride, ctx.mode, ctx.fixed, ctx.stem, ctx.slope = 1, cfg.mode, cfg.mode == NORM_BATCH and not cfg.training, True, slope
+        ctx.small = (bias, beta)
         return z
 
     @staticmethod
@@ -419,7 +450,11 @@ class PlainBlockFn(torch.autograd.Function):
         part = torch.empty((n, slabs, cout, 2), device=dev, dtype=torch.float32)
         cc = torch.empty((2, n, cout), device=dev, dtype=torch.float32)
         dgb = torch.empty((3, cout), device=dev, dtype=torch.float32)
-        dgamma, dbeta, dbias = dgb[0], dgb[1], dgb[2]
+        bias_p, beta_p = ctx.small
+        dgamma, dbeta, dbias = grad_dest(gamma), grad_dest(beta_p), grad_dest(bias_p)
+        dgamma = dgb[0] if dgamma is None else dgamma
+        dbeta = dgb[1] if dbeta is None else dbeta
+        dbias = dgb[2] if dbias is None else dbias
         dy = torch.empty_like(y)
         if ctx.sync is None:
             call("mia_norm_act_bwd", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
@@ -436,11 +471,13 @@ class PlainBlockFn(torch.autograd.Function):
         cin = weight.shape[1]
         if ctx.stem:
             ws = torch.empty(lib().mia_stem_wgrad_workspace(cout), device=dev, dtype=torch.float32)
-            dw = torch.empty(weight.shape, device=dev, dtype=torch.float32)
+            dw = grad_dest(weight)
+            if dw is None:
+                dw = torch.empty(weight.shape, device=dev, dtype=torch.float32)
             call("mia_stem_wgrad", _p(x1), _dt(x1), _p(dy), dtype, _p(ws), _p(dw), n, ho, wo, cout, 0, _stream())
             return None, None, dw, dbias, dgamma, dbeta, None, None, None, None
         wmode = WGRAD_3S2 if ctx.stride == 2 else WGRAD_3S1
-        dw = conv_wgrad(wmode, x1, x2, dy, weight.shape, cout, cin)
+        dw = conv_wgrad(wmode, x1, x2, dy, weight.shape, cout, cin, out=grad_dest(weight))
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             wb, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=False)
@@ -475,6 +512,7 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         wp, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=False)  # [tap][co][ci]
         out, _, _ = conv_mma(CONV_T2S2, x, None, wp, npad, kpad, False, bias.detach().float(), cout, (2 * h, 2 * w))
         ctx.save_for_backward(x, weight)
+        ctx.small = (bias,)
         return out
 
     @staticmethod
@@ -487,7 +525,11 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         dbias = _take_colsum(dout)
         if dbias is None:
             dbias = colsum(dout)
-        dw = conv_wgrad(WGRAD_2S2, dout, None, x, weight.shape, cin, cout)
+        dst = grad_dest(ctx.small[0])
+        if dst is not None:
+            dst.copy_(dbias)
+            dbias = dst
+        dw = conv_wgrad(WGRAD_2S2, dout, None, x, weight.shape, cin, cout, out=grad_dest(weight))
         dx = None
         if ctx.needs_input_grad[0]:
             wb, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=True)  # [tap][ci][co]
@@ -520,6 +562,7 @@ class HeadFn(torch.autograd.Function):
         call("mia_head_fwd", _p(x), _dt(x), _p(w2), _p(bias.detach()), _p(logits), n, _c_i64(h * w), c0, k1,
              _c_i64(h * w * k1), _c_i64(1), _c_i64(k1), _stream())
         ctx.save_for_backward(x, weight)
+        ctx.small = (bias,)
         return logits.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -535,8 +578,9 @@ class HeadFn(torch.autograd.Function):
             st = _pix_strides(dl)
         w2 = weight.detach().reshape(k1, c0).contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty((k1, c0), device=x.device, dtype=torch.float32)
-        db = torch.empty(k1, device=x.device, dtype=torch.float32)
+        dw, db = grad_dest(weight), grad_dest(ctx.small[0])
+        dw = torch.empty((k1, c0), device=x.device, dtype=torch.float32) if dw is None else dw
+        db = torch.empty(k1, device=x.device, dtype=torch.float32) if db is None else db
         ws = torch.empty(lib().mia_head_bwd_workspace(c0, k1), device=x.device, dtype=torch.float32)
         call("mia_head_bwd", _p(dl), _p(x), _dt(x), _p(w2), _p(dx), _p(dw), _p(db), _p(ws), n, _c_i64(h * w), c0, k1,
              _c_i64(st[0]), _c_i64(st[1]), _c_i64(st[2]), 0, _stream())

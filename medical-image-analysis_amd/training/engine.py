@@ -59,7 +59,9 @@ class FlatOptimizer:
                 n = p.numel()
                 self.flat_param[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat_param[o:o + n].view(p.shape)
-                p.grad = self.flat_grad[o:o + n].view(p.shape)
+                p.grad = None
+                ops.register_grad_dest(p, self.flat_grad, o)  # backward kernels write the gradient straight into the slice
+                p.register_post_accumulate_grad_hook(self._make_fixup(o))
         self.param_groups = [dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps, momentum=momentum)]
         self.step_count = 0
         self.last_norm: Optional[torch.Tensor] = None
@@ -85,11 +87,23 @@ class FlatOptimizer:
                     self.param_bucket.append(bi)
                     break
 
+    def _make_fixup(self, o: int):
+        """A gradient that did not come from a registered destination (other autograd nodes, accumulated twice, cloned by
+        autograd) is copied into its slice right after accumulation, so the flat buffer is always the truth."""
+        def hook(p):
+            g = p.grad
+            if g is not None and g.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                dst = self.flat_grad[o:o + p.numel()].view(p.shape)
+                dst.copy_(g)
+                p.grad = dst
+        return hook
+
     def zero_grad(self, set_to_none: bool = False):
+        """Unset .grad (autograd then ADOPTS the first gradient -- a view of the flat buffer -- instead of adding into
+        it) and clear the buffer, so a parameter that gets no gradient this step contributes zeros."""
         self.flat_grad.zero_()
-        for p, o in zip(self.params, self.offsets):  # re-attach if a caller detached the views
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
-                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        for p in self.params:
+            p.grad = None
 
     def step(self, max_grad_norm: float = 0.0, grad_scale: float = 1.0):
         g = self.param_groups[0]
