@@ -295,6 +295,8 @@ def grad_dest(param: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     if hit[0]() is not param:
         _GRAD_DEST.pop(id(param), None)
         return None
+    if param.grad is not None:
+        return None  # a gradient is already there (accumulation over several backward passes): autograd must ADD to it
     _, flat, off, n, shape = hit
     return flat[off:off + n].view(shape)
 
