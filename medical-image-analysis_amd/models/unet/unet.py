@@ -170,6 +170,7 @@ class UNet(nn.Module):
         return self.encoder.forward_nhwc(ops.to_nhwc(x, self.compute_dtype), self.compute_dtype)
 
     def forward(self, x, return_ds=False):
+        ops._COLSUM_HINT.clear()  # hints are only valid inside the backward pass of the forward that produced them
         return self.decoder.forward_nhwc(self._skips(x), return_ds=return_ds)
 
     def get_enc_feature(self, x):

@@ -54,6 +54,7 @@ class FlatOptimizer:
         self.m = torch.zeros(total, device=dev, dtype=torch.float32)
         self.v = torch.zeros(total, device=dev, dtype=torch.float32) if self.kind != OPT_SGD else None
         self.params, self.offsets = order, offs
+        self._token = object()  # marks the parameters as owned by THIS optimizer: hooks of an earlier one go quiet
         with torch.no_grad():
             for p, o in zip(order, offs):
                 n = p.numel()
@@ -61,6 +62,7 @@ class FlatOptimizer:
                 p.data = self.flat_param[o:o + n].view(p.shape)
                 p.grad = None
                 ops.register_grad_dest(p, self.flat_grad, o)  # backward kernels write the gradient straight into the slice
+                p._mia_flat_owner = self._token
                 p.register_post_accumulate_grad_hook(self._make_fixup(o))
         self.param_groups = [dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps, momentum=momentum)]
         self.step_count = 0
@@ -91,6 +93,8 @@ class FlatOptimizer:
         """A gradient that did not come from a registered destination (other autograd nodes, accumulated twice, cloned by
         autograd) is copied into its slice right after accumulation, so the flat buffer is always the truth."""
         def hook(p):
+            if getattr(p, "_mia_flat_owner", None) is not self._token:
+                return  # a newer FlatOptimizer took the parameter over (al_train builds a new optimizer every round)
             g = p.grad
             if g is not None and g.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 dst = self.flat_grad[o:o + p.numel()].view(p.shape)
@@ -163,6 +167,8 @@ class GradBucketReducer:
 
     def _make_hook(self, bi):
         def hook(_p):
+            if getattr(_p, "_mia_flat_owner", None) is not self.opt._token:
+                return  # stale reducer of an optimizer that no longer owns the parameter
             self.pending[bi] += 1
             if self.pending[bi] == self.counts[bi]:
                 s, e = self.opt.buckets[bi]
