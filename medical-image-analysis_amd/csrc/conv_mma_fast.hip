@@ -99,12 +99,20 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
     if (S == 2) a_lds[i] = pix < IH * IW ? iy * PITCH + (ix & 1) * G::IWH + (ix >> 1) : G::NPIX;
   }
   const int bn_ = p4 % BN, tsub = p4 / BN;
-  unsigned b_voff[B_IT];
+  // weight staging offsets.  3x3 / stride 1 with a 64-channel output block stages exactly one tap per iteration: the tap
+  // stride is uniform and rides in the load's scalar offset, so one thread-dependent offset serves all nine loads
+  constexpr bool LINB = (MODE == MODE_G3S1 && TPI == 1);
+  const int wtap_bytes = a.npad * a.kpad * ES;
+  unsigned b_voff[LINB ? 1 : B_IT];
+  if constexpr (LINB) {
+    b_voff[0] = (unsigned)((((size_t)n0 + bn_) * a.kpad + g * EPU) * ES);
+  } else {
 #pragma unroll
-  for (int i = 0; i < B_IT; ++i) {
-    const int tl = i * TPI + tsub;
-    const int ta = tl / ntw, tb = tl - ta * ntw;
-    b_voff[i] = tl < ntaps ? (unsigned)((((size_t)tap_w(ta, tb) * a.npad + n0 + bn_) * a.kpad + g * EPU) * ES) : SENT;
+    for (int i = 0; i < B_IT; ++i) {
+      const int tl = i * TPI + tsub;
+      const int ta = tl / ntw, tb = tl - ta * ntw;
+      b_voff[i] = tl < ntaps ? (unsigned)((((size_t)tap_w(ta, tb) * a.npad + n0 + bn_) * a.kpad + g * EPU) * ES) : SENT;
+    }
   }
 
   f32x4 acc[MT][NT];
@@ -134,7 +142,12 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
       pa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0);
     }
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)b_voff[i], c0 * ES, 0);
+    for (int i = 0; i < B_IT; ++i) {
+      if constexpr (LINB)
+        pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)b_voff[0], c0 * ES + (a.flip ? 8 - i : i) * wtap_bytes, 0);
+      else
+        pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)b_voff[i], c0 * ES, 0);
+    }
   };
   auto commit = [&]() {
 #pragma unroll
