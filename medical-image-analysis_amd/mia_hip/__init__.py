@@ -14,7 +14,7 @@ from typing import Dict, List, Tuple
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 HEADER = os.path.join(ROOT, "include", "mia_hip.h")
-LIB_PATH = os.path.join(HERE, "libmia_hip.so")
+LIB_PATH = os.environ.get("MIA_HIP_LIB") or os.path.join(HERE, "libmia_hip.so")  # MIA_HIP_LIB: A/B a differently built library
 
 F32, BF16 = 0, 1
 CONV_G3S1, CONV_G3S2, CONV_G2S2, CONV_T3S2, CONV_T2S2, CONV_G1 = range(6)
