@@ -195,9 +195,15 @@ class LaunchProbe:
     def __init__(self, match):
         self.match, self.pairs, self.enabled = match, [], False
 
-    def times_ms(self):
+    def times_ms(self, tag=None):
+        """Durations of the bracketed launches (all, or those whose match() returned `tag`)."""
         torch.cuda.synchronize()
-        return [a.elapsed_time(b) for a, b in self.pairs]
+        return [p[0].elapsed_time(p[1]) for p in self.pairs if tag is None or p[2] == tag]
+
+    def records(self):
+        """(duration_ms, tag, (mode, c1 + c2, nout, n, hout, wout)) per bracketed launch."""
+        torch.cuda.synchronize()
+        return [(p[0].elapsed_time(p[1]), p[2], p[3]) for p in self.pairs]
 
 
 PROBE: Optional[LaunchProbe] = None
@@ -225,7 +231,8 @@ def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: tor
     stats = None
     if want_stats:
         stats = torch.empty((n, conv_tiles(mode, hout, wout), nout, 2), device=x1.device, dtype=torch.float32)
-    probe = PROBE if (PROBE is not None and PROBE.enabled and PROBE.match(mode, c1, c2, nout, hin, win, bool(flip))) else None
+    tag = PROBE.match(mode, c1, c2, nout, hin, win, bool(flip)) if (PROBE is not None and PROBE.enabled) else None
+    probe = PROBE if tag else None
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -233,7 +240,7 @@ def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: tor
          _p(out2), o2, _p(stats), n, hin, win, hout, wout, _stream())
     if probe is not None:
         e1.record()
-        probe.pairs.append((e0, e1))
+        probe.pairs.append((e0, e1, tag, (mode, c1 + c2, nout, n, hout, wout)))
     return out1, out2, stats
 
 
