@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"])
     ap.add_argument("--norm", default="instance", choices=["instance", "batch"])
+    ap.add_argument("--dropout", type=float, default=0.1,
+                    help="Dropout2d probability of every PlainBlock (al_train default 0.1, al_trainer.py:109); 0 = None")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -153,7 +155,8 @@ def main():
     batch = args.batch or batch
     dt = args.dtype or dt
     torch.manual_seed(1337)  # identical weights on every rank
-    model = UNet(2, 1, 3, channels, normalization=args.norm, dropout_prob=None).to(dev)
+    drop = args.dropout if args.dropout > 0 else None
+    model = UNet(2, 1, 3, channels, normalization=args.norm, dropout_prob=drop).to(dev)
     model.set_compute_dtype(torch.bfloat16 if dt == "bf16" else torch.float32)
     loss_fn = DiceAndCELoss(dice_loss=DiceLoss, dice_kwargs=dict(num_classes=2, smooth=1e-5, do_bg=True, softmax=True,
                                                                  batch=False, squared=False),
@@ -228,7 +231,7 @@ def main():
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
                "config": {"workload": f"UNet-2D channels {channels} {size}x{size} 1ch, batch {batch}/GPU, {args.norm} norm, "
-                                      f"dropout None, Dice+CE, Adam(wd 5e-4), clip 10 ({args.config})",
+                                      f"dropout {drop}, Dice+CE, Adam(wd 5e-4), clip 10 ({args.config})",
                           "global_batch": world * batch, "parallelism": f"dp{world}"},
                "final_loss": round(loss_v, 6), "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
