@@ -158,6 +158,7 @@ def main():
     drop = args.dropout if args.dropout > 0 else None
     model = UNet(2, 1, 3, channels, normalization=args.norm, dropout_prob=drop).to(dev)
     model.set_compute_dtype(torch.bfloat16 if dt == "bf16" else torch.float32)
+    torch.manual_seed(1337 + rank)  # per-rank stream for the Dropout2d masks (seed + worker id, al_trainer.py:282-288)
     loss_fn = DiceAndCELoss(dice_loss=DiceLoss, dice_kwargs=dict(num_classes=2, smooth=1e-5, do_bg=True, softmax=True,
                                                                  batch=False, squared=False),
                             ce_loss=torch.nn.CrossEntropyLoss, ce_kwargs={})
