@@ -117,10 +117,31 @@ class FlatOptimizer:
             clip = ops.grad_norm(self.flat_grad, float(max_grad_norm), grad_scale)
             self.last_norm = clip
         b1, b2 = (g["momentum"], 0.0) if self.kind == OPT_SGD else g["betas"]
-        ops.optim_step(self.kind, self.flat_param, self.flat_grad, self.m, self.v, float(g["lr"]), b1, b2, g["eps"],
-                       float(g["weight_decay"]), self.step_count, clip, grad_scale)
+        # torch.optim skips a parameter whose .grad is None (no update, no weight decay, no moment decay) -- e.g. deep-
+        # supervision heads al_train never evaluates; update only the runs of the flat buffer that received a gradient
+        for s0, e0 in self._live_runs():
+            ops.optim_step(self.kind, self.flat_param[s0:e0], self.flat_grad[s0:e0], self.m[s0:e0],
+                           None if self.v is None else self.v[s0:e0], float(g["lr"]), b1, b2, g["eps"],
+                           float(g["weight_decay"]), self.step_count, clip, grad_scale)
         ops.bump_param_epoch()  # the kernel bypasses tensor version counters: packed weights must be rebuilt
         self._repack()
+
+    def _live_runs(self):
+        total = self.flat_param.numel()
+        if all(p.grad is not None for p in self.params):
+            return [(0, total)]
+        runs, start = [], None
+        for p, o in zip(self.params, self.offsets):
+            end = o + (p.numel() + 3) // 4 * 4
+            if p.grad is not None:
+                start = o if start is None else start
+                last = end
+            elif start is not None:
+                runs.append((start, last))
+                start = None
+        if start is not None:
+            runs.append((start, last))
+        return runs
 
     def _repack(self):
         """Rebuild every packed weight copy in one launch (ops.PackPlan) once the first steps have shown which are used."""
