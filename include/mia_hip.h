@@ -159,6 +159,23 @@ int mia_dice_ce_bwd(const float* logits, const long long* labels, const float* c
                     int nb, int64_t hw, int k1, int64_t sn, int64_t sk, int64_t sp, int64_t gsn, int64_t gsk, int64_t gsp,
                     int flags, float dice_w, float ce_w, void* stream);
 
+/* Head fused with the last decoder block (unet.py:176 behind blocks.py:98-100): the block's activation
+ * z = lrelu(scale*y + shift) has one consumer, the 1x1 head, so it is never materialised -- the head recomputes it from the
+ * raw conv output y on load, and the block's norm backward recomputes dz = W^T dlogits instead of reading it.
+ * mia_head_norm_eligible: 0 or the units per pixel; contract c0 in {4,8,16} 16-byte units, 2 <= k1 <= 4. */
+int mia_head_norm_eligible(int dtype, int n, int64_t hw, int c0, int k1);
+int mia_head_norm_fwd(const void* y, int dtype, const float* scale, const float* shift, float slope, const float* w,
+                      const float* b, float* logits, int n, int64_t hw, int c0, int k1, int64_t osn, int64_t osk, int64_t osp,
+                      void* stream);
+int mia_head_norm_wgrad(const float* dlogits, const void* y, int dtype, const float* scale, const float* shift, float slope,
+                        float* dw, float* db, float* workspace, int n, int64_t hw, int c0, int k1, int64_t gsn, int64_t gsk,
+                        int64_t gsp, int accumulate, void* stream);
+int mia_norm_act_bwd_head(const float* dlogits, const float* w, int k1, int64_t gsn, int64_t gsk, int64_t gsp, const void* y,
+                          void* dy, int dtype, const float* scale, const float* shift, const float* xa, const float* xb,
+                          const float* ysum, int n, int64_t hw, int c, int mode, int fixed_stats, float slope, int slabs,
+                          float* partials, float* c1, float* c2, float* dgamma, float* dbeta, float* dbias, int accumulate,
+                          void* stream);
+
 /* ------------------------------------------------------------------ optimizer (al_trainer.py:1374-1379) */
 #define MIA_OPT_ADAM 0
 #define MIA_OPT_ADAMW 1

@@ -234,6 +234,114 @@ static int head_fast_upp(int dtype, int c0, int k1, int64_t npix, int64_t sn, in
   } while (0)
 
 
+// ---------------------------------------------------------------- head fused with the last block's norm + LeakyReLU
+// The last decoder block's activated output z = lrelu(scale*y + shift) has exactly one consumer, the 1x1 head.  These
+// kernels recompute it from the raw conv output y on load (per-(image, channel) scale / shift in registers: a block
+// works inside one image), so z is never written or read: the forward apply pass and one activation round trip vanish.
+template <typename T, int K1, int UPP>
+__global__ __launch_bounds__(256) void head_norm_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float slope,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* __restrict__ out, int hw, int slabs, int64_t osn,
+                                                            int64_t osp, int64_t osk) {
+  constexpr int EPU = Elem<T>::EPU, C0 = UPP * EPU, LANES = 256 / UPP;
+  const int u = threadIdx.x % UPP, pl = threadIdx.x / UPP;
+  const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  const int per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  float wr[K1][EPU], sc[EPU], sf[EPU];
+#pragma unroll
+  for (int e = 0; e < EPU; ++e) {
+    sc[e] = scale[(size_t)n * C0 + u * EPU + e];
+    sf[e] = shift[(size_t)n * C0 + u * EPU + e];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) wr[k][e] = w[k * C0 + u * EPU + e];
+  }
+  float bu = 0.f;
+#pragma unroll
+  for (int k = 0; k < K1; ++k) bu = (u == k) ? b[k] : bu;
+  const T* yb = y + (size_t)n * hw * C0 + u * EPU;
+  float* ob = out + (int64_t)n * osn + u * osk;
+  auto body = [&](const u32x4& raw, int p) {
+    alignas(16) T v[EPU];
+    *reinterpret_cast<u32x4*>(v) = raw;
+    float acc[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) {
+      float xv = sc[e] * Elem<T>::ld(v + e) + sf[e];
+      xv = xv > 0.f ? xv : xv * slope;
+#pragma unroll
+      for (int k = 0; k < K1; ++k) acc[k] += xv * wr[k][e];
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int k = 0; k < K1; ++k) { const float t = group_sum<UPP>(acc[k]); mine = (u == k) ? t : mine; }
+    if (u < K1) ob[(int64_t)p * osp] = mine + bu;
+  };
+  int p = r0 + pl;
+  for (; p + LANES < r1; p += 2 * LANES) {
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(yb + (size_t)p * C0);
+    const u32x4 a1 = *reinterpret_cast<const u32x4*>(yb + (size_t)(p + LANES) * C0);
+    body(a0, p); body(a1, p + LANES);
+  }
+  if (p < r1) body(*reinterpret_cast<const u32x4*>(yb + (size_t)p * C0), p);
+}
+
+// part: [gridDim.x][K1][C0 + 1] like head_bwd_weight_fast_kernel, with x = lrelu(scale*y + shift) recomputed
+template <typename T, int K1, int UPP>
+__global__ __launch_bounds__(256) void head_norm_wgrad_kernel(const float* __restrict__ dl, const T* __restrict__ y,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              float slope, float* __restrict__ part, int hw, int slabs,
+                                                              int64_t gsn, int64_t gsp, int64_t gsk) {
+  constexpr int EPU = Elem<T>::EPU, C0 = UPP * EPU, LANES = 256 / UPP, SHS = C0 + 1;
+  __shared__ float shd[LANES * SHS];
+  const int u = threadIdx.x % UPP, pl = threadIdx.x / UPP;
+  const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  const int per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  float sc[EPU], sf[EPU], acc[K1][EPU], bacc[K1];
+#pragma unroll
+  for (int e = 0; e < EPU; ++e) {
+    sc[e] = scale[(size_t)n * C0 + u * EPU + e];
+    sf[e] = shift[(size_t)n * C0 + u * EPU + e];
+  }
+#pragma unroll
+  for (int k = 0; k < K1; ++k) {
+    bacc[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) acc[k][e] = 0.f;
+  }
+  const T* yb = y + (size_t)n * hw * C0 + u * EPU;
+  const float* gb = dl + (int64_t)n * gsn;
+  for (int p = r0 + pl; p < r1; p += LANES) {
+    alignas(16) T v[EPU];
+    *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(yb + (size_t)p * C0);
+    float gv[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) { gv[k] = gb[(int64_t)p * gsp + k * gsk]; bacc[k] += gv[k]; }
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) {
+      float xv = sc[e] * Elem<T>::ld(v + e) + sf[e];
+      xv = xv > 0.f ? xv : xv * slope;
+#pragma unroll
+      for (int k = 0; k < K1; ++k) acc[k][e] += gv[k] * xv;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K1; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) shd[pl * SHS + u * EPU + e] = acc[k][e];
+    if (u == 0) shd[pl * SHS + C0] = bacc[k];
+    __syncthreads();
+    if (threadIdx.x <= C0) {
+      float t = 0.f;
+      for (int j = 0; j < LANES; ++j) t += shd[j * SHS + threadIdx.x];
+      part[((size_t)blockIdx.x * K1 + k) * (C0 + 1) + threadIdx.x] = t;
+    }
+  }
+}
+
 extern "C" int mia_head_fwd(const void* x, int dtype, const float* w, const float* b, float* logits, int n, int64_t hw,
                             int c0, int k1, int64_t osn, int64_t osk, int64_t osp, void* stream) {
   MIA_CHECK_ARG(x && w && b && logits && n > 0 && hw > 0 && c0 > 0, "mia_head_fwd: bad arguments");
@@ -470,6 +578,53 @@ extern "C" int mia_head_bwd(const float* dlogits, const void* x, int dtype, cons
     hipLaunchKernelGGL(head_bwd_weight_kernel<float>, dim3(wblocks), dim3(256), 512 * 4, st, dlogits, static_cast<const float*>(x), workspace, npix, c0, k1, gsp, gsk, gsn, hw);
   } else { mia_set_error("mia_head_bwd: bad dtype"); return MIA_EARG; }
   hipLaunchKernelGGL(head_bwd_final_kernel, dim3(ceil_div(k1 * (c0 + 1), 16)), dim3(256), 0, st, workspace, wblocks, k1, c0, dw, db, accumulate);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// 0 = not eligible for the fused (norm + LeakyReLU + head) kernels, else units per pixel
+extern "C" int mia_head_norm_eligible(int dtype, int n, int64_t hw, int c0, int k1) {
+  const int epu = dtype == MIA_BF16 ? 8 : 4;
+  if ((dtype != MIA_BF16 && dtype != MIA_F32) || c0 % epu != 0) return 0;
+  const int upp = c0 / epu;
+  if ((upp != 4 && upp != 8 && upp != 16) || k1 < 2 || k1 > 4) return 0;
+  if (hw >= ((int64_t)1 << 31) || n > HEAD_BWD_BLOCKS) return 0;
+  return upp;
+}
+static int head_norm_slabs(int n, int64_t hw) {
+  int64_t sl = HEAD_BWD_BLOCKS / n;
+  const int64_t maxsl = hw / 512 > 0 ? hw / 512 : 1;
+  if (sl > maxsl) sl = maxsl;
+  return (int)(sl < 1 ? 1 : sl);
+}
+
+// logits = W * lrelu(scale*y + shift) + b   (y = raw conv output of the last decoder block, NHWC; scale / shift [N][C0])
+extern "C" int mia_head_norm_fwd(const void* y, int dtype, const float* scale, const float* shift, float slope, const float* w,
+                                 const float* b, float* logits, int n, int64_t hw, int c0, int k1, int64_t osn, int64_t osk,
+                                 int64_t osp, void* stream) {
+  MIA_CHECK_ARG(y && scale && shift && w && b && logits && n > 0 && hw > 0, "mia_head_norm_fwd: bad arguments");
+  const int upp = mia_head_norm_eligible(dtype, n, hw, c0, k1);
+  MIA_CHECK_ARG(upp > 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "mia_head_norm_fwd: shape not eligible (c0=%d k1=%d)", c0, k1);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int slabs = head_norm_slabs(n, hw);
+  if (dtype == MIA_BF16) HEAD_DISPATCH(head_norm_fwd_kernel, bf16_t, dim3(n * slabs), static_cast<const bf16_t*>(y), scale, shift, slope, w, b, logits, (int)hw, slabs, osn, osp, osk);
+  else HEAD_DISPATCH(head_norm_fwd_kernel, float, dim3(n * slabs), static_cast<const float*>(y), scale, shift, slope, w, b, logits, (int)hw, slabs, osn, osp, osk);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// dW, db of the head with its input recomputed from y (workspace: mia_head_bwd_workspace floats)
+extern "C" int mia_head_norm_wgrad(const float* dlogits, const void* y, int dtype, const float* scale, const float* shift,
+                                   float slope, float* dw, float* db, float* workspace, int n, int64_t hw, int c0, int k1,
+                                   int64_t gsn, int64_t gsk, int64_t gsp, int accumulate, void* stream) {
+  MIA_CHECK_ARG(dlogits && y && scale && shift && dw && db && workspace && n > 0 && hw > 0, "mia_head_norm_wgrad: bad arguments");
+  const int upp = mia_head_norm_eligible(dtype, n, hw, c0, k1);
+  MIA_CHECK_ARG(upp > 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "mia_head_norm_wgrad: shape not eligible (c0=%d k1=%d)", c0, k1);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int slabs = head_norm_slabs(n, hw);
+  if (dtype == MIA_BF16) HEAD_DISPATCH(head_norm_wgrad_kernel, bf16_t, dim3(n * slabs), dlogits, static_cast<const bf16_t*>(y), scale, shift, slope, workspace, (int)hw, slabs, gsn, gsp, gsk);
+  else HEAD_DISPATCH(head_norm_wgrad_kernel, float, dim3(n * slabs), dlogits, static_cast<const float*>(y), scale, shift, slope, workspace, (int)hw, slabs, gsn, gsp, gsk);
+  hipLaunchKernelGGL(head_bwd_final_kernel, dim3(ceil_div(k1 * (c0 + 1), 16)), dim3(256), 0, st, workspace, n * slabs, k1, c0, dw, db, accumulate);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

@@ -721,3 +721,141 @@ extern "C" int mia_norm_act_bwd_apply_sync(const void* dz, const void* y, void* 
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
+
+// ---------------------------------------------------------------- norm backward fed by the 1x1 head
+// When the block's only consumer is the segmentation head, its output gradient is dz[p][c] = sum_k dl[p][k] * w[k][c]:
+// three FMAs per value from 12 bytes per pixel.  Recomputing it here (weights in registers) removes the head's
+// input-gradient kernel and both reads of dz: nothing activation-sized flows between the head and this block.
+template <typename T, int K1, int CG>
+__global__ __launch_bounds__(256) void colreduce_head_kernel(const float* __restrict__ dl, const float* __restrict__ w,
+                                                             const T* __restrict__ y, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const float* __restrict__ xa,
+                                                             const float* __restrict__ xb, int hw, int c, int slabs, float slope,
+                                                             int64_t gsn, int64_t gsp, int64_t gsk, float* __restrict__ part) {
+  constexpr int EPU = Elem<T>::EPU, UPB = CG / EPU, LANES = 256 / UPB;
+  __shared__ float sh[2][LANES][CG + 1];
+  const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  const int u = threadIdx.x % UPB, pl = threadIdx.x / UPB;
+  const int ch0 = blockIdx.y * CG + u * EPU;
+  const int per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  float s1[EPU], s2[EPU], sc[EPU], sf[EPU], ka[EPU], kb[EPU], wr[K1][EPU];
+#pragma unroll
+  for (int e = 0; e < EPU; ++e) {
+    s1[e] = 0.f; s2[e] = 0.f;
+    const size_t o = (size_t)n * c + ch0 + e;
+    sc[e] = scale[o]; sf[e] = shift[o]; ka[e] = xa[o]; kb[e] = xb[o];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) wr[k][e] = w[k * c + ch0 + e];
+  }
+  const T* yb = y + (size_t)n * hw * c + ch0;
+  const float* gb = dl + (int64_t)n * gsn;
+  for (int r = r0 + pl; r < r1; r += LANES) {
+    alignas(16) T v[EPU];
+    *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(yb + (size_t)r * c);
+    float gv[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) gv[k] = gb[(int64_t)r * gsp + k * gsk];
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) {
+      const float yv = Elem<T>::ld(v + e);
+      float g = 0.f;
+#pragma unroll
+      for (int k = 0; k < K1; ++k) g += gv[k] * wr[k][e];
+      if (!(sc[e] * yv + sf[e] > 0.f)) g *= slope;
+      s1[e] += g; s2[e] += g * (ka[e] * yv + kb[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPU; ++e) { sh[0][pl][u * EPU + e] = s1[e]; sh[1][pl][u * EPU + e] = s2[e]; }
+  __syncthreads();
+  if (threadIdx.x < 2 * CG) {
+    const int k = threadIdx.x / CG, chl = threadIdx.x % CG;
+    float t = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < LANES; ++j) t += sh[k][j][chl];
+    part[(((size_t)n * slabs + s) * c + blockIdx.y * CG + chl) * 2 + k] = t;
+  }
+}
+
+template <typename T, int K1>
+__global__ __launch_bounds__(256) void norm_act_bwd_stream_head_kernel(const float* __restrict__ dl, const float* __restrict__ w,
+                                                                       const T* __restrict__ y, T* __restrict__ dy,
+                                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                       const float* __restrict__ xa, const float* __restrict__ xb,
+                                                                       const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                       int hw, int c, int slabs, int upb, float slope, int64_t gsn,
+                                                                       int64_t gsp, int64_t gsk) {
+  constexpr int EPU = Elem<T>::EPU;
+  const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  const int lanes = 256 / upb;
+  const int u = blockIdx.y * upb + threadIdx.x % upb, pl = threadIdx.x / upb;
+  if (u * EPU >= c) return;
+  const int per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  float sc[EPU], sf[EPU], ka[EPU], kb[EPU], wr[K1][EPU];
+#pragma unroll
+  for (int e = 0; e < EPU; ++e) {
+    const size_t o = (size_t)n * c + u * EPU + e;
+    sc[e] = scale[o]; sf[e] = shift[o];
+    ka[e] = -sc[e] * c2[o] * xa[o];
+    kb[e] = -sc[e] * (c1[o] + c2[o] * xb[o]);
+#pragma unroll
+    for (int k = 0; k < K1; ++k) wr[k][e] = w[k * c + u * EPU + e];
+  }
+  const size_t base = (size_t)n * hw * c + (size_t)u * EPU;
+  const float* gb = dl + (int64_t)n * gsn;
+  for (int r = r0 + pl; r < r1; r += lanes) {
+    alignas(16) T yin[EPU]; alignas(16) T out[EPU];
+    *reinterpret_cast<u32x4*>(yin) = *reinterpret_cast<const u32x4*>(y + base + (size_t)r * c);
+    float gv[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) gv[k] = gb[(int64_t)r * gsp + k * gsk];
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) {
+      const float yv = Elem<T>::ld(yin + e);
+      float g = 0.f;
+#pragma unroll
+      for (int k = 0; k < K1; ++k) g += gv[k] * wr[k][e];
+      if (!(sc[e] * yv + sf[e] > 0.f)) g *= slope;
+      out[e] = Elem<T>::cvt(sc[e] * g + ka[e] * yv + kb[e]);
+    }
+    *reinterpret_cast<u32x4*>(dy + base + (size_t)r * c) = *reinterpret_cast<const u32x4*>(out);
+  }
+}
+
+// mia_norm_act_bwd with dz = W^T dl recomputed on the fly (w: [k1][c] fp32, dl: fp32 logits gradient with element strides
+// gsn / gsk / gsp, pixel-linear).  Contract: c % 32 == 0, 2 <= k1 <= 4, 16-byte aligned y / dy, hw < 2^31.
+extern "C" int mia_norm_act_bwd_head(const float* dlogits, const float* w, int k1, int64_t gsn, int64_t gsk, int64_t gsp,
+                                     const void* y, void* dy, int dtype, const float* scale, const float* shift, const float* xa,
+                                     const float* xb, const float* ysum, int n, int64_t hw, int c, int mode, int fixed_stats,
+                                     float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta,
+                                     float* dbias, int accumulate, void* stream) {
+  MIA_CHECK_ARG(dlogits && w && y && dy && scale && shift && xa && xb && partials && c1 && c2 && dgamma && dbeta,
+                "mia_norm_act_bwd_head: null pointer");
+  MIA_CHECK_ARG(n > 0 && hw > 0 && hw < ((int64_t)1 << 31) && c > 0 && slabs > 0 && k1 >= 2 && k1 <= 4 && c % 32 == 0,
+                "mia_norm_act_bwd_head: bad shape (c=%d k1=%d)", c, k1);
+  if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_norm_act_bwd_head: bad dtype"); return MIA_EARG; }
+  MIA_CHECK_ARG(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0, "mia_norm_act_bwd_head: unaligned");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int epu = dtype == MIA_BF16 ? 8 : 4;
+#define CRH(T, K, CGW) hipLaunchKernelGGL((colreduce_head_kernel<T, K, CGW>), dim3(n * slabs, c / CGW), dim3(256), 0, st, dlogits, w, \
+                                          static_cast<const T*>(y), scale, shift, xa, xb, (int)hw, c, slabs, slope, gsn, gsp, gsk, partials)
+#define CRHK(T, CGW) do { if (k1 == 2) CRH(T, 2, CGW); else if (k1 == 3) CRH(T, 3, CGW); else CRH(T, 4, CGW); } while (0)
+  if (c % 64 == 0) { if (dtype == MIA_BF16) CRHK(bf16_t, 64); else CRHK(float, 64); }
+  else { if (dtype == MIA_BF16) CRHK(bf16_t, 32); else CRHK(float, 32); }
+#undef CRHK
+#undef CRH
+  hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3(n, ceil_div(c, 16)), dim3(256), 0, st, partials, slabs, c, c1, c2);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, mode, fixed_stats, scale, xa,
+                     xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate, nullptr);
+  int sl, upb, gy;
+  stream_geometry(n, hw, c, epu, &sl, &upb, &gy);
+#define BSH(T, K) hipLaunchKernelGGL((norm_act_bwd_stream_head_kernel<T, K>), dim3(n * sl, gy), dim3(256), 0, st, dlogits, w, \
+                                     static_cast<const T*>(y), static_cast<T*>(dy), scale, shift, xa, xb, c1, c2, (int)hw, c, sl, upb, \
+                                     slope, gsn, gsp, gsk)
+#define BSHK(T) do { if (k1 == 2) BSH(T, 2); else if (k1 == 3) BSH(T, 3); else BSH(T, 4); } while (0)
+  if (dtype == MIA_BF16) BSHK(bf16_t); else BSHK(float);
+#undef BSHK
+#undef BSH
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}

@@ -102,6 +102,17 @@ class PlainBlock(nn.Module):
         return ops.PlainBlockFn.apply(x1, x2, conv.weight, conv.bias, norm.weight, norm.bias, self.stride,
                                       self._cfg(x1.shape[0], x1.device), out_dtype)
 
+    def forward_head_nhwc(self, x1, head):
+        """This block followed by the 1x1 head `head` (nn.Conv2d) in one fused node, or None when the fused kernels do
+        not cover the case (the caller then runs the block and the head separately)."""
+        conv, norm = self.all[0], self.all[2]
+        if self.stride != 1 or x1.dtype not in (torch.float32, torch.bfloat16):
+            return None
+        cfg = self._cfg(x1.shape[0], x1.device)
+        if not ops.PlainBlockHeadFn.eligible(x1, conv.weight, head.weight, cfg, x1.dtype):
+            return None
+        return ops.PlainBlockHeadFn.apply(x1, conv.weight, conv.bias, norm.weight, norm.bias, cfg, head.weight, head.bias)
+
     def forward(self, x):
         dt = x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
         return ops.nhwc_as_nchw(self.forward_nhwc(ops.to_nhwc(x, dt)))

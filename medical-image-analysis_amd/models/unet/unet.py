@@ -103,7 +103,7 @@ class UNetDecoder(nn.Module):
                     ds = None
                 self.ds.append(ds)
 
-    def _run(self, skips, return_ds):
+    def _run(self, skips, return_ds, fuse_head=False):
         """skips: NHWC tensors, encoder order (bottleneck last)."""
         skips = list(skips)[::-1]
         x = skips.pop(0)
@@ -112,7 +112,13 @@ class UNetDecoder(nn.Module):
             up = self.upsamples[l]
             x = ops.ConvTranspose2x2Fn.apply(x, up.weight, up.bias)
             x = self.levels[l][0].forward_nhwc(feat, x)  # cat([skip, up], 1) folded into the conv's two-source read
-            x = self.levels[l][1].forward_nhwc(x)
+            last = self.levels[l][1]
+            if fuse_head and l == len(skips) - 1 and isinstance(last, PlainBlock):
+                # nobody but the segmentation head reads the last block's output: one fused node, no activation tensor
+                seg = last.forward_head_nhwc(x, self.seg_output)
+                if seg is not None:
+                    return seg, None, ds_outputs, ds_feats
+            x = last.forward_nhwc(x)
             if return_ds and self.deep_supervision and (l in self.ds_layer_list):
                 head = self.ds[l][0]
                 ds_feats.append(x)
@@ -121,7 +127,7 @@ class UNetDecoder(nn.Module):
         return seg, x, ds_outputs, ds_feats
 
     def forward_nhwc(self, skips, return_ds=False):
-        seg, _, ds_outputs, _ = self._run(skips, return_ds)
+        seg, _, ds_outputs, _ = self._run(skips, return_ds, fuse_head=True)
         if return_ds:
             return [seg] + ds_outputs[::-1]
         return seg
