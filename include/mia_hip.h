@@ -105,10 +105,14 @@ int mia_norm_finalize(const float* partials, int n, int tiles, int c, int64_t hw
 int mia_norm_stats(const void* y, int dtype, int n, int64_t hw, int c, int slabs, float* partials, void* stream);
 int mia_norm_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift, int n, int64_t hw, int c,
                      float slope, void* stream);
+/* dz2 (nullable, here and in the _reduce / _apply_sync forms): a second piece of the output gradient, summed on load --
+ * the two consumers of a skip tensor (unet.py:213 and the next encoder level) each deliver one; needs c % 32 == 0
+ * (mia_norm_two_piece_ok). */
+int mia_norm_two_piece_ok(int dtype, int c);
 /* backward of (dropout . norm . lrelu): dy, dgamma, dbeta.  partials: [N][slabs][C][2]; c1, c2: [N][C].
  * dbias (optional, with ysum [N][C] from mia_norm_finalize) = gradient of the Conv2d bias in front of the norm
  * (= sum over pixels of dy) in closed form from the reduction sums: no extra pass over dy. */
-int mia_norm_act_bwd(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
+int mia_norm_act_bwd(const void* dz, const void* dz2, const void* y, void* dy, int dtype, const float* scale, const float* shift,
                      const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
                      int fixed_stats, float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma,
                      float* dbeta, float* dbias, int accumulate, void* stream);
@@ -128,10 +132,10 @@ int mia_norm_finalize_sync(const float* gathered, int world, int n, int c, int64
                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                            float* running_var, long long* num_batches, float* xa, float* xb, float* scale, float* shift,
                            float* ysum, void* stream);
-int mia_norm_act_bwd_reduce(const void* dz, const void* y, int dtype, const float* scale, const float* shift, const float* xa,
+int mia_norm_act_bwd_reduce(const void* dz, const void* dz2, const void* y, int dtype, const float* scale, const float* shift, const float* xa,
                             const float* xb, int n, int64_t hw, int c, float slope, int slabs, float* partials, float* c1,
                             float* c2, float* tot, void* stream);
-int mia_norm_act_bwd_apply_sync(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
+int mia_norm_act_bwd_apply_sync(const void* dz, const void* dz2, const void* y, void* dy, int dtype, const float* scale, const float* shift,
                                 const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, float slope,
                                 float* c1, float* c2, const float* group_tot, float* dgamma, float* dbeta, float* dbias,
                                 int accumulate, void* stream);

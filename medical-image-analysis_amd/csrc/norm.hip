@@ -192,8 +192,9 @@ extern "C" int mia_norm_finalize_sync(const float* gathered, int world, int n, i
 // ---------------------------------------------------------------- vectorised per-channel reductions (C % 64 == 0)
 // block = (64 channels = UPB 16-byte units) x (256/UPB pixel lanes); grid = (n*slabs, C/64).  Each thread streams
 // 16-byte units of its slab, keeps EPU x 2 running sums in registers, lanes are combined through LDS.
-template <typename T, bool BWD, int CG>
+template <typename T, bool BWD, int CG, bool TWO = false>
 __global__ __launch_bounds__(256) void colreduce_vec_kernel(const T* __restrict__ a0, const T* __restrict__ a1,
+                                                            const T* __restrict__ a2 /* TWO: second gradient piece, dz = a0 + a2 */,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ xa, const float* __restrict__ xb,
                                                             int64_t hw, int c, int slabs, float slope, float* __restrict__ part) {
@@ -213,15 +214,17 @@ __global__ __launch_bounds__(256) void colreduce_vec_kernel(const T* __restrict_
       sc[e] = scale[o]; sf[e] = shift[o]; ka[e] = xa[o]; kb[e] = xb[o];
     }
   }
-  auto body = [&](const u32x4& r0v, const u32x4& r1v) {
-    alignas(16) T v0[EPU]; alignas(16) T v1[EPU];
+  auto body = [&](const u32x4& r0v, const u32x4& r1v, const u32x4& r2v) {
+    alignas(16) T v0[EPU]; alignas(16) T v1[EPU]; alignas(16) T v2[EPU];
     *reinterpret_cast<u32x4*>(v0) = r0v;
     *reinterpret_cast<u32x4*>(v1) = r1v;
+    *reinterpret_cast<u32x4*>(v2) = r2v;
 #pragma unroll
     for (int e = 0; e < EPU; ++e) {
-      if (BWD) {  // a0 = dz, a1 = y
+      if (BWD) {  // a0 (+ a2) = dz, a1 = y
         const float yv = Elem<T>::ld(v1 + e);
         float g = Elem<T>::ld(v0 + e);
+        if (TWO) g += Elem<T>::ld(v2 + e);
         if (!(sc[e] * yv + sf[e] > 0.f)) g *= slope;
         s1[e] += g; s2[e] += g * (ka[e] * yv + kb[e]);
       } else {
@@ -231,16 +234,14 @@ __global__ __launch_bounds__(256) void colreduce_vec_kernel(const T* __restrict_
     }
   };
   const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
+  auto ld = [&](const T* ptr, int64_t r) { return *reinterpret_cast<const u32x4*>(ptr + base + r * c); };
   int64_t r = r0 + pl;
-  for (; r + LANES < r1; r += 2 * LANES) {  // two rows (up to four 16-byte loads) in flight per thread
-    const u32x4 p0 = *reinterpret_cast<const u32x4*>(a0 + base + r * c);
-    const u32x4 q0 = BWD ? *reinterpret_cast<const u32x4*>(a1 + base + r * c) : zero;
-    const u32x4 p1 = *reinterpret_cast<const u32x4*>(a0 + base + (r + LANES) * c);
-    const u32x4 q1 = BWD ? *reinterpret_cast<const u32x4*>(a1 + base + (r + LANES) * c) : zero;
-    body(p0, q0); body(p1, q1);
+  for (; r + LANES < r1; r += 2 * LANES) {  // two rows (up to six 16-byte loads) in flight per thread
+    const u32x4 p0 = ld(a0, r), q0 = BWD ? ld(a1, r) : zero, t0 = TWO ? ld(a2, r) : zero;
+    const u32x4 p1 = ld(a0, r + LANES), q1 = BWD ? ld(a1, r + LANES) : zero, t1 = TWO ? ld(a2, r + LANES) : zero;
+    body(p0, q0, t0); body(p1, q1, t1);
   }
-  for (; r < r1; r += LANES)
-    body(*reinterpret_cast<const u32x4*>(a0 + base + r * c), BWD ? *reinterpret_cast<const u32x4*>(a1 + base + r * c) : zero);
+  for (; r < r1; r += LANES) body(ld(a0, r), BWD ? ld(a1, r) : zero, TWO ? ld(a2, r) : zero);
 #pragma unroll
   for (int e = 0; e < EPU; ++e) { sh[0][pl][u * EPU + e] = s1[e]; sh[1][pl][u * EPU + e] = s2[e]; }
   __syncthreads();
@@ -280,15 +281,17 @@ __global__ void norm_stats_kernel(const T* __restrict__ y, int64_t hw, int c, in
   }
 }
 
-// launch helper: 64-channel blocks, or 32-channel blocks when c is only a multiple of 32 (e.g. 96-channel layers)
-#define CRV(T, BWDF, A0, A1, SC, SF, XA, XB, SLOPE)                                                                       \
+// launch helper: 64-channel blocks, or 32-channel blocks when c is only a multiple of 32 (e.g. 96-channel layers);
+// A2 != nullptr selects the two-piece gradient variant (dz = A0 + A2)
+#define CRV_(T, BWDF, CGW, TWOF, A0, A1, A2, SC, SF, XA, XB, SLOPE)                                                       \
+  hipLaunchKernelGGL((colreduce_vec_kernel<T, BWDF, CGW, TWOF>), dim3(n * slabs, c / CGW), dim3(256), 0, st, A0, A1, A2, SC, \
+                     SF, XA, XB, hw, c, slabs, SLOPE, partials)
+#define CRV(T, BWDF, A0, A1, A2, SC, SF, XA, XB, SLOPE)                                                                   \
   do {                                                                                                                    \
-    if (c % 64 == 0)                                                                                                      \
-      hipLaunchKernelGGL((colreduce_vec_kernel<T, BWDF, 64>), dim3(n * slabs, c / 64), dim3(256), 0, st, A0, A1, SC, SF, XA, \
-                         XB, hw, c, slabs, SLOPE, partials);                                                              \
-    else                                                                                                                  \
-      hipLaunchKernelGGL((colreduce_vec_kernel<T, BWDF, 32>), dim3(n * slabs, c / 32), dim3(256), 0, st, A0, A1, SC, SF, XA, \
-                         XB, hw, c, slabs, SLOPE, partials);                                                              \
+    if (c % 64 == 0) { if ((A2) != nullptr) CRV_(T, BWDF, 64, true, A0, A1, A2, SC, SF, XA, XB, SLOPE);                   \
+                       else CRV_(T, BWDF, 64, false, A0, A1, A2, SC, SF, XA, XB, SLOPE); }                                \
+    else { if ((A2) != nullptr) CRV_(T, BWDF, 32, true, A0, A1, A2, SC, SF, XA, XB, SLOPE);                               \
+           else CRV_(T, BWDF, 32, false, A0, A1, A2, SC, SF, XA, XB, SLOPE); }                                            \
   } while (0)
 
 extern "C" int mia_norm_stats(const void* y, int dtype, int n, int64_t hw, int c, int slabs, float* partials, void* stream) {
@@ -296,9 +299,9 @@ extern "C" int mia_norm_stats(const void* y, int dtype, int n, int64_t hw, int c
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (c % 32 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (dtype == MIA_BF16 || dtype == MIA_F32)) {
     if (dtype == MIA_BF16)
-      CRV(bf16_t, false, static_cast<const bf16_t*>(y), static_cast<const bf16_t*>(nullptr), nullptr, nullptr, nullptr, nullptr, 0.f);
+      CRV(bf16_t, false, static_cast<const bf16_t*>(y), static_cast<const bf16_t*>(nullptr), static_cast<const bf16_t*>(nullptr), nullptr, nullptr, nullptr, nullptr, 0.f);
     else
-      CRV(float, false, static_cast<const float*>(y), static_cast<const float*>(nullptr), nullptr, nullptr, nullptr, nullptr, 0.f);
+      CRV(float, false, static_cast<const float*>(y), static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), nullptr, nullptr, nullptr, nullptr, 0.f);
     MIA_LAUNCH_CHECK();
     return MIA_OK;
   }
@@ -350,8 +353,9 @@ __global__ __launch_bounds__(256) void norm_act_fwd_stream_kernel(const T* __res
 }
 
 // dy = scale*(g - c1 - xhat*c2) = scale*g + ka*y + kb  with ka = -scale*c2*xa, kb = -scale*(c1 + c2*xb)
-template <typename T>
-__global__ __launch_bounds__(256) void norm_act_bwd_stream_kernel(const T* __restrict__ dz, const T* __restrict__ y, T* __restrict__ dy,
+template <typename T, bool TWO = false>
+__global__ __launch_bounds__(256) void norm_act_bwd_stream_kernel(const T* __restrict__ dz, const T* __restrict__ dz2,
+                                                                  const T* __restrict__ y, T* __restrict__ dy,
                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                                   const float* __restrict__ xa, const float* __restrict__ xb,
                                                                   const float* __restrict__ c1, const float* __restrict__ c2,
@@ -371,29 +375,30 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stream_kernel(const T* __res
     kb[e] = -sc[e] * (c1[o] + c2[o] * xb[o]);
   }
   const size_t base = (size_t)n * hw * c + (size_t)u * EPU;
-  auto body = [&](const u32x4& graw, const u32x4& yraw, int64_t r) {
-    alignas(16) T gin[EPU]; alignas(16) T yin[EPU]; alignas(16) T out[EPU];
+  auto body = [&](const u32x4& graw, const u32x4& g2raw, const u32x4& yraw, int64_t r) {
+    alignas(16) T gin[EPU]; alignas(16) T g2in[EPU]; alignas(16) T yin[EPU]; alignas(16) T out[EPU];
     *reinterpret_cast<u32x4*>(gin) = graw;
+    *reinterpret_cast<u32x4*>(g2in) = g2raw;
     *reinterpret_cast<u32x4*>(yin) = yraw;
 #pragma unroll
     for (int e = 0; e < EPU; ++e) {
       const float yv = Elem<T>::ld(yin + e);
       float g = Elem<T>::ld(gin + e);
+      if (TWO) g += Elem<T>::ld(g2in + e);
       if (!(sc[e] * yv + sf[e] > 0.f)) g *= slope;
       out[e] = Elem<T>::cvt(sc[e] * g + ka[e] * yv + kb[e]);
     }
     *reinterpret_cast<u32x4*>(dy + base + r * c) = *reinterpret_cast<const u32x4*>(out);
   };
+  const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
+  auto ld = [&](const T* ptr, int64_t r) { return *reinterpret_cast<const u32x4*>(ptr + base + r * c); };
   int64_t r = r0 + pl;
-  for (; r + lanes < r1; r += 2 * lanes) {  // four independent 16-byte loads in flight per thread
-    const u32x4 g0 = *reinterpret_cast<const u32x4*>(dz + base + r * c);
-    const u32x4 y0 = *reinterpret_cast<const u32x4*>(y + base + r * c);
-    const u32x4 g1 = *reinterpret_cast<const u32x4*>(dz + base + (r + lanes) * c);
-    const u32x4 y1 = *reinterpret_cast<const u32x4*>(y + base + (r + lanes) * c);
-    body(g0, y0, r); body(g1, y1, r + lanes);
+  for (; r + lanes < r1; r += 2 * lanes) {  // four (six) independent 16-byte loads in flight per thread
+    const u32x4 g0 = ld(dz, r), h0 = TWO ? ld(dz2, r) : zero, y0 = ld(y, r);
+    const u32x4 g1 = ld(dz, r + lanes), h1 = TWO ? ld(dz2, r + lanes) : zero, y1 = ld(y, r + lanes);
+    body(g0, h0, y0, r); body(g1, h1, y1, r + lanes);
   }
-  for (; r < r1; r += lanes)
-    body(*reinterpret_cast<const u32x4*>(dz + base + r * c), *reinterpret_cast<const u32x4*>(y + base + r * c), r);
+  for (; r < r1; r += lanes) body(ld(dz, r), TWO ? ld(dz2, r) : zero, ld(y, r), r);
 }
 
 static void stream_geometry(int n, int64_t hw, int c, int epu, int* slabs, int* upb, int* gy) {
@@ -618,7 +623,7 @@ static bool bwd_vec_ok(const void* dz, const void* y, const void* dy, int dtype,
 }
 
 // pass 1: slab partials of (sum g, sum g*xhat), then per-(n,c) sums parked in c1 / c2
-static void bwd_reduce_launch(const void* dz, const void* y, int dtype, const float* scale, const float* shift, const float* xa,
+static void bwd_reduce_launch(const void* dz, const void* dz2, const void* y, int dtype, const float* scale, const float* shift, const float* xa,
                               const float* xb, int n, int64_t hw, int c, float slope, int slabs, float* partials, float* c1,
                               float* c2, hipStream_t st) {
   const bool vec = bwd_vec_ok(dz, y, nullptr, dtype, c);
@@ -627,16 +632,16 @@ static void bwd_reduce_launch(const void* dz, const void* y, int dtype, const fl
                                  slope, partials)
   if (vec && c % 32 == 0) {
     if (dtype == MIA_BF16)
-      CRV(bf16_t, true, static_cast<const bf16_t*>(dz), static_cast<const bf16_t*>(y), scale, shift, xa, xb, slope);
+      CRV(bf16_t, true, static_cast<const bf16_t*>(dz), static_cast<const bf16_t*>(y), static_cast<const bf16_t*>(dz2), scale, shift, xa, xb, slope);
     else
-      CRV(float, true, static_cast<const float*>(dz), static_cast<const float*>(y), scale, shift, xa, xb, slope);
+      CRV(float, true, static_cast<const float*>(dz), static_cast<const float*>(y), static_cast<const float*>(dz2), scale, shift, xa, xb, slope);
   } else if (dtype == MIA_BF16) RD(bf16_t); else RD(float);
 #undef RD
   hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3(n, ceil_div(c, 16)), dim3(256), 0, st, partials, slabs, c, c1, c2);
 }
 
 // pass 2: dy from the finalized group means
-static void bwd_apply_launch(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
+static void bwd_apply_launch(const void* dz, const void* dz2, const void* y, void* dy, int dtype, const float* scale, const float* shift,
                              const float* xa, const float* xb, const float* c1, const float* c2, int n, int64_t hw, int c,
                              float slope, hipStream_t st) {
   const int epu = dtype == MIA_BF16 ? 8 : 4;
@@ -649,16 +654,26 @@ static void bwd_apply_launch(const void* dz, const void* y, void* dy, int dtype,
   if (vec) {
     int sl, upb, gy;
     stream_geometry(n, hw, c, epu, &sl, &upb, &gy);
-    if (dtype == MIA_BF16)
-      hipLaunchKernelGGL(norm_act_bwd_stream_kernel<bf16_t>, dim3(n * sl, gy), dim3(256), 0, st, static_cast<const bf16_t*>(dz), static_cast<const bf16_t*>(y), static_cast<bf16_t*>(dy), scale, shift, xa, xb, c1, c2, hw, c, sl, upb, slope);
-    else
-      hipLaunchKernelGGL(norm_act_bwd_stream_kernel<float>, dim3(n * sl, gy), dim3(256), 0, st, static_cast<const float*>(dz), static_cast<const float*>(y), static_cast<float*>(dy), scale, shift, xa, xb, c1, c2, hw, c, sl, upb, slope);
+#define BS(T, TWOF) hipLaunchKernelGGL((norm_act_bwd_stream_kernel<T, TWOF>), dim3(n * sl, gy), dim3(256), 0, st, static_cast<const T*>(dz), \
+                                       static_cast<const T*>(dz2), static_cast<const T*>(y), static_cast<T*>(dy), scale, shift, xa, xb, \
+                                       c1, c2, hw, c, sl, upb, slope)
+    if (dtype == MIA_BF16) { if (dz2) BS(bf16_t, true); else BS(bf16_t, false); }
+    else { if (dz2) BS(float, true); else BS(float, false); }
+#undef BS
   } else if (dtype == MIA_BF16) AP(bf16_t, false);
   else AP(float, false);
 #undef AP
 }
 
-extern "C" int mia_norm_act_bwd(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
+// dz2 (optional): second piece of the output gradient, dz = dz + dz2 summed on load in fp32 -- a skip tensor's two
+// consumers (unet.py:213 and the next encoder level) each deliver their own gradient and no `add` pass is needed.
+// Needs the vectorised path: c % 32 == 0 and 16-byte aligned tensors (mia_norm_two_piece_ok).
+extern "C" int mia_norm_two_piece_ok(int dtype, int c) { return (dtype == MIA_BF16 || dtype == MIA_F32) && c % 32 == 0; }
+static bool two_piece_ok(const void* dz, const void* dz2, const void* y, const void* dy, int dtype, int c) {
+  return dz2 == nullptr || (c % 32 == 0 && bwd_vec_ok(dz, y, dy, dtype, c) && (reinterpret_cast<uintptr_t>(dz2) & 15) == 0);
+}
+
+extern "C" int mia_norm_act_bwd(const void* dz, const void* dz2, const void* y, void* dy, int dtype, const float* scale, const float* shift,
                                 const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
                                 int fixed_stats, float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma,
                                 float* dbeta, float* dbias, int accumulate, void* stream) {
@@ -667,10 +682,11 @@ extern "C" int mia_norm_act_bwd(const void* dz, const void* y, void* dy, int dty
   MIA_CHECK_ARG(n > 0 && hw > 0 && c > 0 && slabs > 0, "mia_norm_act_bwd: bad shape");
   if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_norm_act_bwd: bad dtype"); return MIA_EARG; }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  bwd_reduce_launch(dz, y, dtype, scale, shift, xa, xb, n, hw, c, slope, slabs, partials, c1, c2, st);
+  MIA_CHECK_ARG(two_piece_ok(dz, dz2, y, dy, dtype, c), "mia_norm_act_bwd: two-piece gradient needs c %% 32 == 0 and aligned tensors");
+  bwd_reduce_launch(dz, dz2, y, dtype, scale, shift, xa, xb, n, hw, c, slope, slabs, partials, c1, c2, st);
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, mode, fixed_stats, scale, xa,
                      xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate, nullptr);
-  bwd_apply_launch(dz, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st);
+  bwd_apply_launch(dz, dz2, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -693,20 +709,21 @@ __global__ void bn_bwd_local_tot_kernel(int n_img, int c, int64_t hw, const floa
   }
 }
 
-extern "C" int mia_norm_act_bwd_reduce(const void* dz, const void* y, int dtype, const float* scale, const float* shift,
+extern "C" int mia_norm_act_bwd_reduce(const void* dz, const void* dz2, const void* y, int dtype, const float* scale, const float* shift,
                                        const float* xa, const float* xb, int n, int64_t hw, int c, float slope, int slabs,
                                        float* partials, float* c1, float* c2, float* tot, void* stream) {
   MIA_CHECK_ARG(dz && y && scale && shift && xa && xb && partials && c1 && c2 && tot, "mia_norm_act_bwd_reduce: null pointer");
   MIA_CHECK_ARG(n > 0 && hw > 0 && c > 0 && slabs > 0, "mia_norm_act_bwd_reduce: bad shape");
   if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_norm_act_bwd_reduce: bad dtype"); return MIA_EARG; }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  bwd_reduce_launch(dz, y, dtype, scale, shift, xa, xb, n, hw, c, slope, slabs, partials, c1, c2, st);
+  MIA_CHECK_ARG(two_piece_ok(dz, dz2, y, nullptr, dtype, c), "mia_norm_act_bwd_reduce: two-piece gradient needs c %% 32 == 0 and aligned tensors");
+  bwd_reduce_launch(dz, dz2, y, dtype, scale, shift, xa, xb, n, hw, c, slope, slabs, partials, c1, c2, st);
   hipLaunchKernelGGL(bn_bwd_local_tot_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, c1, c2, tot);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
 
-extern "C" int mia_norm_act_bwd_apply_sync(const void* dz, const void* y, void* dy, int dtype, const float* scale,
+extern "C" int mia_norm_act_bwd_apply_sync(const void* dz, const void* dz2, const void* y, void* dy, int dtype, const float* scale,
                                            const float* shift, const float* xa, const float* xb, const float* ysum, int n,
                                            int64_t hw, int c, float slope, float* c1, float* c2, const float* group_tot,
                                            float* dgamma, float* dbeta, float* dbias, int accumulate, void* stream) {
@@ -717,7 +734,8 @@ extern "C" int mia_norm_act_bwd_apply_sync(const void* dz, const void* y, void* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, NORM_BATCH, 0, scale, xa, xb,
                      ysum, c1, c2, dgamma, dbeta, dbias, accumulate, group_tot);
-  bwd_apply_launch(dz, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st);
+  MIA_CHECK_ARG(two_piece_ok(dz, dz2, y, dy, dtype, c), "mia_norm_act_bwd_apply_sync: two-piece gradient needs c %% 32 == 0 and aligned tensors");
+  bwd_apply_launch(dz, dz2, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

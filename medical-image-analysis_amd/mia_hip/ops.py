@@ -384,7 +384,13 @@ class PlainBlockFn(torch.autograd.Function):
     inputs x1 [N,H,W,C1] (+ optional x2 [N,H,W,C2], concatenated along C: unet.py:213)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, gamma, beta, stride: int, cfg: NormCfg, out_dtype=None, slope: float = LRELU_SLOPE):
+    def forward(ctx, x1, x2, weight, bias, gamma, beta, stride: int, cfg: NormCfg, out_dtype=None, slope: float = LRELU_SLOPE,
+                dup: bool = False):
+        """dup=True returns the output TWICE (two tensors on one storage): a skip tensor has two consumers, and handing
+        each its own output makes autograd deliver their gradients separately to backward, which sums them on load inside
+        the norm kernels instead of autograd launching an `add` over the full activation."""
+        ctx.dup = dup
+        ctx.set_materialize_grads(False)
         _need_dev(x1, x2, weight)
         x1 = x1.contiguous()
         x2 = None if x2 is None else x2.contiguous()
@@ -393,7 +399,8 @@ class PlainBlockFn(torch.autograd.Function):
         stem = (weight.shape[1] == 1 and x2 is None and stride == 1 and x1.shape[3] == 1 and not x1.requires_grad
                 and cout_ % (8 if out_dtype == torch.bfloat16 else 4) == 0 and cout_ <= 256)
         if stem:
-            return PlainBlockFn._stem_forward(ctx, x1, weight, bias, gamma, beta, cfg, out_dtype, slope)
+            z = PlainBlockFn._stem_forward(ctx, x1, weight, bias, gamma, beta, cfg, out_dtype, slope)
+            return (z, z.view(z.shape)) if dup else z
         if x1.dtype != out_dtype:
             x1 = cast_nhwc(x1, out_dtype)
         if x2 is not None and (x2.shape[:3] != x1.shape[:3] or x2.dtype != x1.dtype):
@@ -418,7 +425,7 @@ class PlainBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x1, x2, y, coefs, weight, gamma)
         ctx.stride, ctx.mode, ctx.fixed, ctx.stem, ctx.slope = stride, cfg.mode, fixed, False, slope
         ctx.small = (bias, beta)  # identities only (gradient destinations); values are not needed in backward
-        return z
+        return (z, z.view(z.shape)) if dup else z
 
     @staticmethod
     def _norm_act(ctx, y, stats, gamma, beta, cfg, n, cout, hw, slope=LRELU_SLOPE):
@@ -448,11 +455,16 @@ class PlainBlockFn(torch.autograd.Function):
         return z
 
     @staticmethod
-    def backward(ctx, dz):
+    def backward(ctx, *grads):
         x1, x2, y, coefs, weight, gamma = ctx.saved_tensors
-        dz = dz.contiguous()
         dtype = _dt(y)
         n, ho, wo, cout = y.shape
+        pieces = [g_.contiguous() for g_ in grads if g_ is not None]
+        if not pieces:
+            return (None,) * 11
+        dz, dz2 = pieces[0], (pieces[1] if len(pieces) > 1 else None)
+        if dz2 is not None and not (lib().mia_norm_two_piece_ok(dtype, cout) and dz.data_ptr() % 16 == 0 and dz2.data_ptr() % 16 == 0):
+            dz, dz2 = dz + dz2, None  # shapes outside the vectorised kernels: one explicit sum
         dev = y.device
         hw = ho * wo
         slabs = _slabs_for(hw)
@@ -466,15 +478,15 @@ class PlainBlockFn(torch.autograd.Function):
         dbias = dgb[2] if dbias is None else dbias
         dy = torch.empty_like(y)
         if ctx.sync is None:
-            call("mia_norm_act_bwd", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
+            call("mia_norm_act_bwd", _p(dz), _p(dz2), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
                  _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs,
                  _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
         else:  # synchronised batch norm: the group means of g and g*xhat cover every rank's shard
             tot = torch.empty((3, cout), device=dev, dtype=torch.float32)
-            call("mia_norm_act_bwd_reduce", _p(dz), _p(y), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]), n,
+            call("mia_norm_act_bwd_reduce", _p(dz), _p(dz2), _p(y), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]), n,
                  _c_i64(hw), cout, _c_float(ctx.slope), slabs, _p(part), _p(cc[0]), _p(cc[1]), _p(tot), _stream())
             ctx.sync.all_reduce_sum(tot)
-            call("mia_norm_act_bwd_apply_sync", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]),
+            call("mia_norm_act_bwd_apply_sync", _p(dz), _p(dz2), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]),
                  _p(coefs[1]), _p(coefs[4]), n, _c_i64(hw), cout, _c_float(ctx.slope), _p(cc[0]), _p(cc[1]), _p(tot),
                  _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
         cin = weight.shape[1]
@@ -484,7 +496,7 @@ class PlainBlockFn(torch.autograd.Function):
             if dw is None:
                 dw = torch.empty(weight.shape, device=dev, dtype=torch.float32)
             call("mia_stem_wgrad", _p(x1), _dt(x1), _p(dy), dtype, _p(ws), _p(dw), n, ho, wo, cout, 0, _stream())
-            return None, None, dw, dbias, dgamma, dbeta, None, None, None, None
+            return None, None, dw, dbias, dgamma, dbeta, None, None, None, None, None
         wmode = WGRAD_3S2 if ctx.stride == 2 else WGRAD_3S1
         dw = conv_wgrad(wmode, x1, x2, dy, weight.shape, cout, cin, out=grad_dest(weight))
         dx1 = dx2 = None
@@ -504,7 +516,7 @@ class PlainBlockFn(torch.autograd.Function):
                 if want:
                     sums = colsum(st.view(-1, 2 * cin)).view(cin, 2)[c1:, 0]
                     _hint_colsum(dx2, sums)
-        return dx1, dx2, dw, dbias, dgamma, dbeta, None, None, None, None
+        return dx1, dx2, dw, dbias, dgamma, dbeta, None, None, None, None, None
 
 
 class PlainBlockHeadFn(torch.autograd.Function):
@@ -821,7 +833,7 @@ class PointwiseNormFn(torch.autograd.Function):
         cc = torch.empty((2, n, cout), device=dev, dtype=torch.float32)
         dgb = torch.empty((3, cout), device=dev, dtype=torch.float32)
         dy = torch.empty_like(y)
-        call("mia_norm_act_bwd", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
+        call("mia_norm_act_bwd", _p(dz), None, _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
              _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(1.0), slabs, _p(part),
              _p(cc[0]), _p(cc[1]), _p(dgb[0]), _p(dgb[1]), _p(dgb[2]), 0, _stream())
         w4 = PointwiseNormFn._as_taps(weight, ctx.stride)
@@ -873,7 +885,7 @@ class ScaleLReLUFn(torch.autograd.Function):
         junk = torch.empty((2, c), device=dev, dtype=torch.float32)
         dv = torch.empty_like(v)
         # frozen statistics: dv = scale * dz * lrelu'(scale*v)
-        call("mia_norm_act_bwd", _p(dz), _p(v), _p(dv), _dt(v), _p(coef[0]), _p(coef[1]), _p(coef[0]), _p(coef[1]), None, n,
+        call("mia_norm_act_bwd", _p(dz), None, _p(v), _p(dv), _dt(v), _p(coef[0]), _p(coef[1]), _p(coef[0]), _p(coef[1]), None, n,
              _c_i64(h * w), c, NORM_INSTANCE, 1, _c_float(ctx.slope), slabs, _p(part), _p(cc[0]), _p(cc[1]), _p(junk[0]), _p(junk[1]),
              None, 0, _stream())
         return dv, None, None

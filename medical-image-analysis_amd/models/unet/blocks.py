@@ -97,10 +97,11 @@ class PlainBlock(nn.Module):
                                norm.num_batches_tracked, drop, sync=self.batch_sync)
         return ops.NormCfg(NORM_INSTANCE, self.training, norm.eps, 0.1, None, None, None, drop)
 
-    def forward_nhwc(self, x1, x2=None, out_dtype=None):
+    def forward_nhwc(self, x1, x2=None, out_dtype=None, dup=False):
+        """dup=True: the output twice (one storage), for a tensor with two consumers -- see ops.PlainBlockFn.forward."""
         conv, norm = self.all[0], self.all[2]
         return ops.PlainBlockFn.apply(x1, x2, conv.weight, conv.bias, norm.weight, norm.bias, self.stride,
-                                      self._cfg(x1.shape[0], x1.device), out_dtype)
+                                      self._cfg(x1.shape[0], x1.device), out_dtype, ops.LRELU_SLOPE, dup)
 
     def forward_head_nhwc(self, x1, head):
         """This block followed by the 1x1 head `head` (nn.Conv2d) in one fused node, or None when the fused kernels do

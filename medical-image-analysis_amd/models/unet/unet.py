@@ -40,9 +40,17 @@ class UNetEncoder(nn.Module):
         """x: NHWC.  A 1-channel fp32 image may be passed as is: the stem kernel reads it directly and emits
         `compute_dtype` activations (no separate cast pass)."""
         skips = []
+        last = len(self.levels) - 1
         for l, s in enumerate(self.levels):
-            x = s[1].forward_nhwc(s[0].forward_nhwc(x, out_dtype=compute_dtype if l == 0 else None))
-            skips.append(x)
+            x = s[0].forward_nhwc(x, out_dtype=compute_dtype if l == 0 else None)
+            if l < last and isinstance(s[1], PlainBlock) and torch.is_grad_enabled():
+                # a level's output feeds the next level AND the decoder: two outputs on one storage, so each consumer's
+                # gradient reaches the block separately and is summed on load in its norm backward (no `add` pass)
+                x, skip = s[1].forward_nhwc(x, dup=True)
+                skips.append(skip)
+            else:
+                x = s[1].forward_nhwc(x)
+                skips.append(x)
         return skips
 
     def forward(self, x, return_skips=False):

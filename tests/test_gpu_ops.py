@@ -347,3 +347,46 @@ def test_validation_argmax_dice_and_selector_scores(k1, layout):
     np.testing.assert_allclose(sc[:, 0].numpy(), ent.numpy(), rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(sc[:, 1].numpy(), conf.numpy(), rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(sc[:, 2].numpy(), marg.numpy(), rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+@pytest.mark.parametrize("dtype,c", [(torch.float32, 64), (torch.bfloat16, 64), (torch.float32, 96), (torch.bfloat16, 32),
+                                     (torch.float32, 24)])
+def test_plain_block_two_output_gradients_are_summed_on_load(norm, dtype, c):
+    """PlainBlockFn(dup=True) hands out its result twice (one storage); the two output gradients reach backward separately
+    and are summed inside the norm kernels (c % 32 == 0) or by one explicit add (other widths).  Must equal a single
+    backward with the pre-summed gradient."""
+    from mia_hip import NORM_BATCH, NORM_INSTANCE, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(17)
+    n, h, w, cin = 2, 24, 40, 16
+    x = nhwc(q(torch.randn(n, cin, h, w, generator=g), dtype), dtype, dev)
+    wt = (torch.randn(c, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(dev)
+    b = torch.randn(c, generator=g).to(dev)
+    ga = (1 + 0.1 * torch.randn(c, generator=g)).to(dev)
+    be = (0.1 * torch.randn(c, generator=g)).to(dev)
+    g1 = nhwc(q(torch.randn(n, c, h, w, generator=g), dtype), dtype, dev)
+    g2 = nhwc(q(torch.randn(n, c, h, w, generator=g), dtype), dtype, dev)
+
+    def cfg():
+        if norm == "batch":
+            return ops.NormCfg(NORM_BATCH, True, 1e-5, 0.1, torch.zeros(c, device=dev), torch.ones(c, device=dev),
+                               torch.zeros((), device=dev, dtype=torch.long), None)
+        return ops.NormCfg(NORM_INSTANCE, True, 1e-5, 0.1, None, None, None, None)
+
+    def run(two):
+        leaves = [t.clone().requires_grad_(True) for t in (x, wt, b, ga, be)]
+        if two:
+            za, zb = ops.PlainBlockFn.apply(leaves[0], None, leaves[1], leaves[2], leaves[3], leaves[4], 1, cfg(), None, 0.01, True)
+            assert za.data_ptr() == zb.data_ptr()
+            torch.autograd.backward([za, zb], [g1, g2])
+        else:
+            z = ops.PlainBlockFn.apply(leaves[0], None, leaves[1], leaves[2], leaves[3], leaves[4], 1, cfg())
+            z.backward((g1.float() + g2.float()).to(dtype))
+        torch.cuda.synchronize()
+        return [t.grad.float() for t in leaves]
+
+    got, want = run(True), run(False)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2  # bf16: the reference rounds g1 + g2 to bf16, the kernels sum in fp32
+    for a_, b_ in zip(got, want):
+        assert relerr(a_, b_) < tol
