@@ -90,8 +90,12 @@ class PlainBlock(nn.Module):
         if self.drop_mask_override is not None:
             drop = self.drop_mask_override.to(device=device, dtype=torch.float32).contiguous()
         elif self.dropout_prob is not None and self.training and self.dropout_prob > 0:
-            keep = 1.0 - float(self.dropout_prob)
-            drop = torch.empty((n, norm.num_features), device=device, dtype=torch.float32).bernoulli_(keep).div_(keep)
+            pooled = self.__dict__.pop("_drop_from_pool", None)  # one RNG launch per model forward (UNet._draw_dropout)
+            if pooled is not None and pooled.shape == (n, norm.num_features) and pooled.device == device:
+                drop = pooled
+            else:
+                keep = 1.0 - float(self.dropout_prob)
+                drop = torch.empty((n, norm.num_features), device=device, dtype=torch.float32).bernoulli_(keep).div_(keep)
         if self.normalization == "batch":
             return ops.NormCfg(NORM_BATCH, self.training, norm.eps, norm.momentum, norm.running_mean, norm.running_var,
                                norm.num_batches_tracked, drop, sync=self.batch_sync)

@@ -183,8 +183,25 @@ class UNet(nn.Module):
             return self.encoder.forward_nhwc(ops.to_nhwc(x, torch.float32), self.compute_dtype)
         return self.encoder.forward_nhwc(ops.to_nhwc(x, self.compute_dtype), self.compute_dtype)
 
+    def _draw_dropout(self, n: int, device) -> None:
+        """All Dropout2d channel masks of this forward ([N, C] of {0, 1/(1-p)} per PlainBlock, blocks.py:92-96) from ONE
+        Bernoulli draw instead of one RNG launch pair per block; a block without a pooled mask draws its own."""
+        if not self.training:
+            return
+        blocks = [m for m in self.modules() if isinstance(m, PlainBlock) and m.dropout_prob and m.drop_mask_override is None]
+        if len(blocks) < 2 or any(b.dropout_prob != blocks[0].dropout_prob for b in blocks):
+            return
+        keep = 1.0 - float(blocks[0].dropout_prob)
+        sizes = [n * b.all[2].num_features for b in blocks]
+        pool = torch.empty(sum(sizes), device=device, dtype=torch.float32).bernoulli_(keep).div_(keep)
+        off = 0
+        for b, sz in zip(blocks, sizes):
+            b._drop_from_pool = pool[off:off + sz].view(n, -1)
+            off += sz
+
     def forward(self, x, return_ds=False):
         ops._COLSUM_HINT.clear()  # hints are only valid inside the backward pass of the forward that produced them
+        self._draw_dropout(x.shape[0], x.device)
         return self.decoder.forward_nhwc(self._skips(x), return_ds=return_ds)
 
     def get_enc_feature(self, x):
