@@ -44,11 +44,24 @@ __global__ void norm_finalize_kernel(int n_img, int c, int64_t hw, int mode, int
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                      float* running_mean, float* running_var, long long* num_batches, float* __restrict__ xa,
                                      float* __restrict__ xb, float* __restrict__ scale, float* __restrict__ shift,
-                                     float* __restrict__ ysum, const float* __restrict__ group, int world) {
+                                     float* __restrict__ ysum, const float* __restrict__ group, int world,
+                                     const float* __restrict__ part, int tiles) {
   __shared__ double sh1[16][17], sh2[16][17];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cl;
   const double M = (double)hw;
+  if (part != nullptr && ch < c) {
+    // small problems (few images x tiles): the per-(n, c) tile sums of norm_fwd_sum_kernel are done here, by the same
+    // lane that consumes them below, and the separate launch is skipped
+    for (int n = tl; n < n_img; n += 16) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int t = 0; t < tiles; ++t) {
+        const float* p = part + (((size_t)n * tiles + t) * c + ch) * 2;
+        s1 += p[0]; s2 += p[1];
+      }
+      xa[(size_t)n * c + ch] = (float)s1; xb[(size_t)n * c + ch] = (float)s2;
+    }
+  }
   if (mode == NORM_INSTANCE) {
     if (ch < c)
       for (int n = tl; n < n_img; n += 16) {
@@ -129,9 +142,11 @@ extern "C" int mia_norm_finalize(const float* partials, int n, int tiles, int c,
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int cgroups = ceil_div(c, 16);
   const bool need_sums = mode == NORM_INSTANCE || training;
-  if (need_sums) hipLaunchKernelGGL(norm_fwd_sum_kernel, dim3(n, cgroups), dim3(256), 0, st, partials, tiles, c, xa, xb);
+  const bool inline_sums = need_sums && (int64_t)n * tiles <= 1024;  // one launch instead of two when the sums are short
+  if (need_sums && !inline_sums) hipLaunchKernelGGL(norm_fwd_sum_kernel, dim3(n, cgroups), dim3(256), 0, st, partials, tiles, c, xa, xb);
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(cgroups), dim3(256), 0, st, n, c, hw, mode, training, drop_scale, gamma, beta, eps,
-                     momentum, running_mean, running_var, num_batches, xa, xb, scale, shift, need_sums ? ysum : nullptr, nullptr, 0);
+                     momentum, running_mean, running_var, num_batches, xa, xb, scale, shift, need_sums ? ysum : nullptr, nullptr, 0,
+                     inline_sums ? partials : nullptr, tiles);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -184,7 +199,7 @@ extern "C" int mia_norm_finalize_sync(const float* gathered, int world, int n, i
                 "mia_norm_finalize_sync: bad arguments");
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, static_cast<hipStream_t>(stream), n, c, hw,
                      NORM_BATCH, 1, drop_scale, gamma, beta, eps, momentum, running_mean, running_var, num_batches, xa, xb, scale,
-                     shift, ysum, gathered, world);
+                     shift, ysum, gathered, world, nullptr, 0);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -542,11 +557,21 @@ __global__ void norm_bwd_finalize_kernel(int n_img, int c, int64_t hw, int mode,
                                          const float* __restrict__ xa, const float* __restrict__ xb, const float* __restrict__ ysum,
                                          float* __restrict__ c1, float* __restrict__ c2, float* __restrict__ dgamma,
                                          float* __restrict__ dbeta, float* __restrict__ dbias, int accumulate,
-                                         const float* __restrict__ group_tot) {
+                                         const float* __restrict__ group_tot, const float* __restrict__ part, int slabs) {
   __shared__ double sh1[16][17], sh2[16][17], sh3[16][17];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cl;
   const double M = (double)hw;
+  if (part != nullptr && ch < c) {  // short sums: norm_bwd_sum_kernel's work done inline (see norm_finalize_kernel)
+    for (int n = tl; n < n_img; n += 16) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int t = 0; t < slabs; ++t) {
+        const float* p = part + (((size_t)n * slabs + t) * c + ch) * 2;
+        s1 += p[0]; s2 += p[1];
+      }
+      c1[(size_t)n * c + ch] = (float)s1; c2[(size_t)n * c + ch] = (float)s2;
+    }
+  }
   double tg = 0.0, tgx = 0.0;
   if (ch < c)
     for (int n = tl; n < n_img; n += 16) { tg += c1[(size_t)n * c + ch]; tgx += c2[(size_t)n * c + ch]; }
@@ -625,7 +650,7 @@ static bool bwd_vec_ok(const void* dz, const void* y, const void* dy, int dtype,
 // pass 1: slab partials of (sum g, sum g*xhat), then per-(n,c) sums parked in c1 / c2
 static void bwd_reduce_launch(const void* dz, const void* dz2, const void* y, int dtype, const float* scale, const float* shift, const float* xa,
                               const float* xb, int n, int64_t hw, int c, float slope, int slabs, float* partials, float* c1,
-                              float* c2, hipStream_t st) {
+                              float* c2, hipStream_t st, bool do_sum = true) {
   const bool vec = bwd_vec_ok(dz, y, nullptr, dtype, c);
 #define RD(T) hipLaunchKernelGGL(norm_act_bwd_reduce_kernel<T>, dim3(n * slabs, ceil_div(c, 256)), dim3(256), 512 * sizeof(float), st,   \
                                  static_cast<const T*>(dz), static_cast<const T*>(y), scale, shift, xa, xb, hw, c, slabs, \
@@ -637,7 +662,7 @@ static void bwd_reduce_launch(const void* dz, const void* dz2, const void* y, in
       CRV(float, true, static_cast<const float*>(dz), static_cast<const float*>(y), static_cast<const float*>(dz2), scale, shift, xa, xb, slope);
   } else if (dtype == MIA_BF16) RD(bf16_t); else RD(float);
 #undef RD
-  hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3(n, ceil_div(c, 16)), dim3(256), 0, st, partials, slabs, c, c1, c2);
+  if (do_sum) hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3(n, ceil_div(c, 16)), dim3(256), 0, st, partials, slabs, c, c1, c2);
 }
 
 // pass 2: dy from the finalized group means
@@ -683,9 +708,10 @@ extern "C" int mia_norm_act_bwd(const void* dz, const void* dz2, const void* y, 
   if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_norm_act_bwd: bad dtype"); return MIA_EARG; }
   hipStream_t st = static_cast<hipStream_t>(stream);
   MIA_CHECK_ARG(two_piece_ok(dz, dz2, y, dy, dtype, c), "mia_norm_act_bwd: two-piece gradient needs c %% 32 == 0 and aligned tensors");
-  bwd_reduce_launch(dz, dz2, y, dtype, scale, shift, xa, xb, n, hw, c, slope, slabs, partials, c1, c2, st);
+  const bool inline_sums = (int64_t)n * slabs <= 1024;  // short slab sums are folded into the finalize launch
+  bwd_reduce_launch(dz, dz2, y, dtype, scale, shift, xa, xb, n, hw, c, slope, slabs, partials, c1, c2, st, !inline_sums);
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, mode, fixed_stats, scale, xa,
-                     xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate, nullptr);
+                     xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate, nullptr, inline_sums ? partials : nullptr, slabs);
   bwd_apply_launch(dz, dz2, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
@@ -733,7 +759,7 @@ extern "C" int mia_norm_act_bwd_apply_sync(const void* dz, const void* dz2, cons
   if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_norm_act_bwd_apply_sync: bad dtype"); return MIA_EARG; }
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, NORM_BATCH, 0, scale, xa, xb,
-                     ysum, c1, c2, dgamma, dbeta, dbias, accumulate, group_tot);
+                     ysum, c1, c2, dgamma, dbeta, dbias, accumulate, group_tot, nullptr, 0);
   MIA_CHECK_ARG(two_piece_ok(dz, dz2, y, dy, dtype, c), "mia_norm_act_bwd_apply_sync: two-piece gradient needs c %% 32 == 0 and aligned tensors");
   bwd_apply_launch(dz, dz2, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st);
   MIA_LAUNCH_CHECK();
@@ -862,9 +888,10 @@ extern "C" int mia_norm_act_bwd_head(const float* dlogits, const float* w, int k
   else { if (dtype == MIA_BF16) CRHK(bf16_t, 32); else CRHK(float, 32); }
 #undef CRHK
 #undef CRH
-  hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3(n, ceil_div(c, 16)), dim3(256), 0, st, partials, slabs, c, c1, c2);
+  const bool inline_sums = (int64_t)n * slabs <= 1024;
+  if (!inline_sums) hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3(n, ceil_div(c, 16)), dim3(256), 0, st, partials, slabs, c, c1, c2);
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, mode, fixed_stats, scale, xa,
-                     xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate, nullptr);
+                     xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate, nullptr, inline_sums ? partials : nullptr, slabs);
   int sl, upb, gy;
   stream_geometry(n, hw, c, epu, &sl, &upb, &gy);
 #define BSH(T, K) hipLaunchKernelGGL((norm_act_bwd_stream_head_kernel<T, K>), dim3(n * sl, gy), dim3(256), 0, st, dlogits, w, \
