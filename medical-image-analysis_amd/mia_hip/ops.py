@@ -363,7 +363,7 @@ def _norm_finalize(cfg: NormCfg, stats, gamma, beta, n, cout, hw, coefs):
     """Per-(n,c) coefficients from the conv-epilogue partials; batch statistics cover every rank when cfg.sync is set."""
     sync = cfg.sync if (cfg.sync is not None and cfg.mode == NORM_BATCH and cfg.training and cfg.sync.world > 1) else None
     if sync is None:
-        call("mia_norm_finalize", _p(stats), n, stats.shape[1], cout, _c_i64(hw), cfg.mode, int(cfg.training),
+        call("mia_norm_finalize", _p(stats), n, 0 if stats is None else stats.shape[1], cout, _c_i64(hw), cfg.mode, int(cfg.training),
              _p(cfg.drop_scale), _p(gamma.detach()), _p(beta.detach()), _c_float(cfg.eps), _c_float(cfg.momentum),
              _p(cfg.running_mean), _p(cfg.running_var), _p(cfg.num_batches), _p(coefs[0]), _p(coefs[1]), _p(coefs[2]),
              _p(coefs[3]), _p(coefs[4]), _stream())
@@ -414,10 +414,10 @@ class PlainBlockFn(torch.autograd.Function):
         ho, wo = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
         wp, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=True)
         mode = CONV_G3S2 if stride == 2 else CONV_G3S1
-        y, _, stats = conv_mma(mode, x1, x2, wp, npad, kpad, False, bias.detach().float(), cout, (ho, wo), want_stats=True)
+        fixed = cfg.mode == NORM_BATCH and not cfg.training  # eval batch norm: running statistics, no batch sums needed
+        y, _, stats = conv_mma(mode, x1, x2, wp, npad, kpad, False, bias.detach().float(), cout, (ho, wo), want_stats=not fixed)
         dev = x1.device
         coefs = torch.empty((5, n, cout), device=dev, dtype=torch.float32)  # xa, xb, scale, shift, sum_y
-        fixed = cfg.mode == NORM_BATCH and not cfg.training
         ctx.sync = _norm_finalize(cfg, stats, gamma, beta, n, cout, ho * wo, coefs)
         z = torch.empty_like(y)
         call("mia_norm_act_fwd", _p(y), _p(z), dtype, _p(coefs[2]), _p(coefs[3]), n, _c_i64(ho * wo), cout,
@@ -546,7 +546,8 @@ class PlainBlockHeadFn(torch.autograd.Function):
         if weight.shape[1] != c1:
             raise RuntimeError(f"conv weight expects {weight.shape[1]} input channels, got {c1}")
         wp, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=True)
-        y, _, stats = conv_mma(CONV_G3S1, x1, None, wp, npad, kpad, False, bias.detach().float(), cout, (h, w), want_stats=True)
+        fixed = cfg.mode == NORM_BATCH and not cfg.training
+        y, _, stats = conv_mma(CONV_G3S1, x1, None, wp, npad, kpad, False, bias.detach().float(), cout, (h, w), want_stats=not fixed)
         coefs = torch.empty((5, n, cout), device=x1.device, dtype=torch.float32)  # xa, xb, scale, shift, sum_y
         ctx.sync = _norm_finalize(cfg, stats, gamma, beta, n, cout, h * w, coefs)
         w2 = head_w.detach().reshape(k1, cout).contiguous()
