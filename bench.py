@@ -175,6 +175,32 @@ def main():
         return "other_3x3"      # every other 3x3 / stride-1 launch (forward and input-gradient) of the same kernel family
 
     probe = ops.LaunchProbe(_match)
+
+    # HBM-bound streams (norm + activation forward, norm backward = reduce + apply): HIP events around the C-ABI call
+    # on the launch stream, algorithmic bytes from the call's own shape arguments
+    stream_log = {"norm_act_fwd": [], "norm_act_bwd": []}
+    stream_on = [False]
+    raw_call = ops.call
+
+    def timed_call(name, *cargs):
+        key = {"mia_norm_act_fwd": "norm_act_fwd", "mia_norm_act_bwd": "norm_act_bwd"}.get(name) if stream_on[0] else None
+        if key is None:
+            return raw_call(name, *cargs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        raw_call(name, *cargs)
+        e1.record()
+        val = lambda v: getattr(v, "value", v)
+        if key == "norm_act_fwd":   # (y, z, dtype, scale, shift, n, hw, c, slope, stream): read y, write z
+            es = 2 if cargs[2] == 1 else 4
+            nbytes = 2.0 * val(cargs[5]) * val(cargs[6]) * val(cargs[7]) * es
+        else:                       # (dz, dz2, y, dy, dtype, ..., n, hw, c, ...): reduce reads dz (+dz2), y; apply reads them again, writes dy
+            es = 2 if cargs[4] == 1 else 4
+            pieces = 2 if cargs[1] is not None else 1
+            nbytes = (2.0 * (pieces + 1) + 1.0) * val(cargs[10]) * val(cargs[11]) * val(cargs[12]) * es
+        stream_log[key].append((e0, e1, nbytes))
+
+    ops.call = timed_call
     ops.PROBE = probe
 
     def sync():
@@ -187,12 +213,14 @@ def main():
         loss = eng.train_step(batch_d)
     sync()
     probe.enabled = True
+    stream_on[0] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = eng.train_step(batch_d)
     sync()
     elapsed = time.perf_counter() - t0
     probe.enabled = False
+    stream_on[0] = False
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -228,6 +256,16 @@ def main():
             roof["all_3x3_s1_launches"] = {"launches": len(recs), "avg_launch_ms": round(1e3 * tm / len(recs), 4),
                                            "achieved": round(fl / tm / 1e12, 2), "unit": "TFLOP/s",
                                            "frac": round(fl / tm / 1e12 / PEAK_MFMA_TFLOPS[dt], 4)}
+        if roof is not None:
+            torch.cuda.synchronize()
+            hbm = {}
+            for key, recs in stream_log.items():
+                if recs:
+                    tm = sum(a.elapsed_time(b) for a, b, _ in recs) * 1e-3
+                    by = sum(r[2] for r in recs)
+                    hbm[key] = {"launches": len(recs), "achieved": round(by / tm / 1e9, 1), "unit": "GB/s", "peak": PEAK_HBM_GBS,
+                                "frac": round(by / tm / 1e9 / PEAK_HBM_GBS, 4)}
+            roof["hbm_streams"] = hbm
         out = {"metric": "training images/sec (whole node), UNet 512x512 1ch bs=32/GPU", "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
