@@ -138,12 +138,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # MIA_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on ONE GPU (RCCL refuses two ranks on one device); every rank
+    # then uses device 0.  The driver's runs use the default, RCCL with one GPU per rank.
+    backend = os.environ.get("MIA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from losses.compound_losses import DiceAndCELoss
     from losses.dice_loss import DiceLoss
