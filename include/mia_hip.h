@@ -152,6 +152,10 @@ int mia_head_bwd(const float* dlogits, const void* x, int dtype, const float* w,
 #define MIA_LOSS_DO_BG 2
 #define MIA_LOSS_BATCH 4
 #define MIA_LOSS_SQUARED 8
+#define MIA_LOSS_DENSE 16 /* `labels` is a dense fp32 target [B][K1][HW] (already one-hot / class probabilities) instead of int64
+                           * indices: DiceLoss skips its one-hot encoder when shapes match (dice_loss.py:40-41) and
+                           * torch.nn.CrossEntropyLoss treats such a target as probabilities.  Pass the float pointer cast to
+                           * `const long long*`; same strides as the logits (sn, sk, sp). */
 /* out[0] = ce_w*CE + dice_w*Dice, out[1] = CE (mean over pixels), out[2] = Dice
  * (DiceLoss.forward dice_loss.py:32-76, DiceAndCELoss.forward compound_losses.py:33-49).
  * sums [B][K1][3] = (I, sum p, sum t); coef [B][K1][2] feeds the backward; *bad_label set on label outside [0,K1). */

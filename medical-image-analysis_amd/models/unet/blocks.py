@@ -50,7 +50,7 @@ class Upsample(nn.Module):
         self.align_corners, self.mode, self.scale_factor, self.size = align_corners, mode, scale_factor, size
 
     def forward(self, x):
-        from transforms import functional_hip as FH
+        from transforms.hip import functional_hip as FH
         n, c, h, w = x.shape
         if self.size is not None:
             oh, ow = (self.size, self.size) if isinstance(self.size, int) else self.size

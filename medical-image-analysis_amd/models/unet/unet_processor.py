@@ -19,7 +19,7 @@ class UnetProcessor:
         self.image_size = image_size
 
     def preprocess(self, X: torch.Tensor):
-        from transforms import functional_hip as FH
+        from transforms.hip import functional_hip as FH
         image = X
         if image.ndim == 3:
             image = image.unsqueeze(0)
@@ -28,7 +28,7 @@ class UnetProcessor:
         return image
 
     def postprocess(self, P: torch.Tensor, ori_shape, do_denoise: bool = False):
-        from transforms import functional_hip as FH
+        from transforms.hip import functional_hip as FH
         masks = P
         if masks.ndim == 2:
             masks = masks.unsqueeze(0)

@@ -1,167 +1,6 @@
-"""Tensor-level wrappers of the augmentation / resize / normalisation kernels (libmia_hip).
+"""Alias of `transforms.hip.functional_hip` (the module object itself, so every name -- private helpers included -- is shared)."""
+import sys
 
-Batched: images ``[B, C, H, W]`` fp32, labels ``[B, H, W]`` int64 on a HIP device; per-sample
-parameters as Python lists (uploaded as tiny device arrays); ``apply`` = list of bools (None = all).
-"""
-from __future__ import annotations
+from .hip import functional_hip as _impl
 
-import ctypes
-from typing import Optional, Sequence
-
-import torch
-
-from mia_hip import MiaError, call, lib
-from mia_hip.ops import _c_float, _c_i64, _need_dev, _p, _stream
-
-EW_GAMMA, EW_CONTRAST, EW_NOISE, EW_ZSCORE = 0, 1, 2, 3
-
-
-def _f32(x: torch.Tensor) -> torch.Tensor:
-    _need_dev(x)
-    if x.dtype != torch.float32:
-        x = x.float()
-    return x.contiguous()
-
-
-def _dev_f(vals, dev):
-    return torch.tensor(list(vals), dtype=torch.float32, device=dev)
-
-
-def _dev_i(vals, dev):
-    return torch.tensor([int(v) for v in vals], dtype=torch.int32, device=dev)
-
-
-def _apply(apply, dev):
-    return None if apply is None else _dev_i(apply, dev)
-
-
-def affine_nearest(img: Optional[torch.Tensor], lab: Optional[torch.Tensor], mats: Sequence[Sequence[float]], apply=None):
-    """torchvision F.affine / F.rotate tensor path (nearest, zero fill) on image and label in one launch."""
-    ref = img if img is not None else lab
-    dev = ref.device
-    b, h, w = ref.shape[0], ref.shape[-2], ref.shape[-1]
-    c = img.shape[1] if img is not None else 1
-    io = oi = lo = ol = None
-    if img is not None:
-        io = _f32(img)
-        oi = torch.empty_like(io)
-    if lab is not None:
-        _need_dev(lab)
-        lo = lab.long().contiguous()
-        ol = torch.empty_like(lo)
-    m = torch.tensor([list(r) for r in mats], dtype=torch.float32, device=dev).reshape(b, 6)
-    ap = _apply(apply, dev)
-    call("mia_affine_nearest", _p(io), _p(oi), _p(lo), _p(ol), b, c, h, w, _p(m), _p(ap), _stream())
-    return oi, ol
-
-
-def rot90_flip(x: torch.Tensor, k: int = 0, flip_h: bool = False, flip_w: bool = False) -> torch.Tensor:
-    """torch.rot90(x, k, (-2, -1)) followed by optional flips of H / W, for 4- or 8-byte dtypes."""
-    _need_dev(x)
-    x = x.contiguous()
-    if x.element_size() not in (4, 8):
-        raise MiaError("rot90_flip supports 4- or 8-byte element types")
-    h, w = x.shape[-2], x.shape[-1]
-    planes = x.numel() // (h * w)
-    oshape = list(x.shape)
-    if k % 2:
-        oshape[-2], oshape[-1] = w, h
-    out = torch.empty(oshape, device=x.device, dtype=x.dtype)
-    call("mia_rot90_flip", _p(x), _p(out), x.element_size(), 1, planes, h, w, int(k) % 4, int(flip_h), int(flip_w), _stream())
-    return out
-
-
-def gaussian_blur(img: torch.Tensor, sigma: Sequence[float], ksize: Sequence[int], apply=None) -> torch.Tensor:
-    x = _f32(img)
-    b, c, h, w = x.shape
-    out = torch.empty_like(x)
-    sg, ks, ap = _dev_f(sigma, x.device), _dev_i(ksize, x.device), _apply(apply, x.device)  # keep alive across the launch
-    call("mia_gaussian_blur", _p(x), _p(out), b, c, h, w, _p(sg), _p(ks), int(max(ksize)), _p(ap), _stream())
-    return out
-
-
-def sample_stats(img: torch.Tensor, gray: bool = False) -> torch.Tensor:
-    """[B, 2] = per-sample (mean, unbiased std) over C*H*W (luma image if gray and C == 3)."""
-    x = _f32(img)
-    b, c, h, w = x.shape
-    ws = torch.empty(lib().mia_sample_stats_workspace(b), device=x.device, dtype=torch.float32)
-    out = torch.empty((b, 2), device=x.device, dtype=torch.float32)
-    call("mia_sample_stats", _p(x), b, c, _c_i64(h * w), int(gray), _p(ws), _p(out), _stream())
-    return out
-
-
-def elementwise(img: torch.Tensor, op: int, p0=None, mean_std: Optional[torch.Tensor] = None,
-                aux: Optional[torch.Tensor] = None, apply=None) -> torch.Tensor:
-    x = _f32(img)
-    b = x.shape[0]
-    out = torch.empty_like(x)
-    pp = None if p0 is None else _dev_f(p0, x.device)
-    if aux is not None:
-        aux = _f32(aux)
-    ap = _apply(apply, x.device)
-    call("mia_elementwise", _p(x), _p(out), _c_i64(x.numel() // b), b, op, _p(pp), _p(mean_std), _p(aux), _p(ap), _stream())
-    return out
-
-
-def noise_clip(img: torch.Tensor, sigma: Sequence[float], seed: int, offset: int = 0, apply=None) -> torch.Tensor:
-    x = _f32(img)
-    b = x.shape[0]
-    out = torch.empty_like(x)
-    sg, ap = _dev_f(sigma, x.device), _apply(apply, x.device)
-    call("mia_noise_clip", _p(x), _p(out), _c_i64(x.numel() // b), b, _p(sg), ctypes.c_uint64(seed), ctypes.c_uint64(offset),
-         _p(ap), _stream())
-    return out
-
-
-def resize_bilinear(img: torch.Tensor, oh: int, ow: int, antialias: bool = False) -> torch.Tensor:
-    """interpolate(bilinear, align_corners=False[, antialias]) on [B, C, H, W]."""
-    x = _f32(img)
-    b, c, h, w = x.shape
-    out = torch.empty((b, c, oh, ow), device=x.device, dtype=torch.float32)
-    if antialias and (oh < h or ow < w):
-        tmp = torch.empty((b, c, h, ow), device=x.device, dtype=torch.float32)
-        call("mia_resize_bilinear_aa", _p(x), _p(tmp), _p(out), b, c, h, w, oh, ow, _stream())
-    else:
-        call("mia_resize_bilinear", _p(x), _p(out), b, c, h, w, oh, ow, None, None, _stream())
-    return out
-
-
-def lowres(img: torch.Tensor, low_hw: Sequence[Sequence[int]], apply=None) -> torch.Tensor:
-    """SimulateLowRes: nearest-exact down to low_hw[b], bilinear back up, fused."""
-    x = _f32(img)
-    b, c, h, w = x.shape
-    out = torch.empty_like(x)
-    lw = torch.tensor([[int(a), int(d)] for a, d in low_hw], dtype=torch.int32, device=x.device)
-    ap = _apply(apply, x.device)
-    call("mia_resize_bilinear", _p(x), _p(out), b, c, h, w, h, w, _p(lw), _p(ap), _stream())
-    return out
-
-
-def resize_nearest(x: torch.Tensor, oh: int, ow: int) -> torch.Tensor:
-    """interpolate(nearest) on the last two dims; float32 images or int64 label maps."""
-    _need_dev(x)
-    if x.dtype not in (torch.float32, torch.int64, torch.int32):
-        x = x.float() if x.is_floating_point() else x.long()
-    x = x.contiguous()
-    h, w = x.shape[-2], x.shape[-1]
-    planes = x.numel() // (h * w)
-    out = torch.empty(list(x.shape[:-2]) + [oh, ow], device=x.device, dtype=x.dtype)
-    call("mia_resize_nearest", _p(x), _p(out), x.element_size(), _c_i64(planes), h, w, oh, ow, _stream())
-    return out
-
-
-class ResizeBilinearFn(torch.autograd.Function):
-    """Differentiable bilinear resize (deep-supervision ``Upsample``, reference blocks.py:45-63, unet.py:193-197)."""
-
-    @staticmethod
-    def forward(ctx, x, oh, ow):
-        ctx.in_shape = tuple(x.shape)
-        return resize_bilinear(x, int(oh), int(ow))
-
-    @staticmethod
-    def backward(ctx, dout):
-        b, c, h, w = ctx.in_shape
-        d = _f32(dout)
-        din = torch.zeros((b, c, h, w), device=d.device, dtype=torch.float32)
-        call("mia_resize_bilinear_bwd", _p(d), _p(din), b, c, h, w, d.shape[2], d.shape[3], _stream())
-        return din, None, None
+sys.modules[__name__] = _impl

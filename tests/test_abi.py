@@ -20,6 +20,20 @@ def test_library_exports_every_declared_symbol():
     assert mia_hip.lib().mia_version() >= 100
 
 
+def test_python_constants_match_header_defines():
+    """Every enum / flag the ctypes side passes is declared in include/mia_hip.h with the same value."""
+    d = mia_hip.parse_defines()
+    pairs = {"MIA_F32": mia_hip.F32, "MIA_BF16": mia_hip.BF16, "MIA_NORM_INSTANCE": mia_hip.NORM_INSTANCE,
+             "MIA_NORM_BATCH": mia_hip.NORM_BATCH, "MIA_LOSS_SOFTMAX": mia_hip.LOSS_SOFTMAX, "MIA_LOSS_DO_BG": mia_hip.LOSS_DO_BG,
+             "MIA_LOSS_BATCH": mia_hip.LOSS_BATCH, "MIA_LOSS_SQUARED": mia_hip.LOSS_SQUARED, "MIA_LOSS_DENSE": mia_hip.LOSS_DENSE,
+             "MIA_OPT_ADAM": mia_hip.OPT_ADAM, "MIA_OPT_ADAMW": mia_hip.OPT_ADAMW, "MIA_OPT_SGD": mia_hip.OPT_SGD,
+             "MIA_CONV_G3S1": mia_hip.CONV_G3S1, "MIA_CONV_G3S2": mia_hip.CONV_G3S2, "MIA_CONV_G2S2": mia_hip.CONV_G2S2,
+             "MIA_CONV_T3S2": mia_hip.CONV_T3S2, "MIA_CONV_T2S2": mia_hip.CONV_T2S2, "MIA_CONV_G1": mia_hip.CONV_G1,
+             "MIA_WGRAD_3S1": mia_hip.WGRAD_3S1, "MIA_WGRAD_3S2": mia_hip.WGRAD_3S2, "MIA_WGRAD_2S2": mia_hip.WGRAD_2S2}
+    for name, val in pairs.items():
+        assert d.get(name) == val, (name, d.get(name), val)
+
+
 def test_argument_errors_are_reported_without_a_gpu():
     l = mia_hip.lib()
     rc = l.mia_conv_mma(99, 0, None, 0, None, 0, None, 0, 0, 0, None, None, 0, None, 0, None, 1, 1, 1, 1, 1, None)
