@@ -658,7 +658,7 @@ __global__ void dice_ce_fwd_kernel(const float* __restrict__ logits, const long 
       if (k < k1) { v[k] = base[p * g.sp + k * g.sk]; mx = fmaxf(mx, v[k]); }
     const float* dense = reinterpret_cast<const float*>(labels) + (int64_t)b * k1 * hw + p;
     const long long lab = (flags & LF_DENSE) ? 0 : labels[(int64_t)b * hw + p];
-    if (lab < 0 || lab >= k1) { *bad_label = 1; continue; }
+    if (lab < 0 || lab >= k1) { *bad_label = 1; continue; }  // finalize poisons the loss with NaN (see there)
     float pr[MAXK];
     float se = 0.f;
 #pragma unroll
@@ -688,11 +688,147 @@ __global__ void dice_ce_fwd_kernel(const float* __restrict__ logits, const long 
   if (threadIdx.x == 0) cepart[(size_t)b * slabs + s] = r;
 }
 
+
+// Fast path: channels-last logits (class stride 1, pixel stride K1), int64 index labels, K1 in {2,3,4}, hw % 4 == 0.
+// A thread owns FOUR consecutive pixels per step: K1 16-byte loads of logits + two 16-byte loads of labels (the generic
+// kernel issues K1 + 2 four-byte loads per pixel), two steps in flight.  One block = one slab of one image; all 3*K1+1
+// block sums share ONE barrier (per-wave DPP sums -> LDS -> 3*K1+1 threads add four waves).
+template <int K1>
+__global__ __launch_bounds__(256) void dice_ce_fwd_fast_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                               int hw, int flags, int slabs, float* __restrict__ part,
+                                                               float* __restrict__ cepart, int* __restrict__ bad_label) {
+  constexpr int NV = 3 * K1 + 1;
+  __shared__ float red[4][NV];
+  const int b = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  const int quads = hw >> 2;
+  const int per = (quads + slabs - 1) / slabs, q0 = s * per, q1 = q0 + per < quads ? q0 + per : quads;
+  const f32x4* lg = reinterpret_cast<const f32x4*>(logits + (size_t)b * hw * K1);
+  const u32x4* lb = reinterpret_cast<const u32x4*>(labels + (size_t)b * hw);
+  float si[K1], sp[K1], st[K1], ce = 0.f;
+#pragma unroll
+  for (int k = 0; k < K1; ++k) { si[k] = 0.f; sp[k] = 0.f; st[k] = 0.f; }
+  bool bad = false;
+  auto one = [&](const f32x4* f, const u32x4& l0, const u32x4& l1) {
+    const unsigned lo[4] = {l0[0], l0[2], l1[0], l1[2]}, hi[4] = {l0[1], l0[3], l1[1], l1[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[K1];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < K1; ++k) { v[k] = f[(j * K1 + k) >> 2][(j * K1 + k) & 3]; mx = fmaxf(mx, v[k]); }
+      const bool ok = hi[j] == 0u && lo[j] < (unsigned)K1;
+      bad |= !ok;
+      float pr[K1], se = 0.f;
+#pragma unroll
+      for (int k = 0; k < K1; ++k) { pr[k] = __expf(v[k] - mx); se += pr[k]; }
+      const float inv = ok ? 1.f / se : 0.f;   // an out-of-range label drops the pixel (and poisons the loss in finalize)
+      const float lse = mx + __logf(se);
+#pragma unroll
+      for (int k = 0; k < K1; ++k) {
+        const float pk = (flags & LF_SOFTMAX) ? pr[k] * inv : (ok ? v[k] : 0.f);
+        const float t = (ok && lo[j] == (unsigned)k) ? 1.f : 0.f;
+        si[k] += pk * t;
+        sp[k] += (flags & LF_SQUARED) ? pk * pk : pk;
+        st[k] += t;
+        ce += t * (lse - v[k]);
+      }
+    }
+  };
+  int q = q0 + threadIdx.x;
+  for (; q + 256 < q1; q += 512) {
+    f32x4 fa[K1], fb[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) { fa[k] = lg[(size_t)q * K1 + k]; fb[k] = lg[(size_t)(q + 256) * K1 + k]; }
+    const u32x4 a0 = lb[2 * (size_t)q], a1 = lb[2 * (size_t)q + 1], b0 = lb[2 * (size_t)(q + 256)], b1 = lb[2 * (size_t)(q + 256) + 1];
+    one(fa, a0, a1);
+    one(fb, b0, b1);
+  }
+  if (q < q1) {
+    f32x4 fa[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) fa[k] = lg[(size_t)q * K1 + k];
+    const u32x4 a0 = lb[2 * (size_t)q], a1 = lb[2 * (size_t)q + 1];
+    one(fa, a0, a1);
+  }
+  if (bad) *bad_label = 1;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < K1; ++k) {
+    const float a = wave_sum(si[k]), c = wave_sum(sp[k]), d = wave_sum(st[k]);
+    if (l == 0) { red[w][3 * k] = a; red[w][3 * k + 1] = c; red[w][3 * k + 2] = d; }
+  }
+  ce = wave_sum(ce);
+  if (l == 0) red[w][3 * K1] = ce;
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const float r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < 3 * K1) part[((size_t)b * slabs + s) * K1 * 3 + threadIdx.x] = r;
+    else cepart[(size_t)b * slabs + s] = r;
+  }
+}
+
+template <int K1>
+__global__ __launch_bounds__(256) void dice_ce_bwd_fast_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                               const float* __restrict__ coef, const float* __restrict__ gout,
+                                                               float* __restrict__ dl, int nb, int hw, int flags, float dice_w,
+                                                               float ce_w) {
+  const int b = blockIdx.y;
+  const int quads = hw >> 2;
+  const float go_s = gout ? gout[0] : 1.f;
+  const float cew = go_s * ce_w / (float)((double)nb * (double)hw);
+  float al[K1], be[K1];
+#pragma unroll
+  for (int k = 0; k < K1; ++k) { al[k] = go_s * dice_w * coef[((size_t)b * K1 + k) * 2]; be[k] = go_s * dice_w * coef[((size_t)b * K1 + k) * 2 + 1]; }
+  const f32x4* lg = reinterpret_cast<const f32x4*>(logits + (size_t)b * hw * K1);
+  const u32x4* lb = reinterpret_cast<const u32x4*>(labels + (size_t)b * hw);
+  f32x4* dst = reinterpret_cast<f32x4*>(dl + (size_t)b * hw * K1);
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < quads; q += gridDim.x * 256) {
+    f32x4 f[K1], o[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) f[k] = lg[(size_t)q * K1 + k];
+    const u32x4 l0 = lb[2 * (size_t)q], l1 = lb[2 * (size_t)q + 1];
+    const unsigned lo[4] = {l0[0], l0[2], l1[0], l1[2]}, hi[4] = {l0[1], l0[3], l1[1], l1[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[K1], pr[K1], gk[K1];
+      float mx = -INFINITY, se = 0.f, dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < K1; ++k) { v[k] = f[(j * K1 + k) >> 2][(j * K1 + k) & 3]; mx = fmaxf(mx, v[k]); }
+#pragma unroll
+      for (int k = 0; k < K1; ++k) { pr[k] = __expf(v[k] - mx); se += pr[k]; }
+      const bool ok = hi[j] == 0u && lo[j] < (unsigned)K1;
+      const float inv = 1.f / se;
+#pragma unroll
+      for (int k = 0; k < K1; ++k) {
+        pr[k] *= inv;
+        const float pk = (flags & LF_SOFTMAX) ? pr[k] : v[k];
+        const float t = (lo[j] == (unsigned)k) ? 1.f : 0.f;
+        gk[k] = al[k] * t + be[k] * ((flags & LF_SQUARED) ? 2.f * pk : 1.f);
+        dot += gk[k] * pr[k];
+      }
+#pragma unroll
+      for (int k = 0; k < K1; ++k) {
+        const float t = (lo[j] == (unsigned)k) ? 1.f : 0.f;
+        const float dd = (flags & LF_SOFTMAX) ? pr[k] * (gk[k] - dot) : gk[k];
+        o[(j * K1 + k) >> 2][(j * K1 + k) & 3] = ok ? dd + cew * (pr[k] - t) : 0.f;  // dropped pixel: same as the forward
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K1; ++k) dst[(size_t)q * K1 + k] = o[k];
+  }
+}
+
+static bool dice_ce_fast_ok(const void* logits, const void* labels, int64_t hw, int k1, int64_t sn, int64_t sk, int64_t sp, int flags) {
+  return !(flags & LF_DENSE) && k1 >= 2 && k1 <= 4 && sk == 1 && sp == k1 && sn == hw * k1 && (hw & 3) == 0 && hw < ((int64_t)1 << 30) &&
+         (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && (reinterpret_cast<uintptr_t>(labels) & 15) == 0;
+}
+
 // finalize: sums[b][k][3]; coef[b][k][2] = (alpha, beta) with dDice/dp_k(pixel) = alpha*t (+2p*... if squared) + beta
 // out[0] = total loss, out[1] = ce, out[2] = dice
 __global__ void dice_ce_finalize_kernel(const float* __restrict__ part, const float* __restrict__ cepart, int nb, int slabs,
                                         int k1, int64_t hw, int flags, float smooth, float dice_w, float ce_w,
-                                        float* __restrict__ sums, float* __restrict__ coef, float* __restrict__ out) {
+                                        float* __restrict__ sums, float* __restrict__ coef, float* __restrict__ out,
+                                        const int* __restrict__ bad_label) {
   // single block; thread -> (b,k)
   __shared__ double dsum[256];
   __shared__ double cesum[256];
@@ -746,6 +882,16 @@ __global__ void dice_ce_finalize_kernel(const float* __restrict__ part, const fl
     c /= ((double)nb * (double)hw);
     out[1] = (float)c; out[2] = (float)d;
     out[0] = (float)(ce_w * c + dice_w * d);
+  }
+  // A label outside [0, K1): the reference raises (scatter index error in DiceLoss, dice_loss.py:25-30; target bound check
+  // in CrossEntropyLoss).  A device kernel cannot raise, so the result is made unusable instead of silently training on
+  // such masks: loss values and the backward coefficients (hence every gradient) become NaN; ops.DiceCEFn.check_labels()
+  // turns the flag into an exception at the caller's next host sync.
+  __syncthreads();
+  if (*bad_label) {
+    const float qn = __builtin_nanf("");
+    if (threadIdx.x < 3) out[threadIdx.x] = qn;
+    for (int i = threadIdx.x; i < total * 2; i += blockDim.x) coef[i] = qn;
   }
 }
 
@@ -810,8 +956,14 @@ extern "C" int mia_dice_ce_fwd(const float* logits, const long long* labels, int
   LossGeom g{sn, sk, sp};
   float* part = workspace;
   float* cepart = workspace + (size_t)nb * slabs * k1 * 3;
-  hipLaunchKernelGGL(dice_ce_fwd_kernel, dim3(nb * slabs), dim3(256), 0, st, logits, labels, hw, k1, g, flags, slabs, part, cepart, bad_label);
-  hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(256), 0, st, part, cepart, nb, slabs, k1, hw, flags, smooth, dice_w, ce_w, sums, coef, out);
+  if (dice_ce_fast_ok(logits, labels, hw, k1, sn, sk, sp, flags)) {
+    if (k1 == 2) hipLaunchKernelGGL(dice_ce_fwd_fast_kernel<2>, dim3(nb * slabs), dim3(256), 0, st, logits, labels, (int)hw, flags, slabs, part, cepart, bad_label);
+    else if (k1 == 3) hipLaunchKernelGGL(dice_ce_fwd_fast_kernel<3>, dim3(nb * slabs), dim3(256), 0, st, logits, labels, (int)hw, flags, slabs, part, cepart, bad_label);
+    else hipLaunchKernelGGL(dice_ce_fwd_fast_kernel<4>, dim3(nb * slabs), dim3(256), 0, st, logits, labels, (int)hw, flags, slabs, part, cepart, bad_label);
+  } else {
+    hipLaunchKernelGGL(dice_ce_fwd_kernel, dim3(nb * slabs), dim3(256), 0, st, logits, labels, hw, k1, g, flags, slabs, part, cepart, bad_label);
+  }
+  hipLaunchKernelGGL(dice_ce_finalize_kernel, dim3(1), dim3(256), 0, st, part, cepart, nb, slabs, k1, hw, flags, smooth, dice_w, ce_w, sums, coef, out, bad_label);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -824,6 +976,17 @@ extern "C" int mia_dice_ce_bwd(const float* logits, const long long* labels, con
   const int64_t total = (int64_t)nb * hw;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   LossGeom g{sn, sk, sp}, go{gsn, gsk, gsp};
+  if (dice_ce_fast_ok(logits, labels, hw, k1, sn, sk, sp, flags) && gsn == sn && gsk == sk && gsp == sp &&
+      (reinterpret_cast<uintptr_t>(dlogits) & 15) == 0) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int quads = (int)(hw >> 2);
+    const dim3 grid((unsigned)(quads + 255) / 256 < 512u ? (unsigned)(quads + 255) / 256 : 512u, (unsigned)nb);
+    if (k1 == 2) hipLaunchKernelGGL(dice_ce_bwd_fast_kernel<2>, grid, dim3(256), 0, st, logits, labels, coef, grad_out, dlogits, nb, (int)hw, flags, dice_w, ce_w);
+    else if (k1 == 3) hipLaunchKernelGGL(dice_ce_bwd_fast_kernel<3>, grid, dim3(256), 0, st, logits, labels, coef, grad_out, dlogits, nb, (int)hw, flags, dice_w, ce_w);
+    else hipLaunchKernelGGL(dice_ce_bwd_fast_kernel<4>, grid, dim3(256), 0, st, logits, labels, coef, grad_out, dlogits, nb, (int)hw, flags, dice_w, ce_w);
+    MIA_LAUNCH_CHECK();
+    return MIA_OK;
+  }
   hipLaunchKernelGGL(dice_ce_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), logits, labels, coef,
                      grad_out, dlogits, nb, hw, k1, g, go, flags, dice_w, ce_w);
   MIA_LAUNCH_CHECK();

@@ -23,6 +23,10 @@ def hip_cross_entropy(module, input: Tensor, target: Tensor) -> Tensor:
             getattr(module, "reduction", "mean") != "mean":
         raise NotImplementedError("HIP cross-entropy implements the al_train configuration: no class weights, "
                                   "no label smoothing, reduction='mean'")
+    ign = getattr(module, "ignore_index", -100)
+    if 0 <= ign < input.shape[1]:
+        raise NotImplementedError("HIP cross-entropy has no ignore_index: every label must be a class in [0, K1)")
+    # the default ignore_index (-100) is not honoured either: such a label is out of range -> NaN loss, ops.check_labels() raises
     if target.shape != input.shape:
         target = target.long()
     return ops.DiceCEFn.apply(input, target, ops.loss_flags(True, True, False, False), 1e-5, 0.0, 1.0, 0)

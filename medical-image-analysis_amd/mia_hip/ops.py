@@ -282,18 +282,30 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
 # then let their kernels write the parameter gradient THERE and return that view, which autograd adopts as .grad without a
 # copy or an accumulation kernel (82 tiny `add` launches per step otherwise).  Unregistered parameters get fresh tensors.
 _GRAD_DEST = {}
+_GRAD_CLAIMED = set()  # id(param) whose slice a backward node of the CURRENT accumulation already writes
 
 
 def register_grad_dest(param: torch.Tensor, flat: torch.Tensor, offset: int) -> None:
     _GRAD_DEST[id(param)] = (__import__("weakref").ref(param), flat, offset, param.numel(), tuple(param.shape))
+    _GRAD_CLAIMED.discard(id(param))
 
 
 def unregister_grad_dest(param: torch.Tensor) -> None:
     _GRAD_DEST.pop(id(param), None)
+    _GRAD_CLAIMED.discard(id(param))
+
+
+def release_grad_dest(param: torch.Tensor) -> None:
+    """The parameter's gradient has been accumulated (post-accumulate hook) or dropped (zero_grad): its slice may be
+    handed out again."""
+    _GRAD_CLAIMED.discard(id(param))
 
 
 def grad_dest(param: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-    """A FRESH view of the registered slice (autograd only adopts a gradient nobody else references)."""
+    """A FRESH view of the registered slice (autograd only adopts a gradient nobody else references), handed out to at
+    most ONE backward node per accumulation: a second node that uses the same parameter in the same backward pass (model
+    called twice before one backward, shared weights) gets None -> a fresh tensor, and autograd sums the two; without the
+    claim both kernels would write the same slice and autograd would add two aliased views (2x the last writer)."""
     if param is None:
         return None
     hit = _GRAD_DEST.get(id(param))
@@ -301,9 +313,13 @@ def grad_dest(param: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
         return None
     if hit[0]() is not param:
         _GRAD_DEST.pop(id(param), None)
+        _GRAD_CLAIMED.discard(id(param))
         return None
     if param.grad is not None:
         return None  # a gradient is already there (accumulation over several backward passes): autograd must ADD to it
+    if id(param) in _GRAD_CLAIMED:
+        return None
+    _GRAD_CLAIMED.add(id(param))
     _, flat, off, n, shape = hit
     return flat[off:off + n].view(shape)
 
@@ -723,7 +739,7 @@ class DiceCEFn(torch.autograd.Function):
                 labels = labels.long()
             labels = labels.contiguous()
         hw = h * w
-        slabs = max(1, min(256, hw // 2048))
+        slabs = max(1, min(256, hw // 8192))
         dev = logits.device
         ws = torch.empty(lib().mia_dice_ce_workspace(b, k1, slabs), device=dev, dtype=torch.float32)
         sums = torch.empty((b, k1, 3), device=dev, dtype=torch.float32)
@@ -755,6 +771,17 @@ class DiceCEFn(torch.autograd.Function):
 
 DiceCEFn.last_bad_label = None
 DiceCEFn.last_sums = None
+
+
+def check_labels() -> None:
+    """Raise if the most recent Dice/CE forward met a label outside [0, K1) (host sync: call it where you already sync,
+    e.g. next to the `loss.item()` you log).  The reference raises at that point (scatter index error in
+    `DiceLoss._one_hot_encoder`, dice_loss.py:25-30, and the target bound check of CrossEntropyLoss); the kernels cannot,
+    so they return NaN losses / NaN gradients for such a batch and keep the flag for this check."""
+    bad = DiceCEFn.last_bad_label
+    if bad is not None and int(bad.item()) != 0:
+        raise MiaError("Dice/CE loss: a label lies outside [0, num_classes] (e.g. 255-valued masks or ignore_index -100); "
+                       "the reference raises an index error for such targets")
 
 
 # ------------------------------------------------------------------ optimizer helpers

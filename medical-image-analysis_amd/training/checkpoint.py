@@ -43,6 +43,8 @@ def optimizer_state_to_torch(opt, model: torch.nn.Module) -> dict:
     state = {}
     if opt.step_count > 0:
         for p, o in zip(opt.params, opt.offsets):
+            if id(p) not in opt.stepped:
+                continue  # never received a gradient (e.g. unused deep-supervision heads): torch.optim holds no state for it
             n, i = p.numel(), index[id(p)]
             if opt.kind == OPT_SGD:
                 state[i] = {"momentum_buffer": opt.m[o:o + n].view(p.shape).clone()}
@@ -63,6 +65,7 @@ def optimizer_state_from_torch(opt, model: torch.nn.Module, sd: dict) -> None:
     index = {id(p): i for i, p in enumerate(params)}
     state = sd.get("state", {})
     step = 0
+    opt.stepped = set()
     opt.m.zero_()
     if opt.v is not None:
         opt.v.zero_()
@@ -72,6 +75,7 @@ def optimizer_state_from_torch(opt, model: torch.nn.Module, sd: dict) -> None:
             if not st:
                 continue
             n = p.numel()
+            opt.stepped.add(id(p))
             if opt.kind == OPT_SGD:
                 if st.get("momentum_buffer") is not None:
                     opt.m[o:o + n].copy_(st["momentum_buffer"].reshape(-1))
@@ -99,7 +103,9 @@ def save_state_dict(engine, save_path, save_training_state: bool = False, curren
     save_model_checkpoint(engine.model, save_path / "model.pth")
     if save_training_state:
         st = {"optimizer": optimizer_state_to_torch(engine.optimizer, engine.model),
-              "current_iter": int(engine.current_iter) - 1,  # the reference stores the LAST FINISHED iteration (:1714-1717)
+              # the reference writes self.current_iter as it stands when the state is saved (:1698), i.e. AFTER train_step's
+              # `self.current_iter += 1` (:1399), and adds 1 again on load (:1716): same value on disk here, same quirk on load
+              "current_iter": int(engine.current_iter),
               "current_epoch": int(current_epoch), "current_round": int(current_round), "data_list": list(data_list or [])}
         st["optimizer"]["step_count"] = int(engine.optimizer.step_count)
         torch.save(st, save_path / "training_state.pth")
@@ -107,7 +113,9 @@ def save_state_dict(engine, save_path, save_training_state: bool = False, curren
 
 def load_state_dict(engine, save_path, map_location=None) -> dict:
     """al_trainer.py:1704-1717.  Returns {"current_epoch", "current_round", "data_list"} already offset by +1 like the
-    reference (the state is written at the end of an iteration); ``engine.current_iter`` is set."""
+    reference; ``engine.current_iter`` = stored value + 1 exactly as the reference does (:1716) -- since the stored value
+    is already the count of finished iterations, a resumed run skips one poly-LR step, in the reference and here alike
+    (files written by either side resume identically on either side)."""
     save_path = Path(save_path)
     out = {}
     model_path, ts_path = save_path / "model.pth", save_path / "training_state.pth"

@@ -66,6 +66,11 @@ class FlatOptimizer:
                 p.register_post_accumulate_grad_hook(self._make_fixup(o))
         self.param_groups = [dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps, momentum=momentum)]
         self.step_count = 0
+        # ids of the parameters that have been updated at least once (checkpoint export: torch.optim keeps no state for a
+        # parameter that never had a gradient).  Limitation, documented: ONE step counter serves the Adam bias correction
+        # of every parameter, so a parameter whose first gradient arrives at step t > 1 is corrected with 1 - beta^t where
+        # torch.optim would use 1 - beta^1 (does not occur on the al_train path: the set of used parameters is fixed).
+        self.stepped = set()
         self.last_norm: Optional[torch.Tensor] = None
         self._pack_plan = None
         # bucket table for data parallelism
@@ -95,6 +100,7 @@ class FlatOptimizer:
         def hook(p):
             if getattr(p, "_mia_flat_owner", None) is not self._token:
                 return  # a newer FlatOptimizer took the parameter over (al_train builds a new optimizer every round)
+            ops.release_grad_dest(p)  # this accumulation is complete: the slice may be claimed again
             g = p.grad
             if g is not None and g.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 dst = self.flat_grad[o:o + p.numel()].view(p.shape)
@@ -108,6 +114,7 @@ class FlatOptimizer:
         self.flat_grad.zero_()
         for p in self.params:
             p.grad = None
+            ops.release_grad_dest(p)
 
     def step(self, max_grad_norm: float = 0.0, grad_scale: float = 1.0):
         g = self.param_groups[0]
@@ -119,6 +126,7 @@ class FlatOptimizer:
         b1, b2 = (g["momentum"], 0.0) if self.kind == OPT_SGD else g["betas"]
         # torch.optim skips a parameter whose .grad is None (no update, no weight decay, no moment decay) -- e.g. deep-
         # supervision heads al_train never evaluates; update only the runs of the flat buffer that received a gradient
+        self.stepped.update(id(p) for p in self.params if p.grad is not None)
         for s0, e0 in self._live_runs():
             ops.optim_step(self.kind, self.flat_param[s0:e0], self.flat_grad[s0:e0], self.m[s0:e0],
                            None if self.v is None else self.v[s0:e0], float(g["lr"]), b1, b2, g["eps"],
@@ -223,11 +231,21 @@ class TrainEngine:
     def __init__(self, model, loss_fn, optimizer_name: str = "adam", optimizer_kwargs: Optional[dict] = None,
                  start_lr: float = 1e-3, num_iters: int = 4000, lr_warmup_iter: int = 250, lr_interval: int = 1,
                  lr_scheduler_name: str = "poly", grad_norm: float = 10.0, process_group=None, bucket_bytes: int = 32 << 20,
-                 sync_batchnorm: bool = False):
+                 sync_batchnorm: Optional[bool] = None):
+        """sync_batchnorm: None (default) = ON whenever the model holds batch-norm blocks and the process group has more
+        than one rank, so N ranks x bs reproduce one process at N*bs (`normalization="batch"` is the al_train
+        default, train.py:25); False keeps per-rank statistics (DDP-without-SyncBN behaviour) and says so once."""
         self.model = model
-        if sync_batchnorm and dist.is_initialized() and dist.get_world_size(process_group) > 1:
-            from models.unet.blocks import convert_sync_batchnorm
-            convert_sync_batchnorm(model, process_group)
+        world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if world > 1:
+            from models.unet.blocks import PlainBlock, convert_sync_batchnorm
+            has_bn = any(isinstance(m, PlainBlock) and m.normalization == "batch" for m in model.modules())
+            if has_bn and (sync_batchnorm is None or sync_batchnorm):
+                convert_sync_batchnorm(model, process_group)
+            elif has_bn:
+                import warnings
+                warnings.warn("TrainEngine: batch-norm model on %d ranks with sync_batchnorm=False -- statistics are per rank, "
+                              "results differ from a single process at the global batch size" % world)
         self.loss_fn = loss_fn
         kw = dict(optimizer_kwargs or {})
         self.optimizer = FlatOptimizer(model, optimizer_name, bucket_bytes=bucket_bytes, **kw)
@@ -258,6 +276,13 @@ class TrainEngine:
         self.optimizer.step(max_grad_norm=self.grad_norm, grad_scale=self.reducer.grad_scale)
         self.current_iter += 1
         return loss.detach()
+
+    def loss_value(self, loss: torch.Tensor) -> float:
+        """`loss.item()` for logging (al_trainer.py:1381) -- the one host sync of a logged step -- plus the label-range check
+        the reference performs by raising inside the loss (dice_loss.py:25-30)."""
+        v = float(loss.item())
+        ops.check_labels()
+        return v
 
     def save_state_dict(self, save_path, save_training_state: bool = False, **extra) -> None:
         """model.pth (+ training_state.pth) in the reference's layout (al_trainer.py:1719-1733)."""

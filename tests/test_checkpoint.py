@@ -24,6 +24,7 @@ def _fake_progress(eng, steps=3):
         if o.v is not None:
             o.v[off:off + p.numel()].copy_(torch.rand(p.numel(), generator=g))
     o.step_count = steps
+    o.stepped = {id(p) for p in o.params}
     o.param_groups[0]["lr"] = 7e-4
     eng.current_iter = steps
 
@@ -44,7 +45,10 @@ def test_round_trip_and_reference_layout(tmp_path, golden_dir):
     np.testing.assert_array_equal(a.optimizer.flat_param.numpy(), b.optimizer.flat_param.numpy())
     np.testing.assert_array_equal(a.optimizer.m.numpy(), b.optimizer.m.numpy())
     np.testing.assert_array_equal(a.optimizer.v.numpy(), b.optimizer.v.numpy())
-    assert b.optimizer.step_count == 3 and b.current_iter == 3 and abs(b.optimizer.param_groups[0]["lr"] - 7e-4) < 1e-12
+    # reference semantics (al_trainer.py:1698 / :1716): the file holds current_iter as it stands at save time (= finished
+    # iterations, train_step has already incremented it, :1399) and the loader adds 1
+    assert torch.load(tmp_path / "training_state.pth", weights_only=True)["current_iter"] == 3
+    assert b.optimizer.step_count == 3 and b.current_iter == 4 and abs(b.optimizer.param_groups[0]["lr"] - 7e-4) < 1e-12
     assert extra == {"current_epoch": 5, "current_round": 3, "data_list": ["case_1", "case_7"]}
     # parameters are still views of the flat buffer after loading
     p0 = b.optimizer.params[0]
@@ -79,3 +83,22 @@ def test_optimizer_state_interchanges_with_torch_optim():
         if name != "sgd":
             np.testing.assert_array_equal(a.optimizer.v.numpy(), b.optimizer.v.numpy())
             assert b.optimizer.step_count == 4
+
+
+def test_unused_parameters_export_no_optimizer_state():
+    """torch.optim keeps no state for a parameter that never had a gradient (unused deep-supervision heads): neither
+    does the exported state_dict."""
+    a = _engine("adam", seed=1)
+    _fake_progress(a, steps=2)
+    unused = a.optimizer.params[:2]
+    a.optimizer.stepped -= {id(p) for p in unused}
+    exported = checkpoint.optimizer_state_to_torch(a.optimizer, a.model)
+    index = {id(p): i for i, p in enumerate(a.model.parameters())}
+    assert all(index[id(p)] not in exported["state"] for p in unused)
+    assert len(exported["state"]) == len(a.optimizer.params) - 2
+    t = torch.optim.Adam(a.model.parameters(), lr=1e-3)
+    t.load_state_dict({k: v for k, v in exported.items() if k in ("state", "param_groups")})
+    assert all(p not in t.state for p in unused)
+    b = _engine("adam", seed=1)
+    checkpoint.optimizer_state_from_torch(b.optimizer, b.model, exported)
+    assert b.optimizer.stepped == {id(p) for p in b.optimizer.params[2:]}

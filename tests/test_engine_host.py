@@ -41,8 +41,12 @@ def test_gradient_destinations_and_live_runs():
     opt.zero_grad()
     assert all(p.grad is None for p in opt.params) and float(opt.flat_grad.abs().max()) == 0.0
     p0, o0 = opt.params[3], opt.offsets[3]
-    d1, d2 = ops.grad_dest(p0), ops.grad_dest(p0)
-    assert d1 is not d2 and d1.data_ptr() == d2.data_ptr() == opt.flat_grad.data_ptr() + 4 * o0 and d1.shape == p0.shape
+    d1 = ops.grad_dest(p0)
+    assert d1.data_ptr() == opt.flat_grad.data_ptr() + 4 * o0 and d1.shape == p0.shape
+    assert ops.grad_dest(p0) is None  # the slice is claimed until this accumulation completes (second node -> fresh tensor)
+    ops.release_grad_dest(p0)
+    d2 = ops.grad_dest(p0)
+    assert d1 is not d2 and d1.data_ptr() == d2.data_ptr()
     assert ops.grad_dest(torch.nn.Parameter(torch.zeros(3))) is None  # unregistered parameter
     p0.grad = d1
     assert ops.grad_dest(p0) is None  # a gradient is present: autograd has to accumulate, no direct write
@@ -66,3 +70,41 @@ def test_gradient_destinations_and_live_runs():
     d = ops.grad_dest(p0)
     o2 = opt2.offsets[[id(q) for q in opt2.params].index(id(p0))]
     assert d.data_ptr() == opt2.flat_grad.data_ptr() + 4 * o2 and p0._mia_flat_owner is opt2._token
+
+
+class _MockNode(torch.autograd.Function):
+    """Stands in for a backward node of ops.py: writes the parameter gradient into ops.grad_dest(w) when it gets one."""
+
+    @staticmethod
+    def forward(ctx, x, w, scale):
+        ctx.w, ctx.scale, ctx.n = w, scale, x.numel()
+        return (x * w.detach().sum() * scale).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        dst = ops.grad_dest(ctx.w)
+        val = torch.full_like(ctx.w, ctx.scale)
+        if dst is None:
+            dst = val
+        else:
+            dst.copy_(val)
+        return None, dst, None
+
+
+def test_two_nodes_sharing_one_parameter_in_one_backward_accumulate():
+    """two autograd nodes that use the same registered parameter inside ONE backward pass (model called twice
+    before one loss.backward(), weight sharing) must sum their gradients, not alias the flat slice (2 instead of 11)."""
+    m = _model()
+    opt = FlatOptimizer(m, "sgd")
+    p0, o0 = opt.params[3], opt.offsets[3]
+    for _ in range(2):  # the claim is released again by the post-accumulate hook / zero_grad
+        opt.zero_grad()
+        x = torch.ones(4)
+        loss = _MockNode.apply(x, p0, 1.0) + _MockNode.apply(x, p0, 10.0)
+        loss.backward()
+        assert torch.allclose(p0.grad, torch.full_like(p0, 11.0))
+        assert p0.grad.data_ptr() == opt.flat_grad.data_ptr() + 4 * o0  # the flat buffer holds the sum
+        assert torch.allclose(opt.flat_grad[o0:o0 + p0.numel()], torch.full((p0.numel(),), 11.0))
+    # accumulation over two backward passes without zero_grad still adds
+    _MockNode.apply(torch.ones(4), p0, 5.0).backward()
+    assert torch.allclose(opt.flat_grad[o0:o0 + p0.numel()], torch.full((p0.numel(),), 16.0))

@@ -279,6 +279,63 @@ def test_losses_golden(golden_dir):
     np.testing.assert_allclose(li.grad.cpu().numpy(), 2 * g1.cpu().numpy(), rtol=1e-6)
 
 
+@pytest.mark.parametrize("k1", [2, 3, 4])
+@pytest.mark.parametrize("hw", [(64, 64), (96, 136), (31, 20)])
+@pytest.mark.parametrize("flags", [(True, False, False), (False, True, False), (True, False, True)])
+def test_dice_ce_vectorised_path_vs_oracle(k1, hw, flags):
+    """Channels-last logits (what the UNet head emits) take the 4-pixels-per-thread kernels; every DiceLoss flag
+    combination and ragged slab ends against the CPU oracle (oracle/losses_ref.py; tolerance = the golden test's)."""
+    from losses.compound_losses import DiceAndCELoss
+    from oracle import losses_ref
+    dev = _dev()
+    do_bg, batch, squared = flags
+    g = torch.Generator().manual_seed(100 * k1 + hw[0])
+    b = 3
+    logits = torch.randn(b, k1, *hw, generator=g) * 2
+    labels = torch.randint(0, k1, (b, *hw), generator=g)
+    ref_in = logits.clone().requires_grad_(True)
+    ref = losses_ref.dice_and_ce(ref_in, labels, k1 - 1, 0.6, 0.9, do_bg=do_bg, batch=batch, squared=squared)
+    ref.backward()
+    li = logits.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2).requires_grad_(True)  # channels-last storage
+    fn = DiceAndCELoss(dice_kwargs=dict(num_classes=k1 - 1, do_bg=do_bg, batch=batch, squared=squared), ce_loss=torch.nn.CrossEntropyLoss)
+    v = fn(li, labels.to(dev), dice_weight=0.6, ce_weight=0.9)
+    v.backward()
+    assert abs(v.item() - ref.item()) < 2e-6
+    np.testing.assert_allclose(li.grad.cpu().numpy(), ref_in.grad.numpy(), atol=2e-7)
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_out_of_range_label_poisons_loss_and_is_reported(layout):
+    """The reference raises for a label outside [0, K1) (scatter index error, dice_loss.py:25-30; CE target bound check).
+    The kernels return NaN loss and NaN gradients for such a batch and ops.check_labels() raises."""
+    import mia_hip
+    from mia_hip import ops
+    from losses.compound_losses import DiceAndCELoss
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(2, 3, 16, 16, generator=g).to(dev)
+    if layout == "nhwc":
+        logits = logits.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    logits.requires_grad_(True)
+    labels = torch.randint(0, 3, (2, 16, 16), generator=g).to(dev)
+    fn = DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss)
+    ok = fn(logits, labels)
+    assert math.isfinite(ok.item())
+    ops.check_labels()
+    for badval in (255, -100, 3):
+        lab = labels.clone()
+        lab[1, 7, 9] = badval
+        logits.grad = None
+        v = fn(logits, lab)
+        v.backward()
+        assert math.isnan(v.item()) and bool(torch.isnan(logits.grad).any())
+        with pytest.raises(mia_hip.MiaError):
+            ops.check_labels()
+    with pytest.raises(NotImplementedError):
+        fn2 = DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss, ce_kwargs=dict(ignore_index=1))
+        fn2.get_ce_loss(logits, labels)
+
+
 @pytest.mark.parametrize("kind", ["adam", "adamw", "sgd"])
 def test_optimizer_and_clip(kind):
     from mia_hip import ops, OPT_ADAM, OPT_ADAMW, OPT_SGD
