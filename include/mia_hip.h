@@ -207,6 +207,10 @@ int mia_affine_nearest(const float* img_in, float* img_out, const long long* lab
 /* RandomRotation90 / MirrorTransform (joint_transform.py:40-97): torch.rot90(k) then optional flips; 4- or 8-byte elements */
 int mia_rot90_flip(const void* in, void* out, int elem_bytes, int nb, int c, int h, int w, int k, int flip_h, int flip_w,
                    void* stream);
+/* RandomCrop2D (joint_transform.py:130-155): F.crop with per-sample window origins top[b], left[b] (device int arrays);
+ * the window lies inside the image (T.RandomCrop.get_params draws it so); 4- or 8-byte elements */
+int mia_crop(const void* in, void* out, int elem_bytes, int nb, int c, int h, int w, int oh, int ow, const int* top,
+             const int* left, void* stream);
 /* RandomGaussianBlur (image_transform.py:145-193): F.gaussian_blur = k x k outer-product kernel, reflect pad */
 int mia_gaussian_blur(const float* in, float* out, int nb, int c, int h, int w, const float* sigma, const int* ksize,
                       int max_ksize, const int* apply, void* stream);

@@ -13,35 +13,83 @@
 __device__ __forceinline__ bool on(const int* apply, int b) { return apply == nullptr || apply[b] != 0; }
 
 // ---------------------------------------------------------------- inverse-affine nearest warp (image + label)
-// mats[b] = the 6 entries of torchvision's inverse affine matrix (centre frame).  Follows
-// _gen_affine_grid + grid_sample(nearest, zeros, align_corners=False): base (x+0.5-W/2, y+0.5-H/2),
-// theta rescaled by (0.5W, 0.5H), unnormalise ((g+1)*size-1)/2, round-half-even, zero outside.
+// mats[b] = the 6 entries of torchvision's inverse affine matrix (centre frame).  The source pixel of every output pixel
+// is INDEX arithmetic and must equal torchvision's tensor path bit for bit (F.affine -> _gen_affine_grid ->
+// grid_sample(nearest, zeros, align_corners=False), joint_transform.py:189-190), so the fp32 operations are pinned one by
+// one, contraction off:
+//   base   = (x + 0.5 - W/2, y + 0.5 - H/2, 1)                    linspace with step exactly 1
+//   theta' = theta / (0.5 W, 0.5 H)                               one correctly rounded division per entry
+//   g      = base @ theta'^T as the CPU sgemm accumulates it:     acc = x*t0; acc = fma(y, t1, acc); acc = fma(1, t2, acc)
+//   f      = ((g + 1) * size - 1) / 2                             grid_sampler unnormalize, align_corners=False
+//   src    = round-half-even(f), zero outside [0, size-1]
+// (checked against torch-CPU on 4e7 pixels of random rotations / scales: 0 differing indices; the orders
+// (x*t0 + y*t1) + t2 without fma and fma(x, t0, fma(y, t1, t2)) differ on ~1e-6 of the pixels.)
+struct AffineSrc { int idx; bool inside; };
+
+__device__ __forceinline__ AffineSrc affine_src(const float* __restrict__ m, int x, int y, int w, int h) {
+#pragma clang fp contract(off)
+  const float hx = 0.5f * (float)w, hy = 0.5f * (float)h;
+  const float xb = ((float)x + 0.5f) - hx, yb = ((float)y + 0.5f) - hy;
+  const float t0 = m[0] / hx, t1 = m[1] / hx, t2 = m[2] / hx, t3 = m[3] / hy, t4 = m[4] / hy, t5 = m[5] / hy;
+  float gx = xb * t0, gy = xb * t3;
+  gx = __builtin_fmaf(yb, t1, gx); gy = __builtin_fmaf(yb, t4, gy);
+  gx = gx + t2; gy = gy + t5;
+  const float fx = (((gx + 1.f) * (float)w) - 1.f) * 0.5f, fy = (((gy + 1.f) * (float)h) - 1.f) * 0.5f;
+  const float rx = __builtin_rintf(fx), ry = __builtin_rintf(fy);
+  AffineSrc s;
+  s.inside = (rx >= 0.f && rx <= (float)(w - 1) && ry >= 0.f && ry <= (float)(h - 1));
+  s.idx = s.inside ? (int)ry * w + (int)rx : 0;
+  return s;
+}
+
+// VEC = 4: a thread owns four consecutive output pixels of one row (W % 4 == 0): the gathers stay scalar (nearest
+// sampling reads arbitrary source pixels) but every store is 16 bytes -- one for the image, two for the int64 labels.
+template <int VEC>
 __global__ void affine_nearest_kernel(const float* __restrict__ img_in, float* __restrict__ img_out,
                                       const long long* __restrict__ lab_in, long long* __restrict__ lab_out, int nb, int c,
                                       int h, int w, const float* __restrict__ mats, const int* __restrict__ apply) {
-  const int64_t hw = (int64_t)h * w, total = (int64_t)nb * hw;
+  const int64_t hw = (int64_t)h * w, groups = hw / VEC, total = (int64_t)nb * groups;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int b = (int)(i / hw);
-    const int64_t p = i - (int64_t)b * hw;
-    const int y = (int)(p / w), x = (int)(p - (int64_t)y * w);
-    int sy = y, sx = x;
-    bool inside = true;
-    if (on(apply, b)) {
-      const float* m = mats + b * 6;
-      const float hx = 0.5f * w, hy = 0.5f * h;
-      const float xb = (float)x + 0.5f - hx, yb = (float)y + 0.5f - hy;
-      const float gx = xb * (m[0] / hx) + yb * (m[1] / hx) + (m[2] / hx);
-      const float gy = xb * (m[3] / hy) + yb * (m[4] / hy) + (m[5] / hy);
-      const float fx = ((gx + 1.f) * w - 1.f) * 0.5f, fy = ((gy + 1.f) * h - 1.f) * 0.5f;
-      const float rx = nearbyintf(fx), ry = nearbyintf(fy);
-      inside = (rx >= 0.f && rx <= (float)(w - 1) && ry >= 0.f && ry <= (float)(h - 1));
-      sx = (int)rx; sy = (int)ry;
+    const int b = (int)(i / groups);
+    const int64_t p = (i - (int64_t)b * groups) * VEC;
+    const int y = (int)(p / w), x0 = (int)(p - (int64_t)y * w);
+    const bool act = on(apply, b);
+    int src[VEC];
+    bool ins[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (act) {
+        const AffineSrc s = affine_src(mats + b * 6, x0 + j, y, w, h);
+        src[j] = s.idx; ins[j] = s.inside;
+      } else {
+        src[j] = (int)p + j; ins[j] = true;
+      }
     }
-    const int64_t sp = (int64_t)sy * w + sx;
-    if (img_in)
-      for (int ch = 0; ch < c; ++ch)
-        img_out[((int64_t)b * c + ch) * hw + p] = inside ? img_in[((int64_t)b * c + ch) * hw + sp] : 0.f;
-    if (lab_in) lab_out[(int64_t)b * hw + p] = inside ? lab_in[(int64_t)b * hw + sp] : 0;
+    if (img_in) {
+      for (int ch = 0; ch < c; ++ch) {
+        const float* pi = img_in + ((int64_t)b * c + ch) * hw;
+        float v[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = ins[j] ? pi[src[j]] : 0.f;
+        float* po = img_out + ((int64_t)b * c + ch) * hw + p;
+        if constexpr (VEC == 4) *reinterpret_cast<f32x4*>(po) = f32x4{v[0], v[1], v[2], v[3]};
+        else po[0] = v[0];
+      }
+    }
+    if (lab_in) {
+      const long long* pl = lab_in + (int64_t)b * hw;
+      long long v[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = ins[j] ? pl[src[j]] : 0;
+      long long* po = lab_out + (int64_t)b * hw + p;
+      if constexpr (VEC == 4) {
+        typedef __attribute__((ext_vector_type(2))) long long i64x2;
+        reinterpret_cast<i64x2*>(po)[0] = i64x2{v[0], v[1]};
+        reinterpret_cast<i64x2*>(po)[1] = i64x2{v[2], v[3]};
+      } else {
+        po[0] = v[0];
+      }
+    }
   }
 }
 
@@ -49,10 +97,13 @@ extern "C" int mia_affine_nearest(const float* img_in, float* img_out, const lon
                                   int c, int h, int w, const float* mats, const int* apply, void* stream) {
   MIA_CHECK_ARG((img_in || lab_in) && mats && nb > 0 && h > 0 && w > 0, "mia_affine_nearest: bad arguments");
   MIA_CHECK_ARG((img_in == nullptr) == (img_out == nullptr) && (lab_in == nullptr) == (lab_out == nullptr), "mia_affine_nearest: in/out mismatch");
-  const int64_t total = (int64_t)nb * h * w;
+  MIA_CHECK_ARG((int64_t)h * w < ((int64_t)1 << 31), "mia_affine_nearest: image too large");
+  const bool vec = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(img_out) | reinterpret_cast<uintptr_t>(lab_out)) & 15) == 0;
+  const int64_t total = (int64_t)nb * h * w / (vec ? 4 : 1);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(affine_nearest_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), img_in, img_out, lab_in,
-                     lab_out, nb, c, h, w, mats, apply);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (vec) hipLaunchKernelGGL(affine_nearest_kernel<4>, dim3(blocks), dim3(256), 0, st, img_in, img_out, lab_in, lab_out, nb, c, h, w, mats, apply);
+  else hipLaunchKernelGGL(affine_nearest_kernel<1>, dim3(blocks), dim3(256), 0, st, img_in, img_out, lab_in, lab_out, nb, c, h, w, mats, apply);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -92,6 +143,38 @@ extern "C" int mia_rot90_flip(const void* in, void* out, int elem_bytes, int nb,
     hipLaunchKernelGGL(rot_flip_kernel<unsigned int>, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned int*>(in), static_cast<unsigned int*>(out), nb, c, h, w, k, flip_h, flip_w);
   else
     hipLaunchKernelGGL(rot_flip_kernel<unsigned long long>, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned long long*>(in), static_cast<unsigned long long*>(out), nb, c, h, w, k, flip_h, flip_w);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---------------------------------------------------------------- crop window (RandomCrop2D, joint_transform.py:130-155)
+// out[b][.][y][x] = in[b][.][top[b] + y][left[b] + x]; F.crop with an in-range window (RandomCrop.get_params never pads).
+template <typename T>
+__global__ void crop_kernel(const T* __restrict__ in, T* __restrict__ out, int nb, int c, int h, int w, int oh, int ow,
+                            const int* __restrict__ top, const int* __restrict__ left) {
+  const int64_t ohw = (int64_t)oh * ow, per = (int64_t)c * ohw, total = (int64_t)nb * per;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per);
+    const int64_t r = i - (int64_t)b * per;
+    const int ch = (int)(r / ohw);
+    const int64_t p = r - (int64_t)ch * ohw;
+    const int y = (int)(p / ow), x = (int)(p - (int64_t)y * ow);
+    out[i] = in[(((int64_t)b * c + ch) * h + top[b] + y) * w + left[b] + x];
+  }
+}
+
+extern "C" int mia_crop(const void* in, void* out, int elem_bytes, int nb, int c, int h, int w, int oh, int ow, const int* top,
+                        const int* left, void* stream) {
+  MIA_CHECK_ARG(in && out && top && left && nb > 0 && c > 0 && h > 0 && w > 0, "mia_crop: bad arguments");
+  MIA_CHECK_ARG(oh > 0 && ow > 0 && oh <= h && ow <= w, "mia_crop: window %dx%d does not fit %dx%d", oh, ow, h, w);
+  MIA_CHECK_ARG(elem_bytes == 4 || elem_bytes == 8, "mia_crop: element size %d not 4 or 8", elem_bytes);
+  const int64_t total = (int64_t)nb * c * oh * ow;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL(crop_kernel<unsigned int>, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned int*>(in), static_cast<unsigned int*>(out), nb, c, h, w, oh, ow, top, left);
+  else
+    hipLaunchKernelGGL(crop_kernel<unsigned long long>, dim3(blocks), dim3(256), 0, st, static_cast<const unsigned long long*>(in), static_cast<unsigned long long*>(out), nb, c, h, w, oh, ow, top, left);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

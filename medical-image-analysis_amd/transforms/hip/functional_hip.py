@@ -71,6 +71,22 @@ def rot90_flip(x: torch.Tensor, k: int = 0, flip_h: bool = False, flip_w: bool =
     return out
 
 
+def crop(x: torch.Tensor, top: Sequence[int], left: Sequence[int], oh: int, ow: int) -> torch.Tensor:
+    """x [B, ..., H, W] (4- or 8-byte dtype) -> [B, ..., oh, ow]: per-sample window x[b, ..., top[b]:top[b]+oh, left[b]:left[b]+ow]."""
+    _need_dev(x)
+    x = x.contiguous()
+    if x.element_size() not in (4, 8):
+        raise MiaError("crop supports 4- or 8-byte element types")
+    b, h, w = x.shape[0], x.shape[-2], x.shape[-1]
+    if len(top) != b or len(left) != b or min(top) < 0 or min(left) < 0 or max(top) + oh > h or max(left) + ow > w:
+        raise MiaError(f"crop: window {oh}x{ow} at {list(top)},{list(left)} does not fit {h}x{w}")
+    planes = x.numel() // (b * h * w)
+    out = torch.empty(tuple(x.shape[:-2]) + (oh, ow), device=x.device, dtype=x.dtype)
+    tp, lf = _dev_i(top, x.device), _dev_i(left, x.device)
+    call("mia_crop", _p(x), _p(out), x.element_size(), b, planes, h, w, oh, ow, _p(tp), _p(lf), _stream())
+    return out
+
+
 def gaussian_blur(img: torch.Tensor, sigma: Sequence[float], ksize: Sequence[int], apply=None) -> torch.Tensor:
     x = _f32(img)
     b, c, h, w = x.shape

@@ -143,13 +143,15 @@ class RandomCrop2D(BaseTransform):
         return (shape[0], self.crop[0], self.crop[1])
 
     def apply_batch(self, images, labels, params):
-        imgs, labs = [], []
-        for b, p in enumerate(params):
-            i, j, h, w = p
-            imgs.append(images[b:b + 1, :, i:i + h, j:j + w])
-            if labels is not None:
-                labs.append(labels[b:b + 1, i:i + h, j:j + w])
-        return torch.cat(imgs).contiguous(), (torch.cat(labs).contiguous() if labels is not None else None)
+        th, tw = self.crop
+        top, left = [], []
+        for p in params:  # None (skipped by an enclosing RandomTransform) cannot keep the old size in a batch: crop at 0,0
+            i, j, h, w = p if p is not None else (0, 0, th, tw)
+            if (h, w) != (th, tw):
+                raise ValueError(f"RandomCrop2D: window {(h, w)} differs from the configured crop {(th, tw)}")
+            top.append(i)
+            left.append(j)
+        return FH.crop(images, top, left, th, tw), (FH.crop(labels, top, left, th, tw) if labels is not None else None)
 
     def get_params_dict(self):
         return {RandomCrop2D.__name__: {"crop": self.crop}}
