@@ -108,8 +108,67 @@ def test_conv3x3_fwd_dgrad_wgrad(case, stride, dtype):
     assert relerr(ops.colsum(dyd), dy.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
 
 
+# Every distinct 3x3 conv of the benchmarked models at their own widths (the golden UNets are 4..20
+# channels wide and never reach the branch-free kernels): [64..1024] (cfg2 / cfg3) on the 128x128-input pyramid, encoder
+# (one source; stride 2 = first block of the next level), decoder (two sources = skip | upsampled), plus cfg5's
+# [96..3072] extremes.  Inputs are quantised to the storage dtype on both sides, so bf16 differs from the fp32-CPU
+# reference only by fp32 accumulation order and the final rounding of a bf16 OUTPUT (<= 2^-9 relative per element);
+# weight gradients are fp32 on both sides.
+WIDE_CASES = [
+    (2, 64, 0, 64, 128, 128), (2, 64, 0, 128, 128, 128), (2, 128, 0, 128, 64, 64), (1, 128, 0, 256, 64, 64),
+    (1, 256, 0, 256, 32, 32), (1, 256, 0, 512, 32, 32), (1, 512, 0, 512, 16, 16), (1, 512, 0, 1024, 16, 16),
+    (1, 1024, 0, 1024, 8, 8), (1, 512, 512, 512, 16, 16), (1, 256, 256, 256, 32, 32), (1, 128, 128, 128, 64, 64),
+    (2, 64, 64, 64, 128, 128), (1, 96, 0, 96, 48, 80), (1, 96, 96, 96, 48, 48), (1, 1536, 0, 3072, 6, 6),
+    (1, 3072, 0, 3072, 3, 3), (1, 1536, 1536, 1536, 6, 6),
+]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", [(2, 32, 16, 8, 8), (1, 64, 32, 16, 16), (2, 20, 12, 5, 9), (1, 256, 128, 4, 4)])
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_conv3x3_benchmark_widths(case, dtype):
+    from mia_hip import ops, CONV_G3S1, CONV_G3S2, CONV_T3S2, WGRAD_3S1, WGRAD_3S2
+    dev = _dev()
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    n, c1, c2, cout, h, w = case
+    stride = 2 if (c2 == 0 and cout == 2 * c1) else 1  # channel doubling = first block of a level (unet.py:54-66)
+    g = torch.Generator().manual_seed(c1 + cout + h)
+    cin = c1 + c2
+    x = q(torch.randn(n, cin, h, w, generator=g), dtype)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
+    dy = q(torch.randn(n, cout, ho, wo, generator=g), dtype)
+    xr, wr = x.clone().requires_grad_(True), q(wt, dtype).clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b, stride=stride, padding=1)
+    yr.backward(dy)
+    x1 = nhwc(x[:, :c1], dtype, dev)
+    x2 = nhwc(x[:, c1:], dtype, dev) if c2 else None
+    wd = wt.to(dev)
+    pc = ops.PackCache()
+    wp, npad, kpad = pc.get(wd, ops._dt(dtype), True)
+    y, _, stats = ops.conv_mma(CONV_G3S2 if stride == 2 else CONV_G3S1, x1, x2, wp, npad, kpad, False, b.to(dev), cout, (ho, wo),
+                               want_stats=True)
+    otol = 2e-5 if dtype == torch.float32 else 6e-3  # bf16: output rounding 2^-9 of |y| <= max|y|, + accumulation order
+    assert relerr(nchw(y), yr) < otol
+    s = stats.sum(1).cpu()
+    assert relerr(s[..., 0], yr.detach().sum((2, 3))) < 1e-3
+    assert relerr(s[..., 1], (yr.detach() ** 2).sum((2, 3))) < 1e-3
+    dyd = nhwc(dy, dtype, dev)
+    wb, npb, kpb = pc.get(wd, ops._dt(dtype), False)
+    split = c1 if c2 else None
+    if stride == 2:
+        dx1, dx2, _ = ops.conv_mma(CONV_T3S2, dyd, None, wb, npb, kpb, False, None, cin, (h, w), out_split=split)
+    else:
+        dx1, dx2, _ = ops.conv_mma(CONV_G3S1, dyd, None, wb, npb, kpb, True, None, cin, (h, w), out_split=split)
+    dx = nchw(dx1) if dx2 is None else torch.cat([nchw(dx1), nchw(dx2)], 1)
+    assert relerr(dx, xr.grad) < otol
+    dw = ops.conv_wgrad(WGRAD_3S2 if stride == 2 else WGRAD_3S1, x1, x2, dyd, wt.shape, cout, cin)
+    assert relerr(dw, wr.grad) < 1e-4  # fp32 slabs of exact products: accumulation order only, in both dtypes
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 32, 16, 8, 8), (1, 64, 32, 16, 16), (2, 20, 12, 5, 9), (1, 256, 128, 4, 4),
+                                  (1, 1024, 512, 8, 8), (1, 512, 256, 16, 16), (2, 128, 64, 64, 64), (1, 3072, 1536, 3, 3)])
 def test_conv_transpose2x2(case, dtype):
     from mia_hip import ops
     dev = _dev()
