@@ -157,8 +157,11 @@ def inverse_affine_matrix(center, angle, translate, scale, shear) -> List[float]
     return m
 
 
-def _affine_grid(matrix: Sequence[float], w: int, h: int) -> torch.Tensor:
-    """[tv] _functional_tensor._gen_affine_grid with ow=w, oh=h."""
+def _affine_grid_bmm(matrix: Sequence[float], w: int, h: int) -> torch.Tensor:
+    """[tv] _functional_tensor._gen_affine_grid with ow=w, oh=h, literally: the grid is an fp32 ``bmm``.  The summation
+    order / fusing inside that sgemm belongs to the BLAS kernel the CPU dispatches to, so the last bit of a grid value --
+    and with it a nearest-sample tie on about one pixel in a million -- is machine dependent.  Kept to pin `_affine_grid`
+    below against torch as run in the dev container (tests/test_oracle_golden.py)."""
     theta = torch.tensor(matrix, dtype=torch.float32).reshape(1, 2, 3)
     d = 0.5
     base = torch.empty(1, h, w, 3, dtype=torch.float32)
@@ -167,6 +170,32 @@ def _affine_grid(matrix: Sequence[float], w: int, h: int) -> torch.Tensor:
     base[..., 2].fill_(1)
     rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h], dtype=torch.float32)
     return base.view(1, h * w, 3).bmm(rescaled).view(1, h, w, 2)
+
+
+def _fma32(a, b, c):
+    """fp32 fused multiply-add on numpy arrays: the product of two fp32 values is exact in x87 extended precision."""
+    import numpy as np
+    ld = np.longdouble
+    return (a.astype(ld) * b.astype(ld) + c.astype(ld)).astype(np.float32)
+
+
+def _affine_grid(matrix: Sequence[float], w: int, h: int) -> torch.Tensor:
+    """[tv] _gen_affine_grid with the sgemm written out, so the oracle is the same on every machine:
+    g = acc(x * t0); acc = fma(y, t1, acc); acc = fma(1, t2, acc) -- k-sequential fused accumulation, which is what MKL's
+    sgemm does for this [HW x 3] x [3 x 2] product on the dev container's CPU (bit-equal to `_affine_grid_bmm` there on
+    4e7 pixels of random rotations / scales / shears; the unfused order and the reversed order differ on ~1e-6 of them)."""
+    import numpy as np
+    theta = torch.tensor(matrix, dtype=torch.float32).reshape(2, 3)
+    r = (theta / torch.tensor([[0.5 * w], [0.5 * h]], dtype=torch.float32)).numpy()  # one correctly rounded division each
+    d = 0.5
+    xs = torch.linspace(-w * 0.5 + d, w * 0.5 + d - 1, steps=w).numpy()[None, :]  # step is exactly 1
+    ys = torch.linspace(-h * 0.5 + d, h * 0.5 + d - 1, steps=h).numpy()[:, None]
+    out = np.empty((1, h, w, 2), dtype=np.float32)
+    for j in range(2):
+        acc = np.broadcast_to(xs * r[j, 0], (h, w)).astype(np.float32)
+        acc = _fma32(np.broadcast_to(ys, (h, w)), np.broadcast_to(r[j, 1], (h, w)), acc)
+        out[0, :, :, j] = acc + r[j, 2]
+    return torch.from_numpy(out)
 
 
 def warp_nearest(x: torch.Tensor, matrix: Sequence[float]) -> torch.Tensor:

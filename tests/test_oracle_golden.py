@@ -164,3 +164,27 @@ def test_transform_draw_order():
             im = T.apply_gamma(im, T.draw_gamma(0.7, 1.5))
         np.testing.assert_array_equal(im.numpy(), d[f"compose_{seed}/image"])
         np.testing.assert_array_equal(lb.numpy(), d[f"compose_{seed}/label"])
+
+
+def test_affine_grid_restatement_equals_torch_bmm_on_this_cpu():
+    """oracle._affine_grid writes torchvision's `base.bmm(theta')` out as k-sequential fused accumulation so that it is
+    machine independent; here it is pinned to torch's own bmm, bit for bit, as run on the dev container's CPU (the GPU
+    kernel csrc/augment.hip::affine_src follows the same order).  Another CPU may dispatch a different sgemm kernel; a
+    difference there is reported as a skip, not a failure."""
+    import numpy as np
+    from oracle import transforms_ref as R
+    rng = np.random.default_rng(3)
+    bad = tot = 0
+    for t in range(40):
+        h, w = int(rng.integers(30, 400)), int(rng.integers(30, 400))
+        ang = float(rng.uniform(-20, 20)) if t % 3 else float(rng.integers(-20, 21))
+        sc = float(rng.uniform(0.7, 1.4)) if t % 2 else 1.0
+        sh = [float(rng.uniform(-8, 8)), 0.0] if t % 4 == 0 else [0.0, 0.0]
+        tr = [float(rng.integers(-6, 7)), float(rng.integers(-6, 7))] if t % 5 == 0 else [0.0, 0.0]
+        m = R.inverse_affine_matrix([0.0, 0.0], ang, tr, sc, sh)
+        g1, g2 = R._affine_grid(m, w, h), R._affine_grid_bmm(m, w, h)
+        bad += int((g1 != g2).sum())
+        tot += g1.numel()
+    if bad and torch.backends.cpu.get_cpu_capability() != "AVX512":
+        pytest.skip(f"{bad} of {tot} grid values differ from this CPU's sgemm ({torch.backends.cpu.get_cpu_capability()})")
+    assert bad == 0, (bad, tot)
