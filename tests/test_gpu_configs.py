@@ -8,8 +8,8 @@
 * cfg5: `[96..3072]` six levels: one fp32 image vs the oracle at a size the CPU affords, and the full 768x768 bs 16 bf16
   shape through size-independent properties (batch independence, determinism, descent).
 
-Tolerances: fp32 logits / loss 1e-4 (north_star); fp32 parameter gradients 2e-3 of each tensor's max against the EXACT
-(fp64-oracle) gradient, or 2x the fp32 oracle's own distance from it (see `_fp32_step_vs_oracle`); bf16 -- `BF16_*` below.
+Tolerances: fp32 logits / loss 1e-4 (north_star); fp32 parameter gradients: relative L2 5e-3 from the EXACT (fp64-oracle)
+gradient, or 2x the fp32 oracle's own distance from it (why: `_check_grads_vs_exact`); bf16 -- `BF16_*` below.
 """
 import math
 
@@ -98,33 +98,42 @@ def _oracle_step(state, x, y, k1, norm, lr, opt_name="adamw", wd=5e-4, dtype=tor
 
 
 def _grad_err(got, ref64):
-    return float((got.double() - ref64).abs().max() / max(float(ref64.abs().max()), 1e-3))
+    """(relative L2 distance, max |err| / max |ref|) of a gradient tensor from the exact (fp64-oracle) one."""
+    d = got.double() - ref64
+    nrm = float(ref64.norm())
+    rel = float(d.norm()) / nrm if nrm > 1e-7 * math.sqrt(ref64.numel()) else float(d.abs().max()) / 1e-4  # zero true gradient: |err| < 1e-4 * bound
+    return rel, float(d.abs().max() / max(float(ref64.abs().max()), 1e-3))
 
 
 def _check_grads_vs_exact(named_grads, ref_grads32, g64):
-    """Per-tensor gradient bar: within 2e-3 (of the tensor's max) of the EXACT gradient (oracle in fp64), or within 2x the
-    fp32 oracle's own distance from it on that tensor, or within 4x the chain's fp32 noise floor (the median over tensors of
-    the fp32 oracle's distance): two fp32 evaluations of these nets are two draws of amplified rounding noise, and a single
-    tensor's draw can be several times luckier on one side.  Returns (worst name, hip err, oracle err, worst hip-vs-fp32)."""
+    """Per-tensor gradient bar, measured against the EXACT gradient (the oracle run in fp64):
+    relative L2 distance <= max(5e-3, 2x the fp32 oracle's own distance on that tensor, 1.5x the fp32 oracle's worst tensor).
+
+    Why not "max |err| <= 2e-3 of the tensor's max against the fp32 oracle" (the bar of the small golden models): at these
+    widths two fp32 evaluations of one network do not agree that closely with each other.  A pre-activation that lands
+    within fp32 rounding of zero takes LeakyReLU's other slope (0.01 vs 1) in one evaluation and not in the other; that one
+    element changes the 9*Cin weight-gradient entries of its output channel by ~1 / sqrt(pixels) of their size (seen as
+    a single row off by 1e-2..1e-1 of the tensor's max while every other row agrees to 1e-4: tools/diag_fullwidth.py) and
+    every gradient upstream by ~1 / sqrt(elements of the layer) ~ 1e-3 in relative L2; the normalisation backward behind it
+    (mean / x-hat projections) amplifies it further.  Such flips hit the fp32 CPU oracle and the HIP path independently
+    -- the oracle's own tensors sit 3e-3 .. 1.6e-1 (max norm) from exact.  Relative L2 is the norm in which a flip stays
+    small (few e-3) while a structural fault does not (one dropped 16x16 tile of a 128x128 map: >= 0.12; a wrong tap:
+    ~0.33; a missed 32-channel chunk of 64: ~0.7).  Returns the worst tensor's figures for the log."""
     e_cpu = {k: _grad_err(ref_grads32[k], g64[k]) for k in g64}
-    floor = float(np.median([v for v in e_cpu.values()]))
-    worst, worst32 = ("", 0.0, 0.0), 0.0
+    cpu_worst = max(v[0] for v in e_cpu.values())
+    worst, worst_max = ("", 0.0, 0.0), 0.0
     for name, g in named_grads:
-        e_hip = _grad_err(g.cpu(), g64[name])
-        worst32 = max(worst32, _grad_err(g.cpu(), ref_grads32[name].double()))
-        if e_hip > worst[1]:
-            worst = (name, e_hip, e_cpu[name])
-        assert e_hip < max(2e-3, 2.0 * e_cpu[name], 4.0 * floor), (name, e_hip, e_cpu[name], floor)
-    return worst + (worst32, floor)
+        rel, mx = _grad_err(g.cpu(), g64[name])
+        worst_max = max(worst_max, mx)
+        if rel > worst[1]:
+            worst = (name, rel, e_cpu[name][0])
+        assert rel < max(5e-3, 2.0 * e_cpu[name][0], 1.5 * cpu_worst), (name, rel, e_cpu[name], cpu_worst)
+    return worst + (worst_max, cpu_worst, max(v[1] for v in e_cpu.values()))
 
 
 def _fp32_step_vs_oracle(channels, norm, size, n, k1=3, seed=3, lr=1e-3):
-    """fp32 parity of one train step.  Logits / loss / label maps: 1e-4 against the fp32 oracle (north_star).  Parameter
-    gradients: measured against the oracle run in fp64, because at these widths the fp32 ORACLE ITSELF sits 3e-3 .. 8e-2
-    (of a tensor's max) away from exact arithmetic on some tensors -- normalisation backward cancels most of each incoming
-    gradient, which amplifies fp32 rounding (figures: tools/diag_fullwidth.py) -- so "equal to the fp32 oracle to 2e-3"
-    would test rounding noise against rounding noise.  Bar: the HIP path is within 2e-3 of the exact gradient, or within
-    2x the fp32 oracle's own distance from it, per tensor; the direct HIP-vs-fp32-oracle figure is printed."""
+    """fp32 parity of one train step: logits / loss / label maps 1e-4 against the fp32 oracle (north_star); parameter
+    gradients by `_check_grads_vs_exact`; clip norm; post-AdamW state (incl. batch-norm running statistics)."""
     dev = _dev()
     torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
     m = _model(dev, channels, norm, k1).train()
@@ -157,8 +166,8 @@ def _fp32_step_vs_oracle(channels, norm, size, n, k1=3, seed=3, lr=1e-3):
         else:
             assert torch.equal(v.cpu(), ref), k
     print(f"[fp32 {channels[0]}..{channels[-1]} {norm} {size}x{size}x{n}] loss {loss.item():.6f} (oracle {ref_loss:.6f}); gradient "
-          f"vs exact (fp64 oracle): worst {worst[1]:.2e} at {worst[0]} where the fp32 oracle has {worst[2]:.2e}; worst vs the fp32 "
-          f"oracle {worst[3]:.2e}; fp32 noise floor (median oracle distance) {worst[4]:.2e}")
+          f"rel-L2 from exact: worst {worst[1]:.2e} at {worst[0]} (fp32 oracle there {worst[2]:.2e}, oracle's worst tensor "
+          f"{worst[4]:.2e}); max-norm: HIP {worst[3]:.2e}, fp32 oracle {worst[5]:.2e}")
 
 
 def test_full_width_fp32_train_step_vs_oracle():
@@ -265,8 +274,8 @@ def test_cfg4_busi_pipeline_and_train_step_vs_oracle():
             assert float((v.cpu() - ref).abs().max()) < 2e-5, k
         elif ref.is_floating_point():
             assert float((v.cpu() - ref).abs().max()) < 2.5 * lr + 1e-6, k
-    print(f"[cfg4] stages {names}, loss {loss.item():.6f} (oracle {ref_loss:.6f}); gradient vs exact: worst {worst[1]:.2e} at {worst[0]} "
-          f"(fp32 oracle there {worst[2]:.2e}), worst vs the fp32 oracle {worst[3]:.2e}, noise floor {worst[4]:.2e}")
+    print(f"[cfg4] stages {names}, loss {loss.item():.6f} (oracle {ref_loss:.6f}); gradient rel-L2 from exact: worst {worst[1]:.2e} at "
+          f"{worst[0]} (fp32 oracle there {worst[2]:.2e}, oracle's worst {worst[4]:.2e}); max-norm: HIP {worst[3]:.2e}, oracle {worst[5]:.2e}")
 
 
 CH5 = [96, 192, 384, 768, 1536, 3072]

@@ -9,11 +9,12 @@ import test_gpu_configs as T
 dev = torch.device("cuda:0")
 torch.set_num_threads(16)
 dtype = torch.bfloat16 if "bf16" in sys.argv else torch.float32
-channels, norm, k1 = [64, 128, 256, 512, 1024], "instance", 3
+channels = [int(c) for c in os.environ.get("DIAG_CH", "64,128,256,512,1024").split(",")]
+norm, k1 = os.environ.get("DIAG_NORM", "instance"), 3
 m = T._model(dev, channels, norm, k1, dtype).train()
 state = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
 SIZE = int(os.environ.get("DIAG_SIZE", "128")); NB = int(os.environ.get("DIAG_N", "2"))
-x, y = T._batch(NB, SIZE, seed=3)
+x, y = T._batch(NB, SIZE, seed=int(os.environ.get("DIAG_SEED", "3")))
 
 def oracle(dt):
     p = {k: (v.detach().to(dt).clone() if v.is_floating_point() else v.clone()) for k, v in state.items()}
