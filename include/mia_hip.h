@@ -58,6 +58,9 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
 #define MIA_CONV_T3S2 3 /* transposed 3x3 s2: strided Conv2d input gradient */
 #define MIA_CONV_T2S2 4 /* transposed 2x2 s2: ConvTranspose2d fwd (unet.py:142, :212) */
 #define MIA_CONV_G1 5   /* 1x1: ResidualBlock skip conv (blocks.py:147-153) */
+/* Tuning / A-B knobs (process-wide, not part of any reference interface): "conv64" = 1 (default) lets 64 -> 64 channel
+ * bf16 3x3 stride-1 launches take the persistent register-weight kernel, 0 sends them through the generic tile kernel. */
+int mia_set_option(const char* name, int value);
 /* out[p][n] = bias[n] + sum_taps sum_k in[p*s + tap - pad][k] * wpack[tap][n][k].
  * in1|in2 are concatenated along channels (c1 + c2) -- this is how torch.cat([skip, up], 1)
  * (unet.py:213) is eliminated; out1|out2 are split along channels (o1 + o2) for its gradient.

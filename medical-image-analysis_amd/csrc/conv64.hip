@@ -1,0 +1,318 @@
+// 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels, bf16 -- the "canonical block" launch of the
+// benchmark (the full-resolution C0 -> C0 PlainBlock conv, reference src/models/unet/blocks.py:83-90)
+// and its input gradient (same kernel, taps flipped).  Persistent, weights held in registers.
+//
+// Why a second kernel for this one shape: at 64 channels the generic tile kernel (conv_mma_fast.hip) re-stages the whole
+// 72 KB weight tensor for every 256-pixel tile -- more bytes through the load / ds_write path than the tile's own input
+// (41 KB) -- and spends a third of each tile in an LDS-transposed epilogue.  Here
+//   * a workgroup walks MANY tiles; the weights are read from memory ONCE per workgroup: wave w owns output channels
+//     16w .. 16w+15 and keeps their 2 x 9 MFMA A-operand fragments (all taps, both 32-channel halves) in 72 VGPRs;
+//   * the MFMA operands are swapped (A = weights: M = output channel, B = pixels: N = pixel), so a lane's four accumulator
+//     registers are four CONSECUTIVE output channels of one pixel: the epilogue stores 8 bytes per lane straight from the
+//     accumulators (each pixel's 32-byte segment per wave), no LDS transpose, and the bias rides in as the first MFMA's C;
+//   * only the input tile is staged per tile (12 buffer loads + 12 ds_write_b128 per thread instead of 30 + 30), prefetched
+//     into registers behind the previous tile's MFMAs;
+//   * per (channel half, horizontal tap) a wave reads each of the 18 input rows once and slides the three vertical taps over
+//     it: 108 ds_read_b128 per 288 MFMAs;
+//   * blockIdx -> tile mapping gives each XCD a contiguous run of tiles per step (neighbouring tiles share halo rows in
+//     that XCD's L2).
+// LDS image of a tile: the layout of conv_mma_fast.hip ([channel-group plane][pixel], plane pitch == 2 (mod 16) units, pixel
+// <-> MFMA column permuted by pi16) so fragment reads and staging writes are bank-conflict free.
+//
+// Contract (checked by conv64_eligible, otherwise conv_mma_fast runs): bf16, one source, one destination, 64 -> 64 channels,
+// packed weights [9][64][64], 16-byte aligned pointers, per-image tensors < 2 GiB.
+#include "conv_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define SENT 0xFFFFFFF0u /* always beyond num_records */
+
+namespace {
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+constexpr int C = 64;             // channels in == out
+constexpr int TH = 16, TW = 16;   // output tile
+constexpr int IH = TH + 2, IW = TW + 2, PITCH = IW;
+constexpr int A_IT = (IH * IW + 63) / 64;                  // 6 staging iterations of 64 pixels x 4 channel groups (x 2 halves)
+constexpr int NPA = ((A_IT * 64 + 13) / 16) * 16 + 2;      // plane pitch in 16-byte units, == 2 (mod 16)
+constexpr int LDS_BYTES = 8 * NPA * 16;
+
+struct Tile { int img, ty, tx; };
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// two floats -> packed bf16 pair (low = a): ONE v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+
+// sum over the 16 lanes of a DPP row (every lane gets the total): 4 v_add_f32 with DPP operands, no LDS crossbar
+__device__ __forceinline__ float row16_sum(float v) {
+  int iv;
+  iv = __builtin_bit_cast(int, v); v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xF, 0xF, false));   // lane ^ 1
+  iv = __builtin_bit_cast(int, v); v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xF, 0xF, false));   // lane ^ 2
+  iv = __builtin_bit_cast(int, v); v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  iv = __builtin_bit_cast(int, v); v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x140, 0xF, 0xF, false));  // row_mirror
+  return v;
+}
+
+}  // namespace
+
+// Diagnostic build only (-DCONV64_STAMPS, tools/conv64_stamps.py): per-wave cycle sums of the phases of a tile.  The shipped
+// library executes no stamp.
+#ifdef CONV64_STAMPS
+__device__ unsigned long long conv64_dbg[512 * 4 * 8];
+#define STAMP(var)                                                                          \
+  do {                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");             \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  } while (0)
+extern "C" int mia_conv64_debug_read(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(conv64_dbg), sizeof(conv64_dbg));
+}
+#else
+#define STAMP(var) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a, int total_tiles, int tiles_per_img, int run) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  u32x4* ldsA = reinterpret_cast<u32x4*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, c16 = lane & 15;
+  const int pr = pi16(c16);          // pixel (within a 16-pixel run) of this lane's MFMA column
+  const int g = tid & 3, p4 = tid >> 2;
+
+  // ---- weights: A operand fragments, lane (row = c16 -> output channel 16*wave + c16, k group q), resident for the whole launch
+  const rsrc_t rsw = make_rsrc(a.wp, (unsigned)(9 * C * C * 2));
+  u32x4 wf[2][3][3];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < 3; ++tb) {
+        const int t = ta * 3 + tb;
+        const int tw = a.flip ? 8 - t : t;
+        wf[c][ta][tb] = __builtin_amdgcn_raw_buffer_load_b128(rsw, ((16 * wave + c16) * C + 32 * c + 8 * q) * 2, tw * C * C * 2, 0);
+      }
+  // bias of this lane's four output channels = the first MFMA's C operand
+  f32x4 bv;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bv[r] = a.bias ? a.bias[16 * wave + 4 * q + r] : 0.f;
+
+  // tile walk: per step every XCD (blocks b, b+8, ... share one) takes a contiguous run of `run` tiles
+  const int nblk = gridDim.x, b = blockIdx.x;
+  const int first = (b & 7) * run + (b >> 3);
+  const int stride = 8 * run;  // == nblk when nblk % 8 == 0 (the host launches multiples of 8)
+  auto decode = [&](int t) -> Tile {
+    Tile r;
+    r.img = t / tiles_per_img;
+    const int rem = t - r.img * tiles_per_img;
+    r.ty = rem / a.tiles_x;
+    r.tx = rem - r.ty * a.tiles_x;
+    return r;
+  };
+  // the walk advances by a constant number of tiles: its (image, row, column) digits once, then carries -- no divisions per tile
+  const Tile dstep = decode(stride);
+  auto advance = [&](Tile r) -> Tile {
+    r.tx += dstep.tx;
+    if (r.tx >= a.tiles_x) { r.tx -= a.tiles_x; r.ty += 1; }
+    r.ty += dstep.ty;
+    if (r.ty >= a.tiles_y) { r.ty -= a.tiles_y; r.img += 1; }
+    r.img += dstep.img;
+    return r;
+  };
+
+  const size_t ipix = (size_t)a.Hin * a.Win;
+  const unsigned img_bytes = (unsigned)(ipix * C * 2);
+  const bf16_t* in = static_cast<const bf16_t*>(a.in1);
+  bf16_t* out = static_cast<bf16_t*>(a.out1);
+
+  u32x4 pf[2 * A_IT];
+  auto fetch = [&](const Tile& t) {
+    const rsrc_t rs = make_rsrc(in + (size_t)t.img * ipix * C, img_bytes);
+    const int iy0 = t.ty * TH - 1, ix0 = t.tx * TW - 1;
+    // staging geometry is recomputed per tile from an opaque copy of the thread's pixel slot: a hoisted per-thread table
+    // would be spilled around the tile loop, and its reload's vmcnt(0) would serialise the prefetch behind the stores
+    int p4v = p4;
+    asm volatile("" : "+v"(p4v));
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= a.Hin && ix0 + IW <= a.Win;  // uniform: no border tests needed
+    const int tile_off = (iy0 * a.Win + ix0) * (C * 2) + g * 16;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int pix = p4v + 64 * i, iy = pix / IW, ix = pix - iy * IW;
+      unsigned voff;
+      if (interior) {
+        voff = (unsigned)(tile_off + (iy * a.Win + ix) * (C * 2));
+        if (i == A_IT - 1) voff = (pix < IH * IW) ? voff : SENT;
+      } else {
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        const int okm = -(int)(((unsigned)gy < (unsigned)a.Hin) & ((unsigned)gx < (unsigned)a.Win) & (pix < IH * IW));
+        const unsigned off = (unsigned)((gy * a.Win + gx) * (C * 2) + g * 16);
+        voff = (off & (unsigned)okm) | (SENT & ~(unsigned)okm);
+      }
+      pf[2 * i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
+      pf[2 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 64, 0);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      ldsA[g * NPA + p4 + 64 * i] = pf[2 * i];
+      ldsA[(4 + g) * NPA + p4 + 64 * i] = pf[2 * i + 1];
+    }
+  };
+
+  int t = first;
+  if (t >= total_tiles) return;  // uniform per workgroup
+  Tile cur = decode(t);
+  fetch(cur);
+  commit();
+  __syncthreads();
+
+#ifdef CONV64_STAMPS
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, acc_f = 0, acc_m = 0, acc_e = 0, acc_b = 0, acc_c = 0, ntl = 0;
+#endif
+  while (true) {
+    STAMP(ts0);
+    const int tn = t + stride;
+    const bool more = tn < total_tiles;  // uniform
+    Tile nxt = cur;
+    if (more) { nxt = advance(cur); fetch(nxt); }
+
+    STAMP(ts1);
+    // ---- 288 MFMAs: 2 channel halves x 3 horizontal taps x 18 input rows, each row feeding up to three output rows
+    f32x4 acc[TH];
+    constexpr int GROUPS = 6, RPG = 3;  // rows per prefetch group
+    u32x4 fr[2][RPG];
+    auto load_group = [&](int gi, u32x4* f) {  // gi in [0, 36): phase = gi / 6 -> (c, tb), rows 3*(gi%6) .. +2
+      const int ph = gi / GROUPS, c = ph / 3, tb = ph % 3, r0 = (gi % GROUPS) * RPG;
+#pragma unroll
+      for (int j = 0; j < RPG; ++j) f[j] = ldsA[(4 * c + q) * NPA + (r0 + j) * PITCH + tb + pr];
+    };
+    load_group(0, fr[0]);
+#pragma unroll
+    for (int gi = 0; gi < 6 * GROUPS; ++gi) {
+      const int ph = gi / GROUPS, c = ph / 3, tb = ph % 3, r0 = (gi % GROUPS) * RPG;
+      if (gi + 1 < 6 * GROUPS) load_group(gi + 1, fr[(gi + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the next group's reads ahead of this group's MFMAs
+#pragma unroll
+      for (int j = 0; j < RPG; ++j) {
+        const int r = r0 + j;
+#pragma unroll
+        for (int ta = 0; ta < 3; ++ta) {
+          const int m = r - ta;
+          if (m >= 0 && m < TH) {
+            const bool first_touch = (ph == 0 && ta == 0);  // (c, tb) = (0, 0), ta = 0 is the first product into acc[m]
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[c][ta][tb]),
+                                                             __builtin_bit_cast(bf16x8, fr[gi & 1][j]), first_touch ? bv : acc[m], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    STAMP(ts2);
+    // ---- epilogue: statistics + 8-byte stores straight from the accumulators
+    const int oy0 = cur.ty * TH, ox0 = cur.tx * TW;
+    const bool full = (oy0 + TH <= a.Hout) && (ox0 + TW <= a.Wout);  // uniform
+    const bool colok = ox0 + pr < a.Wout;
+    const rsrc_t rso = make_rsrc(out + (size_t)cur.img * ipix * C, img_bytes);
+    // Two output rows per store: v_permlane16_swap trades the 8-byte halves between the lane pairs (q, q^1) that hold the
+    // same pixel column, so an even-q lane ends up with 8 consecutive channels (16 bytes) of row m and its odd-q partner
+    // with the same 8 channels of row m+1 -- 8 dwordx4 stores per tile instead of 16 dwordx2 (the tail is store-ISSUE bound).
+    const int qodd = q & 1;
+    const unsigned obase = (unsigned)((((oy0 + qodd) * a.Wout) + ox0 + pr) * (C * 2) + (16 * wave + 8 * (q >> 1)) * 2);
+    const int row_bytes = a.Wout * (C * 2);
+    const bool want_stats = a.stats != nullptr;  // uniform
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    auto store_rows = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+      for (int m = 0; m < TH; m += 2) {
+        if (want_stats) {
+#pragma unroll
+          for (int mm = m; mm < m + 2; ++mm) {
+            const float w = (FULL || (colok && oy0 + mm < a.Hout)) ? 1.f : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float v = acc[mm][r]; const float vm = FULL ? v : v * w; s1[r] += vm; s2[r] += vm * v; }
+          }
+        }
+        // packed bf16 pairs: x = row m, y = row m+1 (this lane's 4 channels each)
+        const unsigned x0 = pack_bf16x2(acc[m][0], acc[m][1]), x1 = pack_bf16x2(acc[m][2], acc[m][3]);
+        const unsigned y0 = pack_bf16x2(acc[m + 1][0], acc[m + 1][1]), y1 = pack_bf16x2(acc[m + 1][2], acc[m + 1][3]);
+        // vdst rows 1,3 (odd q) <-> src rows 0,2 (even q): even q gets its partner's x in y, odd q its partner's y in x
+        const auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+        const u32x4 d = {r0[0], r1[0], r0[1], r1[1]};
+        if constexpr (FULL) {
+          __builtin_amdgcn_raw_buffer_store_b128(d, rso, (int)obase, m * row_bytes, 0);  // row offset rides in the scalar offset
+        } else {
+          const bool ok = colok && (oy0 + m + qodd < a.Hout);
+          const unsigned voff = ok ? obase + (unsigned)(m * row_bytes) : SENT;
+          __builtin_amdgcn_raw_buffer_store_b128(d, rso, (int)voff, 0, 0);
+        }
+      }
+    };
+    if (full) store_rows(std::true_type{});
+    else store_rows(std::false_type{});
+    if (want_stats) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
+      if (c16 == 0) {
+        const size_t tile = (size_t)cur.img * tiles_per_img + (size_t)cur.ty * a.tiles_x + cur.tx;
+        typedef __attribute__((address_space(1))) f32x4 gf32x4;  // global (not flat) store: see conv_mma_fast.hip
+        gf32x4* dst = (gf32x4*)(a.stats + (tile * C + 16 * wave + 4 * q) * 2);
+        dst[0] = f32x4{s1[0], s2[0], s1[1], s2[1]};
+        dst[1] = f32x4{s1[2], s2[2], s1[3], s2[3]};
+      }
+    }
+    STAMP(ts3);
+#ifdef CONV64_STAMPS
+    acc_f += ts1 - ts0; acc_m += ts2 - ts1; acc_e += ts3 - ts2; ntl += 1;
+#endif
+    if (!more) break;
+    __syncthreads();  // every wave has read the current image out of LDS
+    STAMP(ts4);
+    commit();
+    __syncthreads();
+    STAMP(ts5);
+#ifdef CONV64_STAMPS
+    acc_b += ts4 - ts3; acc_c += ts5 - ts4;
+#endif
+    t = tn;
+    cur = nxt;
+  }
+#ifdef CONV64_STAMPS
+  if (lane == 0) {
+    unsigned long long* d = conv64_dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+    d[0] = acc_f; d[1] = acc_m; d[2] = acc_e; d[3] = acc_b; d[4] = acc_c; d[5] = ntl;
+  }
+#endif
+}
+
+bool conv64_eligible(int mode, int dtype, const ConvArgs& a) {
+  if (mode != MODE_G3S1 || dtype != MIA_BF16) return false;
+  if (a.c1 != C || a.c2 != 0 || a.o1 != C || a.o2 != 0 || a.npad != C || a.kpad != C) return false;
+  if (!a.vec_in || !a.vec_out) return false;
+  if ((size_t)a.Hin * a.Win * C * 2 >= ((size_t)1 << 31)) return false;
+  if (a.Hout <= 8) return false;  // the statistics layout of small maps uses 8-row tiles (mia_conv_mma_tiles)
+  return true;
+}
+
+int conv64_launch(const ConvArgs& a, hipStream_t st) {
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int total = a.N * tiles_per_img;
+  // two workgroups per CU (256 CUs); a multiple of 8 so the per-XCD runs tile the step exactly
+  int nblk = total < 512 ? ((total + 7) / 8) * 8 : 512;
+  if (const char* e = getenv("MIA_CONV64_BLOCKS")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0 && v <= nblk) nblk = v; }  // diagnostics
+  const int run = nblk / 8;
+  hipLaunchKernelGGL(conv64_persist_kernel, dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run);
+  return MIA_OK;
+}

@@ -54,3 +54,8 @@ template <> struct Mma<float> {
 // shape does not meet its alignment contract and the generic kernel must be used.
 bool conv_mma_fast_eligible(int dtype, const ConvArgs& a, int nt);
 int conv_mma_fast_launch(int mode, int dtype, const ConvArgs& a, int mt, int nt, int grid_y, hipStream_t st);
+
+// conv64.hip: persistent 64 -> 64 channel 3x3 / stride-1 bf16 kernel with register-resident weights (the canonical block
+// launch of the benchmark and its input gradient); false = shape outside its contract.
+bool conv64_eligible(int mode, int dtype, const ConvArgs& a);
+int conv64_launch(const ConvArgs& a, hipStream_t st);

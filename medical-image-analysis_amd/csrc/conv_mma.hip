@@ -290,6 +290,15 @@ static int dispatch(int mode, const ConvArgs& a, int mt, int nt, int grid_y, hip
 // Tile-domain geometry shared with the host (stats buffer sizing): see include/mia_hip.h.
 static int g_big_tiles = -1;  // MIA_CONV_MT8=1: 32-row tiles for bf16 3x3 s1 (experiment knob, default off)
 
+static int g_use64 = -1;  // MIA_CONV64=0 / mia_set_option("conv64", 0): 64-channel launches take the generic tile kernel (A/B knob)
+
+extern "C" int mia_set_option(const char* name, int value) {
+  MIA_CHECK_ARG(name != nullptr, "mia_set_option: null name");
+  if (strcmp(name, "conv64") == 0) { g_use64 = value ? 1 : 0; return MIA_OK; }
+  mia_set_error("mia_set_option: unknown option '%s'", name);
+  return MIA_EARG;
+}
+
 extern "C" int mia_conv_mma_tiles(int mode, int hout, int wout, int* tiles_y, int* tiles_x, int* tile_h) {
   const bool tmode = (mode == MODE_T3S2 || mode == MODE_T2S2);
   const int hd = tmode ? (hout + 1) / 2 : hout, wd = tmode ? (wout + 1) / 2 : wout;
@@ -347,7 +356,9 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
     mia_set_error("mia_conv_mma: MIA_CONV_MT8 tiles need the bf16 fast path with >= 64 output channels");
     return MIA_EUNSUPPORTED;
   }
-  if (fast) rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
+  if (g_use64 < 0) { const char* e = getenv("MIA_CONV64"); g_use64 = (e && e[0] == '0') ? 0 : 1; }
+  if (g_use64 && mt == 4 && conv64_eligible(mode, dtype, a)) rc = conv64_launch(a, st);
+  else if (fast) rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
   else rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);
   if (rc != MIA_OK) return rc;
   MIA_LAUNCH_CHECK();

@@ -55,6 +55,11 @@ CONV_CASES = [
     (1, 96, 96, 96, 24, 40),
     (2, 40, 24, 64, 20, 36),
     (1, 32, 96, 128, 16, 48),
+    # 64 -> 64 persistent register-weight kernel (conv64.hip): ragged right / bottom tiles, fewer tiles than workgroups,
+    # more tiles than workgroups (several steps of the tile walk)
+    (2, 64, 0, 64, 37, 53),
+    (1, 64, 0, 64, 9, 200),
+    (3, 64, 0, 64, 200, 216),
 ]
 
 

@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Diagnostic: where a tile of the persistent 64-channel conv spends its cycles (in-kernel s_memtime stamps).
+
+Builds a SEPARATE library with -DCONV64_STAMPS into tools/ab/ (never the shipped one), runs the canonical launch and
+prints the per-wave mean cycles per tile of each phase.  Read the SHARES, not the length (the stamps serialise)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "medical-image-analysis_amd")
+OUT = os.path.join(ROOT, "tools", "ab")
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    lib = os.path.join(OUT, "libmia_hip_stamps.so")
+    srcs = sorted(os.path.join(PKG, "csrc", f) for f in os.listdir(os.path.join(PKG, "csrc")) if f.endswith(".hip"))
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-shared", "-DCONV64_STAMPS",
+           "-o", lib] + srcs
+    subprocess.run(cmd, check=True)
+    return lib
+
+
+def main():
+    if "build" in sys.argv:
+        print(build())
+        return
+    os.environ["MIA_HIP_LIB"] = os.path.join(OUT, "libmia_hip_stamps.so")
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import numpy as np
+    import torch
+    import mia_hip
+    from mia_hip import CONV_G3S1, ops
+    dev = torch.device("cuda:0")
+    x = torch.randn(32, 512, 512, 64, device=dev).to(torch.bfloat16)
+    w = (torch.randn(64, 64, 3, 3, device=dev) / 24)
+    b = torch.randn(64, device=dev)
+    wp, npad, kpad = ops.PackCache().get(w, mia_hip.BF16, True)
+    for _ in range(3):
+        ops.conv_mma(CONV_G3S1, x, None, wp, npad, kpad, False, b, 64, (512, 512), want_stats=True)
+    torch.cuda.synchronize()
+    l = ctypes.CDLL(os.environ["MIA_HIP_LIB"])
+    buf = np.zeros(512 * 4 * 8, dtype=np.uint64)
+    rc = l.mia_conv64_debug_read(buf.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0, rc
+    d = buf.reshape(512, 4, 8).astype(np.float64)
+    n = d[..., 5]
+    names = ["fetch issue", "MFMA loop", "epilogue", "barrier 1 (wait)", "commit + barrier 2"]
+    tot = 0.0
+    for i, nm in enumerate(names):
+        per = (d[..., i] / np.maximum(n, 1)).mean()
+        tot += per
+        print(f"{nm:20s} {per:9.0f} cycles / tile / wave")
+    print(f"{'sum':20s} {tot:9.0f}   (tiles per workgroup: {n.mean():.1f}; MFMA issue floor 288 x 16 = 4608)")
+
+
+if __name__ == "__main__":
+    main()
