@@ -14,6 +14,7 @@
 //     into registers behind the previous tile's MFMAs;
 //   * per (channel half, horizontal tap) a wave reads each of the 18 input rows once and slides the three vertical taps over
 //     it: 108 ds_read_b128 per 288 MFMAs;
+//   * measured and rejected here: s_setprio 1 around the matrix phase (0.543 -> 0.552 ms on the canonical launch);
 //   * blockIdx -> tile mapping gives each XCD a contiguous run of tiles per step (neighbouring tiles share halo rows in
 //     that XCD's L2).
 // LDS image of a tile: the layout of conv_mma_fast.hip ([channel-group plane][pixel], plane pitch == 2 (mod 16) units, pixel
@@ -48,6 +49,12 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 // two floats -> packed bf16 pair (low = a): ONE v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+
+// s1 += v; s2 += v * v as two single-issue VALU instructions (hipcc otherwise SLP-packs the pair into mov + mul + v_pk_add_f32,
+// three instructions of which the packed one costs double beside MFMAs)
+__device__ __forceinline__ void stat_acc(float& s1, float& s2, float v) {
+  asm volatile("v_add_f32 %0, %2, %0\n\tv_fmac_f32 %1, %2, %2" : "+v"(s1), "+v"(s2) : "v"(v));
 }
 
 // sum over the 16 lanes of a DPP row (every lane gets the total): 4 v_add_f32 with DPP operands, no LDS crossbar
@@ -234,6 +241,9 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     auto store_rows = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
+      // the inline-asm statistics below read MFMA results; hipcc pads hazards only for instructions it emits itself, so the
+      // last accumulators written (rows 15, 14, 13) get their 12+ wait states here
+      if constexpr (FULL) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
 #pragma unroll
       for (int m = 0; m < TH; m += 2) {
         if (want_stats) {
@@ -241,7 +251,11 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
           for (int mm = m; mm < m + 2; ++mm) {
             const float w = (FULL || (colok && oy0 + mm < a.Hout)) ? 1.f : 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float v = acc[mm][r]; const float vm = FULL ? v : v * w; s1[r] += vm; s2[r] += vm * v; }
+            for (int r = 0; r < 4; ++r) {
+              const float v = acc[mm][r];
+              if constexpr (FULL) stat_acc(s1[r], s2[r], v);
+              else { const float vm = v * w; s1[r] += vm; s2[r] += vm * v; }
+            }
           }
         }
         // packed bf16 pairs: x = row m, y = row m+1 (this lane's 4 channels each)
