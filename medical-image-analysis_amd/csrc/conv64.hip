@@ -20,8 +20,9 @@
 // LDS image of a tile: the layout of conv_mma_fast.hip ([channel-group plane][pixel], plane pitch == 2 (mod 16) units, pixel
 // <-> MFMA column permuted by pi16) so fragment reads and staging writes are bank-conflict free.
 //
-// Contract (checked by conv64_eligible, otherwise conv_mma_fast runs): bf16, one source, one destination, 64 -> 64 channels,
-// packed weights [9][64][64], 16-byte aligned pointers, per-image tensors < 2 GiB.
+// Contract (checked by conv64_eligible, otherwise conv_mma_fast runs): bf16, one 64-channel source, one or two 64-channel
+// destinations (two = the input gradient of a decoder block whose input was [skip | up]: one launch per destination over
+// the same input), packed weights [9][64 or 128][64], 16-byte aligned pointers, per-image tensors < 2 GiB.
 #include "conv_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -86,7 +87,7 @@ extern "C" int mia_conv64_debug_read(unsigned long long* host_out) {
 #define STAMP(var) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a, int total_tiles, int tiles_per_img, int run) {
+__global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a, int total_tiles, int tiles_per_img, int run, int n_base) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
   u32x4* ldsA = reinterpret_cast<u32x4*>(smem);
 
@@ -97,7 +98,9 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
   const int g = tid & 3, p4 = tid >> 2;
 
   // ---- weights: A operand fragments, lane (row = c16 -> output channel 16*wave + c16, k group q), resident for the whole launch
-  const rsrc_t rsw = make_rsrc(a.wp, (unsigned)(9 * C * C * 2));
+  // n_base: first of this launch's 64 output channels inside a wider packed weight tensor / statistics row (a two-destination
+  // input gradient runs as two launches, one per destination)
+  const rsrc_t rsw = make_rsrc(a.wp, (unsigned)(9 * a.npad * C * 2));
   u32x4 wf[2][3][3];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -107,12 +110,12 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
       for (int tb = 0; tb < 3; ++tb) {
         const int t = ta * 3 + tb;
         const int tw = a.flip ? 8 - t : t;
-        wf[c][ta][tb] = __builtin_amdgcn_raw_buffer_load_b128(rsw, ((16 * wave + c16) * C + 32 * c + 8 * q) * 2, tw * C * C * 2, 0);
+        wf[c][ta][tb] = __builtin_amdgcn_raw_buffer_load_b128(rsw, ((n_base + 16 * wave + c16) * C + 32 * c + 8 * q) * 2, tw * a.npad * C * 2, 0);
       }
   // bias of this lane's four output channels = the first MFMA's C operand
   f32x4 bv;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) bv[r] = a.bias ? a.bias[16 * wave + 4 * q + r] : 0.f;
+  for (int r = 0; r < 4; ++r) bv[r] = a.bias ? a.bias[n_base + 16 * wave + 4 * q + r] : 0.f;
 
   // tile walk: per step every XCD (blocks b, b+8, ... share one) takes a contiguous run of `run` tiles
   const int nblk = gridDim.x, b = blockIdx.x;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
   const size_t ipix = (size_t)a.Hin * a.Win;
   const unsigned img_bytes = (unsigned)(ipix * C * 2);
   const bf16_t* in = static_cast<const bf16_t*>(a.in1);
-  bf16_t* out = static_cast<bf16_t*>(a.out1);
+  bf16_t* out = static_cast<bf16_t*>(n_base ? a.out2 : a.out1);
 
   u32x4 pf[2 * A_IT];
   auto fetch = [&](const Tile& t) {
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
       if (c16 == 0) {
         const size_t tile = (size_t)cur.img * tiles_per_img + (size_t)cur.ty * a.tiles_x + cur.tx;
         typedef __attribute__((address_space(1))) f32x4 gf32x4;  // global (not flat) store: see conv_mma_fast.hip
-        gf32x4* dst = (gf32x4*)(a.stats + (tile * C + 16 * wave + 4 * q) * 2);
+        gf32x4* dst = (gf32x4*)(a.stats + (tile * (size_t)(a.o1 + a.o2) + n_base + 16 * wave + 4 * q) * 2);
         dst[0] = f32x4{s1[0], s2[0], s1[1], s2[1]};
         dst[1] = f32x4{s1[2], s2[2], s1[3], s2[3]};
       }
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
 
 bool conv64_eligible(int mode, int dtype, const ConvArgs& a) {
   if (mode != MODE_G3S1 || dtype != MIA_BF16) return false;
-  if (a.c1 != C || a.c2 != 0 || a.o1 != C || a.o2 != 0 || a.npad != C || a.kpad != C) return false;
+  if (a.c1 != C || a.c2 != 0 || a.o1 != C || (a.o2 != 0 && a.o2 != C) || a.npad != a.o1 + a.o2 || a.kpad != C) return false;
   if (!a.vec_in || !a.vec_out) return false;
   if ((size_t)a.Hin * a.Win * C * 2 >= ((size_t)1 << 31)) return false;
   if (a.Hout <= 8) return false;  // the statistics layout of small maps uses 8-row tiles (mia_conv_mma_tiles)
@@ -327,6 +330,8 @@ int conv64_launch(const ConvArgs& a, hipStream_t st) {
   int nblk = total < 512 ? ((total + 7) / 8) * 8 : 512;
   if (const char* e = getenv("MIA_CONV64_BLOCKS")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0 && v <= nblk) nblk = v; }  // diagnostics
   const int run = nblk / 8;
-  hipLaunchKernelGGL(conv64_persist_kernel, dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run);
+  hipLaunchKernelGGL(conv64_persist_kernel, dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, 0);
+  if (a.o2 == C)  // second destination (e.g. the up-sampled half of a decoder block's input gradient): same input, next 64 filters
+    hipLaunchKernelGGL(conv64_persist_kernel, dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, C);
   return MIA_OK;
 }

@@ -60,6 +60,7 @@ CONV_CASES = [
     (2, 64, 0, 64, 37, 53),
     (1, 64, 0, 64, 9, 200),
     (3, 64, 0, 64, 200, 216),
+    (2, 32, 32, 64, 40, 56),  # input gradient = 64 -> (32 | 32): stays on the generic kernel
 ]
 
 
@@ -164,7 +165,9 @@ def test_conv3x3_benchmark_widths(case, dtype):
     if stride == 2:
         dx1, dx2, _ = ops.conv_mma(CONV_T3S2, dyd, None, wb, npb, kpb, False, None, cin, (h, w), out_split=split)
     else:
-        dx1, dx2, _ = ops.conv_mma(CONV_G3S1, dyd, None, wb, npb, kpb, True, None, cin, (h, w), out_split=split)
+        dx1, dx2, dst = ops.conv_mma(CONV_G3S1, dyd, None, wb, npb, kpb, True, None, cin, (h, w), want_stats=True, out_split=split)
+        # epilogue statistics of the input gradient (its per-channel sum is a transposed conv's bias gradient, ops.py)
+        assert relerr(dst.sum(1).cpu()[..., 0], xr.grad.sum((2, 3))) < 2e-3
     dx = nchw(dx1) if dx2 is None else torch.cat([nchw(dx1), nchw(dx2)], 1)
     assert relerr(dx, xr.grad) < otol
     dw = ops.conv_wgrad(WGRAD_3S2 if stride == 2 else WGRAD_3S1, x1, x2, dyd, wt.shape, cout, cin)
