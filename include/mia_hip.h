@@ -48,6 +48,12 @@ int mia_relayout(const void* src, int src_dtype, void* dst, int dst_dtype, int n
 /* out = a + b: the residual connection of ResidualBlock (blocks.py:164) */
 int mia_add(const void* a, const void* b, void* out, int dtype, int64_t n, void* stream);
 /* out[c] (+)= sum over p rows of x[p][c]: bias gradients of Conv2d / ConvTranspose2d. */
+/* Dropout2d channel masks (blocks.py:92-96): out[i] = 1/keep with probability keep, else 0 (Philox4x32-10 keyed by seed, offset) */
+int mia_dropout_mask(float* out, int64_t n, float keep, uint64_t seed, uint64_t offset, void* stream);
+/* optimizer.zero_grad() (al_trainer.py:1375) on a flat buffer: bytes % 16 == 0, 16-byte aligned */
+int mia_zero(void* p, int64_t bytes, void* stream);
+/* dst[i] = src[i * stride], fp32 (per-channel sums out of interleaved statistics) */
+int mia_gather_f32(const float* src, int64_t stride, float* dst, int n, void* stream);
 int mia_colsum_workspace(int64_t p, int c); /* floats */
 int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, float* out, int accumulate, void* stream);
 
@@ -161,7 +167,8 @@ int mia_head_bwd(const float* dlogits, const void* x, int dtype, const float* w,
                            * `const long long*`; same strides as the logits (sn, sk, sp). */
 /* out[0] = ce_w*CE + dice_w*Dice, out[1] = CE (mean over pixels), out[2] = Dice
  * (DiceLoss.forward dice_loss.py:32-76, DiceAndCELoss.forward compound_losses.py:33-49).
- * sums [B][K1][3] = (I, sum p, sum t); coef [B][K1][2] feeds the backward; *bad_label set on label outside [0,K1). */
+ * sums [B][K1][3] = (I, sum p, sum t); coef [B][K1][2] feeds the backward; bad_label = int[2], zero before the first call: [1] = 1 after a call that met a label
+ * outside [0,K1) (loss and coef are NaN then), [0] = scratch re-armed by every call. */
 int mia_dice_ce_workspace(int nb, int k1, int slabs); /* floats */
 int mia_dice_ce_fwd(const float* logits, const long long* labels, int nb, int64_t hw, int k1, int64_t sn, int64_t sk,
                     int64_t sp, int flags, float smooth, float dice_w, float ce_w, int slabs, float* workspace, float* sums,

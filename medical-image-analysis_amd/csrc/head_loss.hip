@@ -828,7 +828,7 @@ static bool dice_ce_fast_ok(const void* logits, const void* labels, int64_t hw, 
 __global__ void dice_ce_finalize_kernel(const float* __restrict__ part, const float* __restrict__ cepart, int nb, int slabs,
                                         int k1, int64_t hw, int flags, float smooth, float dice_w, float ce_w,
                                         float* __restrict__ sums, float* __restrict__ coef, float* __restrict__ out,
-                                        const int* __restrict__ bad_label) {
+                                        int* __restrict__ bad_label) {
   // single block; thread -> (b,k)
   __shared__ double dsum[256];
   __shared__ double cesum[256];
@@ -887,8 +887,13 @@ __global__ void dice_ce_finalize_kernel(const float* __restrict__ part, const fl
   // in CrossEntropyLoss).  A device kernel cannot raise, so the result is made unusable instead of silently training on
   // such masks: loss values and the backward coefficients (hence every gradient) become NaN; ops.DiceCEFn.check_labels()
   // turns the flag into an exception at the caller's next host sync.
+  // bad_label[0] is the working flag the pixel kernels raise; it is copied to bad_label[1] (the verdict of THIS forward, read by
+  // check_labels) and re-armed here, so the caller never has to clear it between calls.
   __syncthreads();
-  if (*bad_label) {
+  const int bad = bad_label[0];
+  __syncthreads();
+  if (threadIdx.x == 0) { bad_label[1] = bad; bad_label[0] = 0; }
+  if (bad) {
     const float qn = __builtin_nanf("");
     if (threadIdx.x < 3) out[threadIdx.x] = qn;
     for (int i = threadIdx.x; i < total * 2; i += blockDim.x) coef[i] = qn;

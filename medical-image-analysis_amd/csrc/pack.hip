@@ -310,3 +310,64 @@ extern "C" int mia_add(const void* a, const void* b, void* out, int dtype, int64
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
+
+
+// ---- small utilities that keep PyTorch kernels out of the training step (north_star: torch = containers / autograd glue only)
+// Dropout2d channel masks (reference blocks.py:92-96: nn.Dropout2d(p, inplace) zeroes whole channels per sample and scales
+// the survivors by 1/(1-p)): out[i] in {0, 1/keep}, one Philox4x32-10 counter per four elements, keyed by (seed, offset).
+__device__ __forceinline__ void philox_round_u(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__global__ void dropout_mask_kernel(float* __restrict__ out, int64_t n, float keep, unsigned long long seed, unsigned long long offset) {
+  const int64_t quads = (n + 3) / 4;
+  const float scale = 1.f / keep;
+  for (int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < quads; qd += (int64_t)gridDim.x * blockDim.x) {
+    unsigned c0 = (unsigned)qd, c1 = (unsigned)(qd >> 32), c2 = (unsigned)offset, c3 = (unsigned)(offset >> 32);
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { philox_round_u(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    const unsigned c[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = qd * 4 + e;
+      if (i < n) out[i] = ((c[e] >> 8) * (1.f / 16777216.f) < keep) ? scale : 0.f;  // U[0,1) with 24 bits, keep with probability `keep`
+    }
+  }
+}
+extern "C" int mia_dropout_mask(float* out, int64_t n, float keep, uint64_t seed, uint64_t offset, void* stream) {
+  MIA_CHECK_ARG(out && n > 0 && keep > 0.f && keep <= 1.f, "mia_dropout_mask: bad arguments (keep=%f)", (double)keep);
+  const int64_t quads = (n + 3) / 4;
+  const int blocks = (int)((quads + 255) / 256 < 1024 ? (quads + 255) / 256 : 1024);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), out, n, keep,
+                     (unsigned long long)seed, (unsigned long long)offset);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// optimizer.zero_grad() on the flat gradient buffer (al_trainer.py:1375): 16-byte stores
+__global__ void zero_kernel(u32x4* __restrict__ p, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) p[i] = u32x4{0u, 0u, 0u, 0u};
+}
+extern "C" int mia_zero(void* p, int64_t bytes, void* stream) {
+  MIA_CHECK_ARG(p && bytes > 0 && bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0, "mia_zero: needs a 16-byte aligned buffer of a multiple of 16 bytes");
+  const int64_t n16 = bytes / 16;
+  const int blocks = (int)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<u32x4*>(p), n16);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// dst[i] = src[i * stride] (fp32): picks the per-channel sums out of interleaved (sum, sum of squares) statistics -- the
+// transposed conv's bias gradient delivered by the decoder block's input-gradient epilogue (ops.py)
+__global__ void gather_f32_kernel(const float* __restrict__ src, int64_t stride, float* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[(int64_t)i * stride];
+}
+extern "C" int mia_gather_f32(const float* src, int64_t stride, float* dst, int n, void* stream) {
+  MIA_CHECK_ARG(src && dst && n > 0 && stride > 0, "mia_gather_f32: bad arguments");
+  hipLaunchKernelGGL(gather_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), src, stride, dst, n);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}

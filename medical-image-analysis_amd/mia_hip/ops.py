@@ -346,6 +346,22 @@ def _slabs_for(hw: int) -> int:
     return max(1, min(64, hw // 1024))
 
 
+# ------------------------------------------------------------------ Dropout2d masks
+def dropout_mask(numel: int, keep: float, device) -> torch.Tensor:
+    """`numel` Dropout2d channel multipliers in {0, 1/keep} (reference blocks.py:92-96) from the library's Philox kernel.
+    Keyed by the device generator's (seed, offset) -- the pair torch.manual_seed / set_rng_state control, so runs are
+    reproducible and per-rank seeds give per-rank masks (al_trainer.py:282-288) -- and the offset is advanced on the host
+    like a PyTorch CUDA RNG consumer would: no host random numbers are drawn and no PyTorch kernel runs."""
+    dev = torch.device(device)
+    gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+    seed, off = int(gen.initial_seed()), int(gen.get_offset())
+    gen.set_offset(off + 4 * ((numel + 3) // 4))
+    out = torch.empty(numel, device=dev, dtype=torch.float32)
+    call("mia_dropout_mask", _p(out), _c_i64(numel), _c_float(keep), ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(off),
+         _stream())
+    return out
+
+
 # ------------------------------------------------------------------ PlainBlock: conv3x3 -> dropout2d -> norm -> lrelu
 class NormCfg:
     __slots__ = ("mode", "training", "eps", "momentum", "running_mean", "running_var", "num_batches", "drop_scale", "sync")
@@ -647,8 +663,8 @@ class ConvTranspose2x2Fn(torch.autograd.Function):
         if dbias is None:
             dbias = colsum(dout)
         dst = grad_dest(ctx.small[0])
-        if dst is not None:
-            dst.copy_(dbias)
+        if dst is not None:  # straight into the flat gradient slice (the hinted sums are a strided view of interleaved statistics)
+            call("mia_gather_f32", _p(dbias), _c_i64(dbias.stride(0)), _p(dst), dbias.numel(), _stream())
             dbias = dst
         dw = conv_wgrad(WGRAD_2S2, dout, None, x, weight.shape, cin, cout, out=grad_dest(weight))
         dx = None
@@ -714,6 +730,19 @@ def loss_flags(softmax: bool, do_bg: bool, batch: bool, squared: bool) -> int:
         (LOSS_SQUARED if squared else 0)
 
 
+_BAD_FLAGS = {}
+
+
+def _bad_flags(dev) -> torch.Tensor:
+    """Per-device int32[2], zeroed once: allocating and clearing a flag per loss call would put two fill kernels in every step."""
+    key = (dev.type, dev.index)
+    t = _BAD_FLAGS.get(key)
+    if t is None:
+        t = torch.zeros(2, device=dev, dtype=torch.int32)
+        _BAD_FLAGS[key] = t
+    return t
+
+
 class DiceCEFn(torch.autograd.Function):
     """dice_w * DiceLoss + ce_w * CrossEntropy in one pass over the logits
     (src/losses/dice_loss.py:32-76, src/losses/compound_losses.py:33-49)."""
@@ -743,9 +772,9 @@ class DiceCEFn(torch.autograd.Function):
         dev = logits.device
         ws = torch.empty(lib().mia_dice_ce_workspace(b, k1, slabs), device=dev, dtype=torch.float32)
         sums = torch.empty((b, k1, 3), device=dev, dtype=torch.float32)
-        coef = torch.zeros((b, k1, 2), device=dev, dtype=torch.float32)
+        coef = torch.empty((b, k1, 2), device=dev, dtype=torch.float32)  # every entry is written by the finalize kernel
         out = torch.empty(3, device=dev, dtype=torch.float32)
-        bad = torch.zeros(1, device=dev, dtype=torch.int32)
+        bad = _bad_flags(dev)  # [0] working flag (set by the pixel kernels, re-armed by finalize), [1] verdict of the latest forward
         call("mia_dice_ce_fwd", _p(logits), _p(labels), b, _c_i64(hw), k1, _c_i64(st[0]), _c_i64(st[1]), _c_i64(st[2]), flags,
              _c_float(smooth), _c_float(dice_w), _c_float(ce_w), slabs, _p(ws), _p(sums), _p(coef), _p(out), _p(bad), _stream())
         ctx.save_for_backward(logits, labels, coef)
@@ -779,7 +808,7 @@ def check_labels() -> None:
     `DiceLoss._one_hot_encoder`, dice_loss.py:25-30, and the target bound check of CrossEntropyLoss); the kernels cannot,
     so they return NaN losses / NaN gradients for such a batch and keep the flag for this check."""
     bad = DiceCEFn.last_bad_label
-    if bad is not None and int(bad.item()) != 0:
+    if bad is not None and int(bad[1].item()) != 0:
         raise MiaError("Dice/CE loss: a label lies outside [0, num_classes] (e.g. 255-valued masks or ignore_index -100); "
                        "the reference raises an index error for such targets")
 

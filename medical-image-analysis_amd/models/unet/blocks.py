@@ -95,7 +95,7 @@ class PlainBlock(nn.Module):
                 drop = pooled
             else:
                 keep = 1.0 - float(self.dropout_prob)
-                drop = torch.empty((n, norm.num_features), device=device, dtype=torch.float32).bernoulli_(keep).div_(keep)
+                drop = ops.dropout_mask(n * norm.num_features, keep, device).view(n, norm.num_features)
         if self.normalization == "batch":
             return ops.NormCfg(NORM_BATCH, self.training, norm.eps, norm.momentum, norm.running_mean, norm.running_var,
                                norm.num_batches_tracked, drop, sync=self.batch_sync)
@@ -171,7 +171,7 @@ class ResidualBlock(nn.Module):
             m = self.drop_mask_override.to(device=x1.device, dtype=torch.float32)
         elif self.dropout_prob is not None and self.training and self.dropout_prob > 0:
             keep = 1.0 - float(self.dropout_prob)
-            m = torch.empty((x1.shape[0], norm.num_features), device=x1.device, dtype=torch.float32).bernoulli_(keep).div_(keep)
+            m = ops.dropout_mask(x1.shape[0] * norm.num_features, keep, x1.device).view(x1.shape[0], norm.num_features)
         out = ops.ScaleLReLUFn.apply(n1, m, ops.LRELU_SLOPE)
         if self.downsample_skip is not None:
             sc, sn = self.downsample_skip[0], self.downsample_skip[1]

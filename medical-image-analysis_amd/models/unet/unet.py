@@ -185,7 +185,7 @@ class UNet(nn.Module):
 
     def _draw_dropout(self, n: int, device) -> None:
         """All Dropout2d channel masks of this forward ([N, C] of {0, 1/(1-p)} per PlainBlock, blocks.py:92-96) from ONE
-        Bernoulli draw instead of one RNG launch pair per block; a block without a pooled mask draws its own."""
+        launch of the library's Philox mask kernel instead of one per block; a block without a pooled mask draws its own."""
         if not self.training:
             return
         blocks = [m for m in self.modules() if isinstance(m, PlainBlock) and m.dropout_prob and m.drop_mask_override is None]
@@ -193,7 +193,7 @@ class UNet(nn.Module):
             return
         keep = 1.0 - float(blocks[0].dropout_prob)
         sizes = [n * b.all[2].num_features for b in blocks]
-        pool = torch.empty(sum(sizes), device=device, dtype=torch.float32).bernoulli_(keep).div_(keep)
+        pool = ops.dropout_mask(sum(sizes), keep, device)
         off = 0
         for b, sz in zip(blocks, sizes):
             b._drop_from_pool = pool[off:off + sz].view(n, -1)

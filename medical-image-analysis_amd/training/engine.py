@@ -111,7 +111,10 @@ class FlatOptimizer:
     def zero_grad(self, set_to_none: bool = False):
         """Unset .grad (autograd then ADOPTS the first gradient -- a view of the flat buffer -- instead of adding into
         it) and clear the buffer, so a parameter that gets no gradient this step contributes zeros."""
-        self.flat_grad.zero_()
+        if self.flat_grad.is_cuda:
+            ops.call("mia_zero", ops._p(self.flat_grad), ops._c_i64(self.flat_grad.numel() * 4), ops._stream())
+        else:
+            self.flat_grad.zero_()  # host-side tests of the layout / reducer
         for p in self.params:
             p.grad = None
             ops.release_grad_dest(p)
@@ -259,6 +262,7 @@ class TrainEngine:
         self.grad_norm = grad_norm
         self.reducer = GradBucketReducer(self.optimizer, process_group)
         self.current_iter = 0
+        self._one = None
 
     def train_step(self, sampled_batch) -> torch.Tensor:
         self.model.train()
@@ -271,7 +275,9 @@ class TrainEngine:
         loss = self.loss_fn(output, label)
         self.optimizer.zero_grad()
         self.reducer.start_step()
-        loss.backward()
+        if self._one is None or self._one.device != loss.device or self._one.dtype != loss.dtype:
+            self._one = torch.ones_like(loss)  # reused d(loss)/d(loss): autograd would launch a fill kernel per step
+        loss.backward(self._one)
         self.reducer.finish()
         self.optimizer.step(max_grad_norm=self.grad_norm, grad_scale=self.reducer.grad_scale)
         self.current_iter += 1

@@ -403,6 +403,32 @@ def test_out_of_range_label_poisons_loss_and_is_reported(layout):
         fn2.get_ce_loss(logits, labels)
 
 
+def test_dropout_mask_zero_and_gather_utilities():
+    """Library kernels that replace PyTorch's bernoulli / fill / strided copy inside the step: Dropout2d masks take the two
+    values {0, 1/keep} with the right frequency, are reproducible under torch.manual_seed and differ call to call."""
+    import ctypes
+    from mia_hip import call, ops
+    dev = _dev()
+    torch.manual_seed(11)
+    a = ops.dropout_mask(1 << 18, 0.9, dev)
+    b = ops.dropout_mask(1 << 18, 0.9, dev)
+    torch.manual_seed(11)
+    a2 = ops.dropout_mask(1 << 18, 0.9, dev)
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    vals = torch.unique(a).cpu().tolist()
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1 / 0.9) < 1e-6
+    assert abs((a > 0).float().mean().item() - 0.9) < 5e-3 and abs(a.mean().item() - 1.0) < 5e-3
+    odd = ops.dropout_mask(1001, 0.5, dev)  # tail of a quad
+    assert odd.shape == (1001,) and abs((odd > 0).float().mean().item() - 0.5) < 0.06
+    buf = torch.randn(4096 + 4, device=dev)
+    call("mia_zero", ops._p(buf), ops._c_i64(4096 * 4), ops._stream())
+    assert float(buf[:4096].abs().max()) == 0.0 and float(buf[4096:].abs().min()) > 0.0
+    src = torch.arange(40, device=dev, dtype=torch.float32)
+    dst = torch.empty(13, device=dev)
+    call("mia_gather_f32", ops._p(src[1:]), ops._c_i64(3), ops._p(dst), 13, ops._stream())
+    assert torch.equal(dst.cpu(), torch.arange(13, dtype=torch.float32) * 3 + 1)
+
+
 @pytest.mark.parametrize("kind", ["adam", "adamw", "sgd"])
 def test_optimizer_and_clip(kind):
     from mia_hip import ops, OPT_ADAM, OPT_ADAMW, OPT_SGD
