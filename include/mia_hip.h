@@ -65,7 +65,9 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
 #define MIA_CONV_T2S2 4 /* transposed 2x2 s2: ConvTranspose2d fwd (unet.py:142, :212) */
 #define MIA_CONV_G1 5   /* 1x1: ResidualBlock skip conv (blocks.py:147-153) */
 /* Tuning / A-B knobs (process-wide, not part of any reference interface): "conv64" = 1 (default) lets 64 -> 64 channel
- * bf16 3x3 stride-1 launches take the persistent register-weight kernel, 0 sends them through the generic tile kernel. */
+ * bf16 3x3 stride-1 launches take the persistent register-weight kernel, 0 sends them through the generic tile kernel;
+ * "wgrad_w8" = 1 (default) runs bf16 3x3 stride-1 weight gradients on the two-workgroups-per-CU kernel, 0 on the
+ * one-workgroup-per-CU kernel. */
 int mia_set_option(const char* name, int value);
 /* out[p][n] = bias[n] + sum_taps sum_k in[p*s + tap - pad][k] * wpack[tap][n][k].
  * in1|in2 are concatenated along channels (c1 + c2) -- this is how torch.cat([skip, up], 1)
@@ -94,6 +96,7 @@ int mia_stem_wgrad(const void* x, int x_dtype, const void* dy, int dtype, float*
 /* slabs[z][tap][npad][kpad] = sum over the z-th share of output pixels of dy[p][n] * x[p*s+tap-pad][k]
  * (autograd weight gradient of the layers above); mia_wgrad_reduce sums the ksplit slabs in a fixed
  * order into grad[nn][kk][taps] (= OIHW for Conv2d, [Cin][Cout][2][2] for ConvTranspose2d). */
+int mia_wgrad_target_blocks(int mode, int dtype); /* split-K workgroups to aim for (ksplit = target / (npad/64 * kpad/64)) */
 int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x);
 int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const void* x2, int c2, const void* dy, int cdy,
                    float* slabs, int ksplit, int npad, int kpad, int n, int hx, int wx, int hy, int wy, void* stream);

@@ -17,6 +17,8 @@
 //   MODE_W3S1: 3x3 stride 1 pad 1;  MODE_W3S2: 3x3 stride 2 pad 1;  MODE_W2S2: 2x2 stride 2 pad 0
 //   (MODE_W2S2 is ConvTranspose2d's wgrad with x := grad_output (fine grid), dy := input (coarse)).
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 enum { MODE_W3S1 = 0, MODE_W3S2 = 1, MODE_W2S2 = 2 };
 
@@ -308,6 +310,194 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
       }
 }
 
+// ---------------------------------------------------------------- bf16, two workgroups per CU
+// wgrad_bf16_fast_kernel ends up at 464 registers = ONE workgroup of four waves per CU, one wave per SIMD.  Measured on the
+// 64-channel launch (rocprofv3 PMC, profiles/r02_pmc_wgrad64.csv): matrix pipe 41 % busy, 3.3 us per 128-pixel tile against
+// 1.2 us of MFMA issue -- with a single tile (39 KB) of loads in flight per CU the walk waits on memory latency, and nothing
+// covers the staging writes and the two barriers of a tile.  This kernel keeps the same 64(n) x 64(k) x all-taps block per
+// workgroup and the same swizzled LDS image, but fits in 256 registers so that TWO workgroups share a CU (two tiles in
+// flight, one workgroup's staging / barriers behind the other's MFMAs):
+//   * the row-block loop stays ROLLED and its fragment reads are "lane-constant base + immediate": the x image lives at a
+//     pitch of 32 pixels (18 used), so a tap / row step is a multiple of 32 LDS rows = 4096 bytes and leaves the swizzle
+//     bits alone (unrolled, hipcc hoists one computed address per (row block, tap) and the fragment reads of all row
+//     blocks: 464 registers);
+//   * staging addresses are branch free and recomputed per tile (a hoisted table is spilled and reloaded behind vmcnt(0)),
+//     the tile walk carries (image, row, column) digits instead of dividing.
+// Stride-1 3x3 only (the 32-pixel pitch); the stride-2 / transposed shapes stay on wgrad_bf16_fast_kernel.
+// Diagnostic build only (-DCONV64_STAMPS, tools/conv64_stamps.py wgrad): per-wave cycle sums of a tile's phases.
+#ifdef CONV64_STAMPS
+__device__ unsigned long long wgrad_dbg[512 * 4 * 8];
+#define WSTAMP(var)                                                                  \
+  do {                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");      \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+  } while (0)
+extern "C" int mia_wgrad_debug_read(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(wgrad_dbg), sizeof(wgrad_dbg));
+}
+#else
+#define WSTAMP(var) do { } while (0)
+#endif
+
+template <int TH>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) {
+  constexpr int KS = 3, PAD = 1, TAPS = 9;
+  constexpr int XH = TH - 1 + KS, XW = 15 + KS, XP = 32;
+  constexpr int X_IT = (XH * XW + 31) / 32, D_IT = TH * 16 / 32;  // 32 pixels x 8 chunks per staging iteration
+  constexpr int X_BYTES = XH * XP * 128, D_BYTES = TH * 16 * 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[X_BYTES + D_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = lane >> 4, i16 = lane & 15, qp = i16 >> 2, pp = i16 & 3;
+  const int ch8 = tid & 7, p8 = tid >> 3;
+  const int kb1 = (a.c1 + 63) / 64, nkb = kb1 + (a.c2 + 63) / 64;
+  const int kblk = blockIdx.x % nkb, nblk = blockIdx.x / nkb;
+  const bool second = kblk >= kb1;
+  const int cs = second ? a.c2 : a.c1, kloc = (second ? kblk - kb1 : kblk) * 64;
+  const int n0 = nblk * 64, k0 = (second ? a.c1 : 0) + kloc;
+  const bf16_t* xsrc = static_cast<const bf16_t*>(second ? a.x2 : a.x1);
+  const bf16_t* dy = static_cast<const bf16_t*>(a.dy);
+  const size_t xpix = (size_t)a.Hx * a.Wx, ypix = (size_t)a.Hy * a.Wy;
+  const bool x_chan_ok = kloc + ch8 * 8 < cs, d_chan_ok = n0 + ch8 * 8 < a.cdy;
+
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  int tile = blockIdx.y;
+  int t_tx, t_ty, t_img;
+  { int tt = tile; t_tx = tt % a.tiles_x; tt /= a.tiles_x; t_ty = tt % a.tiles_y; t_img = tt / a.tiles_y; }
+  int d_tx, d_ty, d_img;
+  { int tt = a.ksplit; d_tx = tt % a.tiles_x; tt /= a.tiles_x; d_ty = tt % a.tiles_y; d_img = tt / a.tiles_y; }
+
+  u32x4 px[X_IT], pd[D_IT];
+  auto fetch = [&](int img, int ty, int tx) {
+    const int oy0 = ty * TH, ox0 = tx * 16;
+    const int iy0 = oy0 - PAD, ix0 = ox0 - PAD;
+    const wrsrc_t rx = wmake_rsrc(xsrc + (size_t)img * xpix * cs, (unsigned)(xpix * cs * 2));
+    const wrsrc_t rd = wmake_rsrc(dy + (size_t)img * ypix * a.cdy, (unsigned)(ypix * a.cdy * 2));
+    int p8v = p8;
+    asm volatile("" : "+v"(p8v));
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int pix = p8v + 32 * i, iy = pix / XW, ix = pix - iy * XW;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      const int okm = -(int)(((unsigned)gy < (unsigned)a.Hx) & ((unsigned)gx < (unsigned)a.Wx) & (pix < XH * XW) & x_chan_ok);
+      const unsigned off = (unsigned)(((gy * a.Wx + gx) * cs + kloc + ch8 * 8) * 2);
+      px[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((off & (unsigned)okm) | (WSENT & ~(unsigned)okm)), 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < D_IT; ++i) {
+      const int pix = p8v + 32 * i;
+      const int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
+      const int okm = -(int)((gy < a.Hy) & (gx < a.Wy) & d_chan_ok);
+      const unsigned off = (unsigned)(((gy * a.Wy + gx) * a.cdy + n0 + ch8 * 8) * 2);
+      pd[i] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)((off & (unsigned)okm) | (WSENT & ~(unsigned)okm)), 0, 0);
+    }
+  };
+  auto commit = [&]() {
+    int p8v = p8;
+    asm volatile("" : "+v"(p8v));
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int pix = p8v + 32 * i, iy = pix / XW, ix = pix - iy * XW;
+      if (pix < XH * XW) *reinterpret_cast<u32x4*>(smem + swz_off(iy * XP + ix, ch8)) = px[i];
+    }
+    const int d0 = swz_off(p8v, ch8);  // + 4096 per iteration (32 rows)
+#pragma unroll
+    for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(smem + X_BYTES + d0 + 4096 * i) = pd[i];
+  };
+
+  f32x4 acc[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // lane-constant read bases (bytes).  Lane group `grp` covers pixels 8*(grp&1) .. +7 of output row 2*kb + (grp>>1); a
+  // transposing read fetches 4 consecutive pixel rows, the pair (lo, hi) = rows r0 .. r0+3 and r0+4 .. r0+7.
+  const int g1 = grp >> 1, xb = 8 * (grp & 1) + qp, sub = 8 * (pp & 1);
+  int dbase[4][2], xbase[KS][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    dbase[c][0] = X_BYTES + swz_off(g1 * 16 + xb, 2 * c + (pp >> 1)) + sub;
+    dbase[c][1] = X_BYTES + swz_off(g1 * 16 + xb + 4, 2 * c + (pp >> 1)) + sub;
+  }
+#pragma unroll
+  for (int kw = 0; kw < KS; ++kw) {
+    xbase[kw][0] = swz_off(g1 * XP + xb + kw, 2 * wave + (pp >> 1)) + sub;
+    xbase[kw][1] = swz_off(g1 * XP + xb + kw + 4, 2 * wave + (pp >> 1)) + sub;
+  }
+
+  if (tile < ntiles) fetch(t_img, t_ty, t_tx);
+#ifdef CONV64_STAMPS
+  unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, a_b1 = 0, a_c = 0, a_b2 = 0, a_f = 0, a_m = 0, a_n = 0;
+#endif
+  for (; tile < ntiles; tile += a.ksplit) {
+    WSTAMP(w0);
+    __syncthreads();  // previous tile's fragment reads are done
+    WSTAMP(w1);
+    commit();
+    WSTAMP(w2);
+    __syncthreads();
+    WSTAMP(w3);
+    if (tile + a.ksplit < ntiles) {
+      t_tx += d_tx; if (t_tx >= a.tiles_x) { t_tx -= a.tiles_x; t_ty += 1; }
+      t_ty += d_ty; if (t_ty >= a.tiles_y) { t_ty -= a.tiles_y; t_img += 1; }
+      t_img += d_img;
+      fetch(t_img, t_ty, t_tx);
+    }
+    WSTAMP(w4);
+#pragma unroll 1
+    for (int kb = 0; kb < TH / 2; ++kb) {
+      const int koff = 4096 * kb;  // 32 dy rows per row block; the x image advances two 32-pixel rows
+      u32x4 af[4], bf[2];
+      auto load_b = [&](int t) -> u32x4 {
+        const int kh = t / KS, kw = t % KS;
+        const s16x4 lo = tr_read(smem, xbase[kw][0] + 2 * koff + 4096 * kh);
+        const s16x4 hi = tr_read(smem, xbase[kw][1] + 2 * koff + 4096 * kh);
+        return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      };
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const s16x4 lo = tr_read(smem, dbase[c][0] + koff);
+        const s16x4 hi = tr_read(smem, dbase[c][1] + koff);
+        af[c] = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+      bf[0] = load_b(0);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        if (t + 1 < TAPS) bf[(t + 1) & 1] = load_b(t + 1);  // next tap's fragment ahead of this tap's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[c]), __builtin_bit_cast(bf16x8, bf[t & 1]),
+                                                              acc[t][c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    WSTAMP(w5);
+#ifdef CONV64_STAMPS
+    a_b1 += w1 - w0; a_c += w2 - w1; a_b2 += w3 - w2; a_f += w4 - w3; a_m += w5 - w4; a_n += 1;
+#endif
+  }
+#ifdef CONV64_STAMPS
+  if (lane == 0 && blockIdx.x == 0 && blockIdx.y < 512) {
+    unsigned long long* d = wgrad_dbg + ((size_t)blockIdx.y * 4 + wave) * 8;
+    d[0] = a_b1; d[1] = a_c; d[2] = a_b2; d[3] = a_f; d[4] = a_m; d[5] = a_n;
+  }
+#endif
+  float* slab = a.slabs + (size_t)blockIdx.y * TAPS * a.npad * a.kpad;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + c * 16 + 4 * grp + r, k = k0 + wave * 16 + i16;
+        if (kloc + wave * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+      }
+}
+
 // ---------------------------------------------------------------- fp32
 template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgArgs a) {
@@ -583,6 +773,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+int g_wgrad_w8 = -1;  // set through mia_set_option("wgrad_w8", v)
+
 // tile heights (rows of 16 output pixels per split-K step)
 static int wgrad_tile_h(int mode, int dtype, int hy, bool fast) {
   const int s = mode == MODE_W3S1 ? 1 : 2;
@@ -590,6 +782,16 @@ static int wgrad_tile_h(int mode, int dtype, int hy, bool fast) {
   (void)hy; (void)fast;  // 16-row tiles measured slower (more VGPRs, partial unroll): 575 vs 621 TFLOP/s at 64ch 512x512
   return s == 1 ? 8 : 4;
 }
+
+static bool wgrad_two_wg(int mode, int dtype) {
+  static int w8 = -1;  // MIA_WGRAD_W8=0 / mia_set_option("wgrad_w8", 0): the one-workgroup-per-CU kernel (A/B knob)
+  if (w8 < 0) { const char* e = getenv("MIA_WGRAD_W8"); w8 = (e && e[0] == '0') ? 0 : 1; }
+  const int on = g_wgrad_w8 >= 0 ? g_wgrad_w8 : w8;
+  return on && mode == MODE_W3S1 && dtype == MIA_BF16;
+}
+
+/* split-K workgroups to aim for: one per CU, or two where the kernel is built for two workgroups per CU */
+extern "C" int mia_wgrad_target_blocks(int mode, int dtype) { return wgrad_two_wg(mode, dtype) ? 512 : 256; }
 
 extern "C" int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x) {
   const int th = wgrad_tile_h(mode, dtype, hy, false);
@@ -628,7 +830,9 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   const int th = wgrad_tile_h(mode, dtype, hy, fast);
   a.tiles_y = ceil_div(hy, th);
   a.tiles_x = ceil_div(wy, 16);
-  if (fast) {
+  if (fast && wgrad_two_wg(mode, dtype)) {  // stride-2 / transposed shapes stay on the one-workgroup-per-CU kernel
+    hipLaunchKernelGGL(wgrad_bf16_2wg_kernel<8>, fgrid, dim3(256), 0, st, a);
+  } else if (fast) {
     if (mode == MODE_W3S1 && th == 16) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 16>), fgrid, dim3(256), 0, st, a);
     else if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 8>), fgrid, dim3(256), 0, st, a);
     else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S2, 4>), fgrid, dim3(256), 0, st, a);

@@ -244,7 +244,7 @@ def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: tor
     return out1, out2, stats
 
 
-WGRAD_TARGET_BLOCKS = int(__import__('os').environ.get('MIA_WGRAD_BLOCKS', '256'))
+WGRAD_TARGET_BLOCKS = int(__import__('os').environ.get('MIA_WGRAD_BLOCKS', '0'))  # 0 = ask the library (one or two workgroups per CU)
 
 
 def conv_wgrad(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], dy: torch.Tensor, grad_shape, nn: int, kk: int,
@@ -260,7 +260,8 @@ def conv_wgrad(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], dy: torc
     call("mia_wgrad_geometry", mode, dtype, hy, wy, ctypes.byref(ty), ctypes.byref(tx))
     ntiles = n * ty.value * tx.value
     base = (npad // 64) * (kpad // 64)
-    ksplit = max(1, min(ntiles, -(-WGRAD_TARGET_BLOCKS // base), 1024))
+    target = WGRAD_TARGET_BLOCKS or lib().mia_wgrad_target_blocks(mode, dtype)
+    ksplit = max(1, min(ntiles, -(-target // base), 1024))
     slabs = torch.empty((ksplit, taps, npad, kpad), device=x1.device, dtype=torch.float32)
     call("mia_conv_wgrad", mode, dtype, _p(x1), c1, _p(x2), c2, _p(dy), cdy, _p(slabs), ksplit, npad, kpad, n, hx, wx, hy,
          wy, _stream())

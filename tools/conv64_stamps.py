@@ -23,10 +23,42 @@ def build():
     return lib
 
 
+def wgrad():
+    os.environ["MIA_HIP_LIB"] = os.path.join(OUT, "libmia_hip_stamps.so")
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import numpy as np
+    import torch
+    import mia_hip
+    from mia_hip import WGRAD_3S1, ops
+    dev = torch.device("cuda:0")
+    x = torch.randn(32, 512, 512, 64, device=dev).to(torch.bfloat16)
+    dy = torch.randn(32, 512, 512, 64, device=dev).to(torch.bfloat16)
+    for _ in range(3):
+        ops.conv_wgrad(WGRAD_3S1, x, None, dy, (64, 64, 3, 3), 64, 64)
+    torch.cuda.synchronize()
+    l = ctypes.CDLL(os.environ["MIA_HIP_LIB"])
+    buf = np.zeros(512 * 4 * 8, dtype=np.uint64)
+    assert l.mia_wgrad_debug_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    d = buf.reshape(512, 4, 8).astype(np.float64)
+    n = d[..., 5]
+    live = n > 0
+    names = ["barrier 1 (readers done)", "commit (ds_write)", "barrier 2", "fetch issue", "MFMA loop"]
+    tot = 0.0
+    for i, nm in enumerate(names):
+        per = (d[..., i][live] / n[live]).mean()
+        tot += per
+        print(f"{nm:26s} {per:9.0f} cycles / tile / wave")
+    print(f"{'sum':26s} {tot:9.0f}   (tiles per workgroup {n[live].mean():.1f}; MFMA issue floor 144 x 16 = 2304)")
+
+
 def main():
     if "build" in sys.argv:
         print(build())
         return
+    if "wgrad" in sys.argv:
+        return wgrad()
     os.environ["MIA_HIP_LIB"] = os.path.join(OUT, "libmia_hip_stamps.so")
     for p in (ROOT, PKG):
         if p not in sys.path:
