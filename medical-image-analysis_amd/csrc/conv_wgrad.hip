@@ -791,7 +791,11 @@ static bool wgrad_two_wg(int mode, int dtype) {
 }
 
 /* split-K workgroups to aim for: one per CU, or two where the kernel is built for two workgroups per CU */
-extern "C" int mia_wgrad_target_blocks(int mode, int dtype) { return wgrad_two_wg(mode, dtype) ? 512 : 256; }
+extern "C" int mia_wgrad_target_blocks(int mode, int dtype) {
+  if (wgrad_two_wg(mode, dtype)) return 512;
+  if (mode == MODE_W2S2 && dtype == MIA_BF16 && g_wgrad_w8 != 0) return 512;  // 4 taps: 172 registers, 40 KB LDS -> two workgroups fit a CU
+  return 256;
+}
 
 extern "C" int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x) {
   const int th = wgrad_tile_h(mode, dtype, hy, false);
@@ -861,7 +865,9 @@ extern "C" int mia_wgrad_reduce(const float* slabs, int ksplit, int taps, int np
                 "mia_wgrad_reduce: bad arguments");
   MIA_CHECK_ARG(taps <= 9 && (int64_t)nn * kk < ((int64_t)1 << 31), "mia_wgrad_reduce: taps > 9 or gradient too large");
   const int64_t total = (int64_t)nn * kk;
-  if (total < 32768 && total * taps < ((int64_t)1 << 31)) {
+  // many slabs: split them over 8 lanes per element (the per-(n,k) kernel below walks all `ksplit` slabs serially, which is
+  // latency bound -- 57 us for 75 MB at 512 slabs); few slabs: one thread per (n,k), all taps
+  if ((total < 32768 || ksplit >= 8) && total * taps < ((int64_t)1 << 31)) {
     const int blocks = (int)((total * taps + 31) / 32);
     hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs, ksplit,
                        taps, npad, kpad, grad, nn, kk, accumulate);
