@@ -52,6 +52,13 @@ __device__ __forceinline__ s16x4 tr_read(const unsigned char* base, int off) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off));
 }
 
+// transposing read at an absolute LDS byte address (the workgroup's LDS base folded into the lane-constant part once, instead of
+// a v_add per read)
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+__device__ __forceinline__ s16x4 tr_read_at(unsigned addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_u8*)(size_t)addr);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgArgs a) {
   using G = WGeo<MODE>;
@@ -416,16 +423,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) 
   // lane-constant read bases (bytes).  Lane group `grp` covers pixels 8*(grp&1) .. +7 of output row 2*kb + (grp>>1); a
   // transposing read fetches 4 consecutive pixel rows, the pair (lo, hi) = rows r0 .. r0+3 and r0+4 .. r0+7.
   const int g1 = grp >> 1, xb = 8 * (grp & 1) + qp, sub = 8 * (pp & 1);
+  const int lds0 = (int)(unsigned)(size_t)(lds_u8*)smem;  // absolute LDS address of the tile image
   int dbase[4][2], xbase[KS][2];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    dbase[c][0] = X_BYTES + swz_off(g1 * 16 + xb, 2 * c + (pp >> 1)) + sub;
-    dbase[c][1] = X_BYTES + swz_off(g1 * 16 + xb + 4, 2 * c + (pp >> 1)) + sub;
+    dbase[c][0] = lds0 + X_BYTES + swz_off(g1 * 16 + xb, 2 * c + (pp >> 1)) + sub;
+    dbase[c][1] = lds0 + X_BYTES + swz_off(g1 * 16 + xb + 4, 2 * c + (pp >> 1)) + sub;
   }
 #pragma unroll
   for (int kw = 0; kw < KS; ++kw) {
-    xbase[kw][0] = swz_off(g1 * XP + xb + kw, 2 * wave + (pp >> 1)) + sub;
-    xbase[kw][1] = swz_off(g1 * XP + xb + kw + 4, 2 * wave + (pp >> 1)) + sub;
+    xbase[kw][0] = lds0 + swz_off(g1 * XP + xb + kw, 2 * wave + (pp >> 1)) + sub;
+    xbase[kw][1] = lds0 + swz_off(g1 * XP + xb + kw + 4, 2 * wave + (pp >> 1)) + sub;
   }
 
   if (tile < ntiles) fetch(t_img, t_ty, t_tx);
@@ -453,14 +461,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) 
       u32x4 af[4], bf[2];
       auto load_b = [&](int t) -> u32x4 {
         const int kh = t / KS, kw = t % KS;
-        const s16x4 lo = tr_read(smem, xbase[kw][0] + 2 * koff + 4096 * kh);
-        const s16x4 hi = tr_read(smem, xbase[kw][1] + 2 * koff + 4096 * kh);
+        const s16x4 lo = tr_read_at((unsigned)(xbase[kw][0] + 2 * koff + 4096 * kh));
+        const s16x4 hi = tr_read_at((unsigned)(xbase[kw][1] + 2 * koff + 4096 * kh));
         return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
       };
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const s16x4 lo = tr_read(smem, dbase[c][0] + koff);
-        const s16x4 hi = tr_read(smem, dbase[c][1] + koff);
+        const s16x4 lo = tr_read_at((unsigned)(dbase[c][0] + koff));
+        const s16x4 hi = tr_read_at((unsigned)(dbase[c][1] + koff));
         af[c] = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
       }
       bf[0] = load_b(0);

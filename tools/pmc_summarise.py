@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     tag = sys.argv[1]
     needle = sys.argv[2] if len(sys.argv) > 2 else "conv64"
+    label = sys.argv[3] if len(sys.argv) > 3 else "canonical_conv"
     out_rows, means = [], {}
     for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_*/"))):
         f = os.path.join(d, "p_counter_collection.csv")
@@ -31,13 +32,13 @@ def main():
             means[k] = sum(v) / len(v)
             out_rows.append({"pass": os.path.basename(d.rstrip("/")), "kernel": needle, "counter": k, "mean_per_launch": means[k],
                              "launches": len(v), "avg_duration_us": sum(dur) / max(1, len(dur))})
-    dst = os.path.join(ROOT, "profiles", f"{tag}_pmc_canonical_conv.csv")
+    dst = os.path.join(ROOT, "profiles", f"{tag}_pmc_{label}.csv")
     with open(dst, "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=list(out_rows[0].keys()))
         w.writeheader()
         w.writerows(out_rows)
     print("wrote", dst)
-    if "FETCH_SIZE" in means and "WRITE_SIZE" in means:
+    if "FETCH_SIZE" in means and "WRITE_SIZE" in means and label == "canonical_conv":
         rec = {"config": "cfg3", "batch": 32, "dtype": "bf16", "kernel": needle, "FETCH_SIZE_KB": means["FETCH_SIZE"],
                "WRITE_SIZE_KB": means["WRITE_SIZE"],
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on tools/microbench.py conv --c 64 --size 512 --batch 32; "
