@@ -365,7 +365,7 @@ def main():
                     hbm[key] = {"launches": len(recs), "achieved": round(by / tm / 1e9, 1), "unit": "GB/s", "peak": PEAK_HBM_GBS,
                                 "frac": round(by / tm / 1e9 / PEAK_HBM_GBS, 4)}
             roof["hbm_streams"] = hbm
-        out = {"metric": "training images/sec (whole node), UNet 512x512 1ch bs=32/GPU", "value": round(value, 2),
+        out = {"metric": f"training images/sec (whole node), UNet {size}x{size} 1ch bs={batch}/GPU", "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
                "config": {"workload": f"UNet-2D channels {channels} {size}x{size} 1ch, batch {batch}/GPU, {args.norm} norm, "
