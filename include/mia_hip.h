@@ -217,6 +217,11 @@ int mia_optim_step(float* param, const float* grad, float* m, float* v, int64_t 
  * = inverse matrix mats[b][6] -> base grid -> grid_sample(nearest, zeros, align_corners=False); image and label in one launch. */
 int mia_affine_nearest(const float* img_in, float* img_out, const long long* lab_in, long long* lab_out, int nb, int c, int h,
                        int w, const float* mats, const int* apply, void* stream);
+/* Elastic deformation (north_star; NO reference counterpart -- SURVEY 0 row 2 -- own spec, see csrc/augment.hip): displacement
+ * vectors disp[B][2][gh][gw] (pixels; component 0 = x, 1 = y) on a coarse control grid spanning the image corner to corner,
+ * bilinearly interpolated per pixel; image sampled bilinearly with zero padding, label at the nearest source pixel. */
+int mia_elastic_warp(const float* img_in, float* img_out, const long long* lab_in, long long* lab_out, int nb, int c, int h,
+                     int w, const float* disp, int gh, int gw, const int* apply, void* stream);
 /* RandomRotation90 / MirrorTransform (joint_transform.py:40-97): torch.rot90(k) then optional flips; 4- or 8-byte elements */
 int mia_rot90_flip(const void* in, void* out, int elem_bytes, int nb, int c, int h, int w, int k, int flip_h, int flip_w,
                    void* stream);

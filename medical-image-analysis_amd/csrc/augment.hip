@@ -108,6 +108,100 @@ extern "C" int mia_affine_nearest(const float* img_in, float* img_out, const lon
   return MIA_OK;
 }
 
+// ---------------------------------------------------------------- elastic deformation (image + label)
+// north_star names an "elastic" augmentation; the reference has none, so this kernel follows its OWN spec
+// (docs: transforms/hip/joint_transform.py::RandomElastic, restated on the CPU in oracle/transforms_ref.py::apply_elastic):
+// the U-Net paper's scheme -- random displacement vectors on a coarse (gh x gw) grid of control points spanning the image
+// corner to corner, per-pixel displacement by bilinear interpolation of the grid, image sampled bilinearly (zero outside),
+// label sampled at the nearest source pixel (round half even, zero outside).  Every fp32 operation below is pinned
+// (contraction off) so label maps are bit-exact against the restatement:
+//   u = x * ((gw-1)/(W-1)), j0 = min(int(u), gw-2), tu = u - j0      (same for v, i0, tv along y)
+//   d = (1-tv) * ((1-tu)*D[i0][j0] + tu*D[i0][j0+1]) + tv * ((1-tu)*D[i0+1][j0] + tu*D[i0+1][j0+1])     per component
+//   (sx, sy) = (x + d_x, y + d_y)
+// disp: [B][2][gh][gw] fp32, component 0 = x displacement, 1 = y displacement, in pixels.
+template <int VEC>
+__global__ void elastic_warp_kernel(const float* __restrict__ img_in, float* __restrict__ img_out,
+                                    const long long* __restrict__ lab_in, long long* __restrict__ lab_out, int nb, int c, int h,
+                                    int w, const float* __restrict__ disp, int gh, int gw, const int* __restrict__ apply) {
+#pragma clang fp contract(off)
+  const int64_t hw = (int64_t)h * w, groups = hw / VEC, total = (int64_t)nb * groups;
+  const float su = w > 1 ? (float)(gw - 1) / (float)(w - 1) : 0.f, sv = h > 1 ? (float)(gh - 1) / (float)(h - 1) : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / groups);
+    const int64_t p = (i - (int64_t)b * groups) * VEC;
+    const int y = (int)(p / w), x0 = (int)(p - (int64_t)y * w);
+    const bool act = on(apply, b);
+    const float* D = disp + (int64_t)b * 2 * gh * gw;
+    const float v = (float)y * sv;
+    int i0 = (int)v; i0 = i0 < gh - 2 ? i0 : gh - 2; i0 = i0 < 0 ? 0 : i0;
+    const float tv = v - (float)i0;
+    float iv[VEC];
+    long long lv[VEC];
+    for (int ch = -1; ch < c; ++ch) {  // ch == -1: the label plane
+      if (ch < 0 && !lab_in) continue;
+      if (ch >= 0 && !img_in) break;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const int x = x0 + j;
+        float sx = (float)x, sy = (float)y;
+        if (act) {
+          const float u = (float)x * su;
+          int j0 = (int)u; j0 = j0 < gw - 2 ? j0 : gw - 2; j0 = j0 < 0 ? 0 : j0;
+          const float tu = u - (float)j0;
+          float d[2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float* g = D + (int64_t)k * gh * gw + (int64_t)i0 * gw + j0;
+            const float top = (1.f - tu) * g[0] + tu * g[1];
+            const float bot = (1.f - tu) * g[gw] + tu * g[gw + 1];
+            d[k] = (1.f - tv) * top + tv * bot;
+          }
+          sx = (float)x + d[0];
+          sy = (float)y + d[1];
+        }
+        if (ch < 0) {
+          const float rx = __builtin_rintf(sx), ry = __builtin_rintf(sy);
+          const bool in = rx >= 0.f && rx <= (float)(w - 1) && ry >= 0.f && ry <= (float)(h - 1);
+          lv[j] = in ? lab_in[(int64_t)b * hw + (int64_t)(int)ry * w + (int)rx] : 0;
+        } else {
+          const float fx = __builtin_floorf(sx), fy = __builtin_floorf(sy);
+          const float ax = sx - fx, ay = sy - fy;
+          const int xi = (int)fx, yi = (int)fy;
+          const float* pi = img_in + ((int64_t)b * c + ch) * hw;
+          auto at = [&](int yy, int xx) -> float { return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? pi[(int64_t)yy * w + xx] : 0.f; };
+          const float top = (1.f - ax) * at(yi, xi) + ax * at(yi, xi + 1);
+          const float bot = (1.f - ax) * at(yi + 1, xi) + ax * at(yi + 1, xi + 1);
+          iv[j] = (1.f - ay) * top + ay * bot;
+        }
+      }
+      if (ch < 0) {
+        long long* po = lab_out + (int64_t)b * hw + p;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) po[j] = lv[j];
+      } else {
+        float* po = img_out + ((int64_t)b * c + ch) * hw + p;
+        if constexpr (VEC == 4) *reinterpret_cast<f32x4*>(po) = f32x4{iv[0], iv[1], iv[2], iv[3]};
+        else po[0] = iv[0];
+      }
+    }
+  }
+}
+
+extern "C" int mia_elastic_warp(const float* img_in, float* img_out, const long long* lab_in, long long* lab_out, int nb, int c,
+                                int h, int w, const float* disp, int gh, int gw, const int* apply, void* stream) {
+  MIA_CHECK_ARG((img_in || lab_in) && disp && nb > 0 && h > 0 && w > 0 && gh >= 2 && gw >= 2, "mia_elastic_warp: bad arguments");
+  MIA_CHECK_ARG((img_in == nullptr) == (img_out == nullptr) && (lab_in == nullptr) == (lab_out == nullptr), "mia_elastic_warp: in/out mismatch");
+  MIA_CHECK_ARG((int64_t)h * w < ((int64_t)1 << 31), "mia_elastic_warp: image too large");
+  const bool vec = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(img_out) | reinterpret_cast<uintptr_t>(lab_out)) & 15) == 0;
+  const int64_t total = (int64_t)nb * h * w / (vec ? 4 : 1);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (vec) hipLaunchKernelGGL(elastic_warp_kernel<4>, dim3(blocks), dim3(256), 0, st, img_in, img_out, lab_in, lab_out, nb, c, h, w, disp, gh, gw, apply);
+  else hipLaunchKernelGGL(elastic_warp_kernel<1>, dim3(blocks), dim3(256), 0, st, img_in, img_out, lab_in, lab_out, nb, c, h, w, disp, gh, gw, apply);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
 // ---------------------------------------------------------------- rot90 (k quarter turns, torch.rot90 on (-2,-1)) + flips
 // out[b][.][y][x] = in[b][.][sy][sx].  Square or non-square: for odd k the output is W x H.
 template <typename T>

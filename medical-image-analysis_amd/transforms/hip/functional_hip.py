@@ -55,6 +55,30 @@ def affine_nearest(img: Optional[torch.Tensor], lab: Optional[torch.Tensor], mat
     return oi, ol
 
 
+def elastic_warp(img: Optional[torch.Tensor], lab: Optional[torch.Tensor], disp: torch.Tensor, apply=None):
+    """Elastic deformation (own spec, csrc/augment.hip): disp [B, 2, gh, gw] fp32 control-point displacements in pixels
+    (component 0 = x, 1 = y); image [B, C, H, W] sampled bilinearly (zero outside), label [B, H, W] at the nearest pixel."""
+    ref = img if img is not None else lab
+    dev = ref.device
+    b, h, w = ref.shape[0], ref.shape[-2], ref.shape[-1]
+    c = img.shape[1] if img is not None else 1
+    _need_dev(disp)
+    d = disp.to(device=dev, dtype=torch.float32).contiguous()
+    if d.ndim != 4 or d.shape[0] != b or d.shape[1] != 2 or d.shape[2] < 2 or d.shape[3] < 2:
+        raise MiaError(f"elastic_warp: displacement grid must be [B, 2, gh >= 2, gw >= 2], got {tuple(d.shape)}")
+    io = oi = lo = ol = None
+    if img is not None:
+        io = _f32(img)
+        oi = torch.empty_like(io)
+    if lab is not None:
+        _need_dev(lab)
+        lo = lab.long().contiguous()
+        ol = torch.empty_like(lo)
+    ap = _apply(apply, dev)
+    call("mia_elastic_warp", _p(io), _p(oi), _p(lo), _p(ol), b, c, h, w, _p(d), d.shape[2], d.shape[3], _p(ap), _stream())
+    return oi, ol
+
+
 def rot90_flip(x: torch.Tensor, k: int = 0, flip_h: bool = False, flip_w: bool = False) -> torch.Tensor:
     """torch.rot90(x, k, (-2, -1)) followed by optional flips of H / W, for 4- or 8-byte dtypes."""
     _need_dev(x)

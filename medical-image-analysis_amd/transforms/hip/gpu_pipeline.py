@@ -11,12 +11,16 @@ import torch
 from .common import ComposeTransform, RandomTransform
 from .image_transform import (RandomBrightness, RandomContrast, RandomGamma, RandomGaussianBlur, RandomGaussianNoise,
                               SimulateLowRes)
-from .joint_transform import JointResize, MirrorTransform, RandomAffine, RandomRotation, RandomRotation90
+from .joint_transform import JointResize, MirrorTransform, RandomAffine, RandomElastic, RandomRotation, RandomRotation90
 from .normalization import ZScoreNormalize
 
 
-def al_train_transforms(dataset: str = "fugc") -> ComposeTransform:
-    """`ALTrainer._get_train_transform` (al_trainer.py:670-717)."""
+def al_train_transforms(dataset: str = "fugc", elastic: bool = False) -> ComposeTransform:
+    """`ALTrainer._get_train_transform` (al_trainer.py:670-717).  `elastic=True` (build-side option, off by default: the
+    reference has no elastic transform) puts `RandomTransform(RandomElastic(), p=0.2)` in front of the reference's stages."""
+    if elastic:
+        base = al_train_transforms(dataset, elastic=False)
+        return ComposeTransform([RandomTransform(RandomElastic(sigma=(0.0, 8.0), grid=(4, 4)), p=0.2)] + base.transforms)
     if dataset.lower() in ("fugc", "busi"):
         return ComposeTransform([
             RandomTransform(RandomAffine(scale=(0.7, 1.4)), p=0.2),

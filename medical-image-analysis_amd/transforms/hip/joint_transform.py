@@ -157,6 +157,41 @@ class RandomCrop2D(BaseTransform):
         return {RandomCrop2D.__name__: {"crop": self.crop}}
 
 
+class RandomElastic(BaseTransform):
+    """Elastic deformation of image and label -- a BUILD-SIDE ADDITION: `BASELINE.json.north_star` names an elastic
+    augmentation kernel, the reference has none (`grep -ri elastic src` -> 0 hits), so there is no reference
+    behaviour to match ("parity unpinned" by construction) and it is part of no `al_train` pipeline unless asked for
+    (`al_train_transforms(..., elastic=True)`).  Spec (U-Net paper's scheme; kernel `mia_elastic_warp`, CPU restatement
+    `oracle/transforms_ref.py::apply_elastic`):
+
+    * draw: `sigma = U(sigma[0], sigma[1])` by `torch.rand(1)`, then `D = torch.randn(2, grid[0], grid[1]) * sigma` -- displacement
+      vectors in pixels (component 0 = x, 1 = y) on a coarse grid of control points spanning the image corner to corner;
+    * per-pixel displacement = bilinear interpolation of D (control point (i, j) sits at pixel (i*(H-1)/(gh-1), j*(W-1)/(gw-1)));
+    * image: bilinear sample at (x + dx, y + dy), zero outside; label: nearest source pixel (round half even), zero outside.
+    """
+
+    def __init__(self, sigma=(0.0, 8.0), grid=(4, 4)):
+        if not isinstance(sigma, Sequence):
+            sigma = (0.0, float(sigma))
+        if not isinstance(grid, Sequence):
+            grid = (int(grid), int(grid))
+        if grid[0] < 2 or grid[1] < 2:
+            raise ValueError("RandomElastic: the control grid needs at least 2 x 2 points")
+        self.sigma, self.grid = [float(sigma[0]), float(sigma[1])], [int(grid[0]), int(grid[1])]
+
+    def draw(self, shape):
+        s = float(torch.rand(1).item() * (self.sigma[1] - self.sigma[0]) + self.sigma[0])
+        return (torch.randn(2, self.grid[0], self.grid[1]) * s, s)
+
+    def apply_batch(self, images, labels, params):
+        zero = torch.zeros(2, self.grid[0], self.grid[1])
+        disp = torch.stack([p[0] if p is not None else zero for p in params]).to(images.device if images is not None else labels.device)
+        return FH.elastic_warp(images, labels, disp, [p is not None for p in params])
+
+    def get_params_dict(self):
+        return {RandomElastic.__name__: {"sigma": self.sigma, "grid": self.grid}}
+
+
 class RandomAffine(BaseTransform):
     def __init__(self, degrees=0.0, translate=None, scale=None, shear=None):
         if not isinstance(degrees, Sequence):

@@ -104,6 +104,58 @@ def test_affine_index_maps_bit_exact_random_sweep():
         assert torch.equal(ol.cpu(), R.apply_affine(lab, ang, (0, 0), sc, sh)), (t, h, w, ang, sc, sh)
 
 
+def test_elastic_deformation_own_spec():
+    """Elastic deformation has NO reference counterpart (parity unpinned by construction): the kernel is
+    checked against the CPU restatement of the build's own spec (oracle/transforms_ref.py::apply_elastic) -- label maps
+    bit-exact, images to 1e-6 -- and against known answers: zero displacement = identity, a constant integer displacement =
+    a shift with zero fill, apply=0 = pass-through, per-sample draw order and determinism of the transform class."""
+    from transforms import functional_hip as FH
+    from transforms.gpu_pipeline import BatchedAugment, al_train_transforms
+    from transforms.joint_transform import RandomElastic
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    for (h, w, c, gh, gw) in ((48, 64, 1, 4, 4), (37, 53, 3, 3, 5), (336, 544, 1, 4, 4)):
+        img, lab = _sample(h, w, c=c, seed=h)
+        disp = torch.randn(2, 2, gh, gw, generator=g) * torch.tensor([6.0, 0.0]).view(2, 1, 1, 1)  # sample 1: zero field
+        imgs, labs = torch.stack([img, img]).to(dev), torch.cat([lab, lab]).to(dev)
+        oi, ol = FH.elastic_warp(imgs, labs, disp.to(dev))
+        ri, rl = R.apply_elastic(img, disp[0]), R.apply_elastic(lab, disp[0])
+        assert torch.equal(ol[0].cpu(), rl[0]), (h, w)
+        np.testing.assert_allclose(oi[0].cpu().numpy(), ri.numpy(), atol=1e-6)
+        assert torch.equal(oi[1].cpu(), img) and torch.equal(ol[1].cpu(), lab[0])  # zero displacement = identity
+        assert (ol[0].cpu() != lab[0]).float().mean().item() > 0.01  # and a 6-pixel field does move things
+    # constant displacement (+3, -2): out[y][x] = in[y - 2][x + 3], zero outside
+    img, lab = _sample(40, 56, c=1, seed=1)
+    disp = torch.zeros(1, 2, 2, 2)
+    disp[0, 0] += 3.0
+    disp[0, 1] -= 2.0
+    oi, ol = FH.elastic_warp(img[None].to(dev), lab.to(dev), disp.to(dev))
+    want = torch.zeros_like(lab[0])
+    want[2:, :-3] = lab[0][:-2, 3:]
+    assert torch.equal(ol[0].cpu(), want)
+    wi = torch.zeros_like(img[0])
+    wi[2:, :-3] = img[0][:-2, 3:]
+    np.testing.assert_allclose(oi[0, 0].cpu().numpy(), wi.numpy(), atol=1e-6)
+    o2, l2 = FH.elastic_warp(img[None].to(dev), lab.to(dev), disp.to(dev), [False])
+    assert torch.equal(o2[0].cpu(), img) and torch.equal(l2.cpu(), lab)
+    # transform class: one torch.rand(1) then one torch.randn(2, gh, gw); reproducible under the seed; dict API
+    t = RandomElastic(sigma=(2.0, 6.0), grid=(3, 4))
+    torch.manual_seed(9)
+    s = float(torch.rand(1).item() * 4.0 + 2.0)
+    d = torch.randn(2, 3, 4) * s
+    torch.manual_seed(9)
+    out = t({"image": img.to(dev), "label": lab.to(dev), "case_name": "e"})
+    assert out["case_name"] == "e" and out["label"].shape == (1, 40, 56) and out["label"].dtype == torch.long
+    assert torch.equal(out["label"].cpu(), R.apply_elastic(lab, d))
+    np.testing.assert_allclose(out["image"].cpu().numpy(), R.apply_elastic(img, d).numpy(), atol=1e-6)
+    assert t.get_params_dict() == {"RandomElastic": {"sigma": [2.0, 6.0], "grid": [3, 4]}}
+    # off by default in the al_train pipelines; one extra leading stage when asked for
+    assert len(al_train_transforms("fugc", elastic=True).transforms) == len(al_train_transforms("fugc").transforms) + 1
+    torch.manual_seed(3)
+    b = BatchedAugment(al_train_transforms("busi", elastic=True), image_size=32)(torch.stack([img] * 4).to(dev), torch.cat([lab] * 4).to(dev))
+    assert b["image"].shape == (4, 1, 32, 32) and b["label"].shape == (4, 32, 32)
+
+
 def test_random_crop2d():
     """RandomCrop2D (joint_transform.py:130-155): T.RandomCrop.get_params draw order (i then j, none when the size already
     matches) and F.crop, per-sample dict API and batched, image + label bit-exact vs the oracle's draw + slice."""

@@ -188,3 +188,26 @@ def test_affine_grid_restatement_equals_torch_bmm_on_this_cpu():
     if bad and torch.backends.cpu.get_cpu_capability() != "AVX512":
         pytest.skip(f"{bad} of {tot} grid values differ from this CPU's sgemm ({torch.backends.cpu.get_cpu_capability()})")
     assert bad == 0, (bad, tot)
+
+
+def test_elastic_restatement_known_answers():
+    """oracle.apply_elastic restates the build's OWN elastic-deformation spec (the reference has none):
+    zero field = identity, constant integer field = shift with zero fill, label values never invented."""
+    from oracle import transforms_ref as R
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(2, 20, 24, generator=g)
+    lab = torch.randint(0, 3, (1, 20, 24), generator=g)
+    assert torch.equal(R.apply_elastic(img, torch.zeros(2, 3, 4)), img)
+    assert torch.equal(R.apply_elastic(lab, torch.zeros(2, 3, 4)), lab)
+    d = torch.zeros(2, 2, 2)
+    d[0] += 3
+    d[1] -= 2
+    want = torch.zeros_like(lab[0])
+    want[2:, :-3] = lab[0][:-2, 3:]
+    assert torch.equal(R.apply_elastic(lab, d)[0], want)
+    wi = torch.zeros_like(img)
+    wi[:, 2:, :-3] = img[:, :-2, 3:]
+    assert torch.allclose(R.apply_elastic(img, d), wi, atol=1e-6)
+    rnd = torch.randn(2, 4, 4, generator=g) * 5
+    out = R.apply_elastic(lab, rnd)
+    assert set(out.unique().tolist()) <= {0, 1, 2} and out.shape == lab.shape
