@@ -8,6 +8,7 @@
 // an LDS reduction.  Weight gradient: dW[co][t] = sum_p x[p+t] * dy[p][co], a 9 x C0 reduction over all
 // pixels, two-stage (block partials, then the generic slab reduce); no float atomics.
 #include "common.h"
+#include <stdlib.h>
 
 template <typename T, typename TI>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const TI* __restrict__ x, const float* __restrict__ w /*[C0][9]*/,
@@ -67,6 +68,136 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const TI* __restrict__ x,
       float t = 0.f;
       for (int j = 0; j < lanes; ++j) t += red[(k * lanes + j) * c0 + ch];
       stats[(((size_t)n * slabs + s) * c0 + ch) * 2 + k] = t;
+    }
+  }
+}
+
+// ---- stem forward on the fp32 matrix cores.  The VALU kernel above needs 72 FMAs (+ 9 image loads in each of the 8 threads
+// that share a pixel) per 16-byte unit it writes and runs at 2.6 TB/s; v_mfma_f32_16x16x4_f32 is EXACT fp32 (an fmaf chain,
+// MI355X_MICROARCH.md) at the vector rate but leaves the VALU free, so the kernel becomes a pure stream:
+//   out[co][px] = sum_tap w[co][tap] * img[px + tap]  =  A(co x tap) * B(tap x px),  K = 9 taps padded to 12 = three MFMAs
+// per 16-pixel run and 16-channel tile.  A = weights (lane: row = channel, k = tap), resident in 3 registers per channel tile;
+// B = one image value per lane (lane: k = tap, column = pixel), fetched straight from global / L1 with a per-lane-group tap
+// offset (image border -> buffer-load zero); C starts as the bias.  D has a lane's four registers = four consecutive
+// channels of one pixel, so bf16 output goes out in 16-byte stores (v_permlane16_swap pairs the channel tiles), fp32 output
+// directly.  No LDS, no barrier in the main loop: a wave walks its own (row, 16-pixel strip) units of the workgroup's band.
+typedef __amdgpu_buffer_rsrc_t srsrc_t;
+template <typename T, int MT>
+__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w /*[C0][9]*/,
+                                                            const float* __restrict__ bias, T* __restrict__ y, int h, int wd,
+                                                            int slabs, float* __restrict__ stats /*[N][slabs][C0][2]*/) {
+  constexpr int C0 = 16 * MT;
+  __shared__ float red[4][2][C0];
+  __shared__ __attribute__((aligned(16))) unsigned char tbuf[4 * 16 * (2 * C0 + 16)];  // per-wave store transpose (bf16 path)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, c16 = lane & 15;
+  const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  const int band = (h + slabs - 1) / slabs, rb = s * band, re = rb + band < h ? rb + band : h;
+  const int strips = (wd + 15) / 16;
+  const size_t hw = (size_t)h * wd;
+  const srsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)n * hw), 0, (int)(hw * 4), 0x00020000);
+  // A fragments: wa[m][g] = w[16m + c16][4g + q] (taps >= 9 are zero columns)
+  float wa[MT][3];
+  f32x4 bv[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) { const int t = 4 * g + q; wa[m][g] = t < 9 ? w[(16 * m + c16) * 9 + t] : 0.f; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[m][r] = bias ? bias[16 * m + 4 * q + r] : 0.f;
+  }
+  // tap of this lane in K-group g: (dy, dx) in -1..1
+  int tdy[3], tdx[3];
+  bool tok[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) { const int t = 4 * g + q; tok[g] = t < 9; tdy[g] = (t < 9 ? t / 3 : 1) - 1; tdx[g] = (t < 9 ? t % 3 : 1) - 1; }
+  float s1[MT][4], s2[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[m][r] = 0.f; s2[m][r] = 0.f; }
+  const int units = (re > rb ? re - rb : 0) * strips;
+  T* yimg = y + (size_t)n * hw * C0;
+  auto load_b = [&](int u, float* b) {
+    const int row = rb + u / strips, x0 = (u % strips) * 16;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const int yy = row + tdy[g], xx = x0 + c16 + tdx[g];
+      const bool ok = u < units && tok[g] && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)wd;
+      b[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (yy * wd + xx) * 4 : (int)0xFFFFFFF0u, 0, 0));
+    }
+  };
+  float bnext[3];
+  load_b(wave, bnext);
+  for (int u = wave; u < units; u += 4) {
+    const int row = rb + u / strips, x0 = (u % strips) * 16;
+    float b[3] = {bnext[0], bnext[1], bnext[2]};
+    load_b(u + 4, bnext);  // the next unit's image values travel behind this unit's MFMAs and stores
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][0], b[0], bv[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][1], b[1], acc[m], 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][2], b[2], acc[m], 0, 0, 0);
+    }
+    const bool colok = x0 + c16 < wd;
+    const float msk = colok ? 1.f : 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float v = acc[m][r] * msk; s1[m][r] += v; s2[m][r] += v * acc[m][r]; }
+    const size_t pix = (size_t)row * wd + x0 + c16;
+    if constexpr (sizeof(T) == 4) {
+      if (colok)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>(yimg + pix * C0 + 16 * m + 4 * q) = acc[m];
+    } else {
+      // bf16: a lane holds 8 bytes (4 channels) per channel tile.  Even channel-tile counts go through a wave-private LDS
+      // transpose (16 pixels x C0 bf16 at a 16-byte-padded pitch) so that every global store covers WHOLE 2*C0-byte pixel
+      // lines (8 pixels x 128 B contiguous per instruction at C0 = 64) instead of 64-byte halves; no barrier: one wave's LDS
+      // operations execute in order.
+      typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+      typedef float f2_t __attribute__((ext_vector_type(2)));
+      typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+      auto pk = [](float a, float c) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f2_t{a, c}, bf2_t)); };
+      if constexpr ((MT & 1) == 0) {
+        constexpr int PITCH = 2 * C0 + 16;  // bytes per pixel row in LDS
+        unsigned char* t = tbuf + wave * (16 * PITCH);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          *reinterpret_cast<u32x2*>(t + c16 * PITCH + 32 * m + 8 * q) = u32x2{pk(acc[m][0], acc[m][1]), pk(acc[m][2], acc[m][3])};
+        constexpr int UPP = 2 * MT;  // 16-byte units per pixel
+#pragma unroll
+        for (int it = 0; it < UPP * 16 / 64; ++it) {
+          const int idx = lane + 64 * it, pxl = idx / UPP, ch = idx - pxl * UPP;
+          const u32x4 d = *reinterpret_cast<const u32x4*>(t + pxl * PITCH + 16 * ch);
+          if (x0 + pxl < wd) *reinterpret_cast<u32x4*>(yimg + ((size_t)row * wd + x0 + pxl) * C0 + 8 * ch) = d;
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const u32x2 d = {pk(acc[m][0], acc[m][1]), pk(acc[m][2], acc[m][3])};
+          if (colok) *reinterpret_cast<u32x2*>(yimg + pix * C0 + 16 * m + 4 * q) = d;
+        }
+      }
+    }
+  }
+  if (stats != nullptr) {
+    // sums over the 16 pixel columns of a lane row (DPP), then over the four waves (LDS)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = s1[m][r], c = s2[m][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+        if (c16 == 0) { red[wave][0][16 * m + 4 * q + r] = a; red[wave][1][16 * m + 4 * q + r] = c; }
+      }
+    __syncthreads();
+    for (int i = tid; i < 2 * C0; i += 256) {
+      const int k = i / C0, ch = i % C0;
+      stats[(((size_t)n * slabs + s) * C0 + ch) * 2 + k] = red[0][k][ch] + red[1][k][ch] + red[2][k][ch] + red[3][k][ch];
     }
   }
 }
@@ -141,7 +272,7 @@ __global__ void stem_wgrad_final_kernel(const float* __restrict__ part, int nblk
   }
 }
 
-#define STEM_SLABS 64
+#define STEM_SLABS 128
 #define STEM_WBLOCKS 2048
 extern "C" int mia_stem_slabs(void) { return STEM_SLABS; }
 extern "C" int mia_stem_wgrad_workspace(int c0) { return STEM_WBLOCKS * 9 * c0; }
@@ -161,6 +292,19 @@ extern "C" int mia_stem_fwd(const void* x, int x_dtype, const float* w, const fl
   const size_t shb = (size_t)(2 * lanes * c0) * 4;
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(n * STEM_SLABS);
+  // fp32 image, channel count a multiple of 16: the matrix-core kernel (exact fp32 arithmetic, HBM-bound)
+  static int use_mfma = -1;
+  if (use_mfma < 0) { const char* e = getenv("MIA_STEM_MFMA"); use_mfma = (e && e[0] == '0') ? 0 : 1; }
+  const bool al16 = (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+  if (use_mfma && x_dtype == MIA_F32 && al16 && (c0 == 16 || c0 == 32 || c0 == 64 || c0 == 96 || c0 == 128) && (int64_t)h * wd * 4 < ((int64_t)1 << 31)) {
+#define SM(T, MT) hipLaunchKernelGGL((stem_fwd_mfma_kernel<T, MT>), grid, dim3(256), 0, st, static_cast<const float*>(x), w, bias, static_cast<T*>(y), h, wd, STEM_SLABS, stat_partials)
+#define SMT(T) do { if (c0 == 16) SM(T, 1); else if (c0 == 32) SM(T, 2); else if (c0 == 64) SM(T, 4); else if (c0 == 96) SM(T, 6); else SM(T, 8); } while (0)
+    if (dtype == MIA_BF16) SMT(bf16_t); else SMT(float);
+#undef SMT
+#undef SM
+    MIA_LAUNCH_CHECK();
+    return MIA_OK;
+  }
 #define SF(T, TI) hipLaunchKernelGGL((stem_fwd_kernel<T, TI>), grid, dim3(256), shb, st, static_cast<const TI*>(x), w, bias, static_cast<T*>(y), h, wd, c0, STEM_SLABS, stat_partials)
   if (dtype == MIA_BF16 && x_dtype == MIA_F32) SF(bf16_t, float);
   else if (dtype == MIA_BF16) SF(bf16_t, bf16_t);

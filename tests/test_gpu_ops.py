@@ -403,6 +403,32 @@ def test_out_of_range_label_poisons_loss_and_is_reported(layout):
         fn2.get_ce_loss(logits, labels)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c0,hw", [(16, (37, 53)), (32, (64, 64)), (64, (128, 80)), (96, (23, 100)), (128, (16, 16)), (8, (20, 28))])
+def test_stem_forward(c0, hw, dtype):
+    """Conv2d(1, C0, 3, padding=1) on the fp32 image (reference unet.py:54-66 with input_channels=1): the fp32 matrix-core
+    kernel (C0 a multiple of 16; exact fp32 fma chain) and the VALU kernel (other C0) vs F.conv2d, outputs and the
+    per-(image, channel) statistics partials; ragged widths (W not a multiple of 16), heights not a multiple of the bands."""
+    import ctypes
+    from mia_hip import call, lib, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(c0)
+    n, (h, w) = 3, hw
+    x = torch.rand(n, 1, h, w, generator=g)
+    wt = torch.randn(c0, 1, 3, 3, generator=g) / 3
+    b = torch.randn(c0, generator=g)
+    ref = F.conv2d(x, wt, b, padding=1)
+    y = torch.empty((n, h, w, c0), device=dev, dtype=dtype)
+    stats = torch.empty((n, lib().mia_stem_slabs(), c0, 2), device=dev, dtype=torch.float32)
+    xd = x.to(dev).reshape(n, h, w, 1)
+    wd_, bd = wt.reshape(c0, 9).to(dev).contiguous(), b.to(dev)  # named: a temporary would be freed (and its memory reused) before the launch
+    call("mia_stem_fwd", ops._p(xd), ops._dt(xd), ops._p(wd_), ops._p(bd), ops._p(y), ops._dt(y), ops._p(stats), n, h, w, c0, ops._stream())
+    got = nchw(y)
+    assert relerr(got, ref) < (2e-6 if dtype == torch.float32 else 5e-3)
+    s = stats.sum(1).cpu()
+    assert relerr(s[..., 0], ref.sum((2, 3))) < 1e-4 and relerr(s[..., 1], (ref ** 2).sum((2, 3))) < 1e-4
+
+
 def test_dropout_mask_zero_and_gather_utilities():
     """Library kernels that replace PyTorch's bernoulli / fill / strided copy inside the step: Dropout2d masks take the two
     values {0, 1/keep} with the right frequency, are reproducible under torch.manual_seed and differ call to call."""
