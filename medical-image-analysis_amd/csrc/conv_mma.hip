@@ -290,12 +290,14 @@ static int dispatch(int mode, const ConvArgs& a, int mt, int nt, int grid_y, hip
 // Tile-domain geometry shared with the host (stats buffer sizing): see include/mia_hip.h.
 static int g_big_tiles = -1;  // MIA_CONV_MT8=1: 32-row tiles for bf16 3x3 s1 (experiment knob, default off)
 
-extern int g_wgrad_w8;  // conv_wgrad.hip
+extern int g_wgrad_w8, g_wgrad_tab, g_wgrad_dma;  // conv_wgrad.hip
 static int g_use64 = -1;  // MIA_CONV64=0 / mia_set_option("conv64", 0): 64-channel launches take the generic tile kernel (A/B knob)
 
 extern "C" int mia_set_option(const char* name, int value) {
   MIA_CHECK_ARG(name != nullptr, "mia_set_option: null name");
   if (strcmp(name, "conv64") == 0) { g_use64 = value ? 1 : 0; return MIA_OK; }
+  if (strcmp(name, "wgrad_dma") == 0) { g_wgrad_dma = value ? 1 : 0; return MIA_OK; }
+  if (strcmp(name, "wgrad_tab") == 0) { g_wgrad_tab = value ? 1 : 0; return MIA_OK; }
   if (strcmp(name, "wgrad_w8") == 0) { g_wgrad_w8 = value ? 1 : 0; return MIA_OK; }
   mia_set_error("mia_set_option: unknown option '%s'", name);
   return MIA_EARG;

@@ -30,6 +30,7 @@ struct WgArgs {
   int npad, kpad, ksplit;
   int tiles_x, tiles_y;
   int vec_x, vec_dy;
+  int opt;  // bit 0: table-driven staging of interior tiles (wgrad_bf16_2wg_kernel)
 };
 
 template <int MODE> struct WGeo {
@@ -353,7 +354,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) 
   constexpr int XH = TH - 1 + KS, XW = 15 + KS, XP = 32;
   constexpr int X_IT = (XH * XW + 31) / 32, D_IT = TH * 16 / 32;  // 32 pixels x 8 chunks per staging iteration
   constexpr int X_BYTES = XH * XP * 128, D_BYTES = TH * 16 * 128;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[X_BYTES + D_BYTES];
+  static_assert(X_IT == 6 && D_IT == 4, "the staging table below is laid out for TH = 8");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[X_BYTES + D_BYTES + 4 * 256 * 16];
+  u32x4* tab = reinterpret_cast<u32x4*>(smem + X_BYTES + D_BYTES);  // [4][256]: per-thread staging constants, see below
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -376,10 +379,52 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) 
   int d_tx, d_ty, d_img;
   { int tt = a.ksplit; d_tx = tt % a.tiles_x; tt /= a.tiles_x; d_ty = tt % a.tiles_y; d_img = tt / a.tiles_y; }
 
+  // Per-thread staging constants live in LDS, not in registers (there are none to spare) and not in VALU work per tile
+  // (measured with the stamps build: ~200 address instructions per tile, issued at half rate beside the other workgroup's
+  // MFMAs, made the fetch phase 1800 cycles of an 8000-cycle tile): for a tile whose halo lies inside the image the ten
+  // global offsets are "tile origin (folded into the buffer descriptor) + constant", and the six LDS offsets are constant.
+  //   tab[0] = x offsets 0..3, tab[1] = x offsets 4..5 | dy offsets 0..1, tab[2] = dy offsets 2..3 | LDS offsets 0..1,
+  //   tab[3] = LDS offsets 2..5
+  {
+    unsigned xo[X_IT], xl[X_IT], dofs[D_IT];
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int pix = p8 + 32 * i, iy = pix / XW, ix = pix - iy * XW;
+      xo[i] = (pix < XH * XW && x_chan_ok) ? (unsigned)(((iy * a.Wx + ix) * cs + kloc + ch8 * 8) * 2) : WSENT;
+      xl[i] = (unsigned)swz_off(iy * XP + ix, ch8);
+    }
+#pragma unroll
+    for (int i = 0; i < D_IT; ++i) {
+      const int pix = p8 + 32 * i;
+      dofs[i] = d_chan_ok ? (unsigned)((((pix >> 4) * a.Wy + (pix & 15)) * a.cdy + n0 + ch8 * 8) * 2) : WSENT;
+    }
+    tab[tid] = u32x4{xo[0], xo[1], xo[2], xo[3]};
+    tab[256 + tid] = u32x4{xo[4], xo[5], dofs[0], dofs[1]};
+    tab[512 + tid] = u32x4{dofs[2], dofs[3], xl[0], xl[1]};
+    tab[768 + tid] = u32x4{xl[2], xl[3], xl[4], xl[5]};
+  }
+
   u32x4 px[X_IT], pd[D_IT];
   auto fetch = [&](int img, int ty, int tx) {
     const int oy0 = ty * TH, ox0 = tx * 16;
     const int iy0 = oy0 - PAD, ix0 = ox0 - PAD;
+    if ((a.opt & 1) && iy0 >= 0 && ix0 >= 0 && iy0 + XH <= a.Hx && ix0 + XW <= a.Wx && oy0 + TH <= a.Hy && ox0 + 16 <= a.Wy) {
+      const size_t xorg = (size_t)iy0 * a.Wx + ix0, dorg = (size_t)oy0 * a.Wy + ox0;
+      const wrsrc_t rx = wmake_rsrc(xsrc + ((size_t)img * xpix + xorg) * cs, (unsigned)((xpix - xorg) * cs * 2));
+      const wrsrc_t rd = wmake_rsrc(dy + ((size_t)img * ypix + dorg) * a.cdy, (unsigned)((ypix - dorg) * a.cdy * 2));
+      const u32x4 t0 = tab[tid], t1 = tab[256 + tid], t2 = tab[512 + tid];
+      px[0] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)t0.x, 0, 0);
+      px[1] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)t0.y, 0, 0);
+      px[2] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)t0.z, 0, 0);
+      px[3] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)t0.w, 0, 0);
+      px[4] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)t1.x, 0, 0);
+      px[5] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)t1.y, 0, 0);
+      pd[0] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)t1.z, 0, 0);
+      pd[1] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)t1.w, 0, 0);
+      pd[2] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)t2.x, 0, 0);
+      pd[3] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)t2.y, 0, 0);
+      return;
+    }
     const wrsrc_t rx = wmake_rsrc(xsrc + (size_t)img * xpix * cs, (unsigned)(xpix * cs * 2));
     const wrsrc_t rd = wmake_rsrc(dy + (size_t)img * ypix * a.cdy, (unsigned)(ypix * a.cdy * 2));
     int p8v = p8;
@@ -404,11 +449,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) 
   auto commit = [&]() {
     int p8v = p8;
     asm volatile("" : "+v"(p8v));
-#pragma unroll
-    for (int i = 0; i < X_IT; ++i) {
-      const int pix = p8v + 32 * i, iy = pix / XW, ix = pix - iy * XW;
-      if (pix < XH * XW) *reinterpret_cast<u32x4*>(smem + swz_off(iy * XP + ix, ch8)) = px[i];
-    }
+    const u32x4 t2 = tab[512 + tid], t3 = tab[768 + tid];
+    *reinterpret_cast<u32x4*>(smem + t2.z) = px[0];
+    *reinterpret_cast<u32x4*>(smem + t2.w) = px[1];
+    *reinterpret_cast<u32x4*>(smem + t3.x) = px[2];
+    *reinterpret_cast<u32x4*>(smem + t3.y) = px[3];
+    *reinterpret_cast<u32x4*>(smem + t3.z) = px[4];
+    if (p8v + 32 * 5 < XH * XW) *reinterpret_cast<u32x4*>(smem + t3.w) = px[5];
     const int d0 = swz_off(p8v, ch8);  // + 4096 per iteration (32 rows)
 #pragma unroll
     for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(smem + X_BYTES + d0 + 4096 * i) = pd[i];
@@ -492,6 +539,260 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) 
   if (lane == 0 && blockIdx.x == 0 && blockIdx.y < 512) {
     unsigned long long* d = wgrad_dbg + ((size_t)blockIdx.y * 4 + wave) * 8;
     d[0] = a_b1; d[1] = a_c; d[2] = a_b2; d[3] = a_f; d[4] = a_m; d[5] = a_n;
+  }
+#endif
+  float* slab = a.slabs + (size_t)blockIdx.y * TAPS * a.npad * a.kpad;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + c * 16 + 4 * grp + r, k = k0 + wave * 16 + i16;
+        if (kloc + wave * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+      }
+}
+
+// ---------------------------------------------------------------- bf16, LDS-DMA ring (stride-1 3x3)
+// Same block per workgroup (64 n x 64 k x 9 taps), same swizzled LDS image and fragment reads as wgrad_bf16_2wg_kernel, but
+// the tiles arrive by LDS-DMA (`buffer_load_dwordx4 ... offen lds`: no staging registers, no ds_write pass, no second
+// barrier) into a ring of THREE tile images, so a tile's loads have two tile times to land:
+//   * a tile is 4 output rows x 16 pixels: x image [6 rows][24 pixels (18 used)][64 ch] = 18 KB, dy image [64 px][64 ch] =
+//     8 KB; 3 x 26 KB = 78 KB per workgroup, two workgroups per CU (156 of 160 KB);
+//   * one DMA instruction writes 1 KB = one 8-pixel x 128-byte row block of the image, lane L at byte 16 L; the chunk
+//     swizzle is applied on the SOURCE side (lane L fetches chunk (L&3) ^ swizzle(row)), out-of-image / out-of-channel lanes
+//     point past the descriptor and are zero filled.  26 pieces per tile, dealt round-robin to the 4 waves;
+//   * per tile: issue tile t+2 -> MFMAs of tile t -> s_waitcnt vmcnt(own pieces of t+2) [= own pieces of t+1 landed] ->
+//     s_barrier [everyone's pieces of t+1 landed, everyone done reading t].  The DMA is issued and counted in inline asm
+//     (hipcc would drain it with vmcnt(0) at every barrier / LDS read it can see);
+//   * the 40 staging registers of the 2wg kernel pay for a second set of dy fragments and a three-deep x fragment ring, so
+//     the fragment reads run two taps ahead of their MFMAs.
+typedef int wi32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wi32x4 wmake_rsrc_i(const void* p, unsigned bytes) {
+  const unsigned long long addr = (unsigned long long)p;
+  wi32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)addr);
+  r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(addr >> 32));
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void lds_dma16(wi32x4 rsrc, unsigned voff, unsigned lds_dst) {
+  // M0 = wave-uniform LDS byte address of the 1 KB piece.  M0 is written and read inside this one statement and not restored:
+  // hipcc uses M0 for nothing else in these kernels (checked in the ISA: no other reference to m0), and a save / restore
+  // pair per piece is two more scalar instructions in the phase that has to hide behind the other workgroup's MFMAs.
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) {
+  constexpr int KS = 3, TAPS = 9, TH = 4;
+  constexpr int XH = TH + 2, XROW = 3072;  // 24 pixels x 128 B per image row of the x tile
+  constexpr int X_BYTES = XH * XROW, D_BYTES = TH * 16 * 128, STAGE = X_BYTES + D_BYTES, NSTAGE = 3;
+  constexpr int XPIECES = XH * 3, PIECES = XPIECES + TH * 2;  // 18 + 8
+  constexpr int MAXOWN = (PIECES + 3) / 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = lane >> 4, i16 = lane & 15, qp = i16 >> 2, pp = i16 & 3;
+  const int kb1 = (a.c1 + 63) / 64, nkb = kb1 + (a.c2 + 63) / 64;
+  const int kblk = blockIdx.x % nkb, nblk = blockIdx.x / nkb;
+  const bool second = kblk >= kb1;
+  const int cs = second ? a.c2 : a.c1, kloc = (second ? kblk - kb1 : kblk) * 64;
+  const int n0 = nblk * 64, k0 = (second ? a.c1 : 0) + kloc;
+  const bf16_t* xsrc = static_cast<const bf16_t*>(second ? a.x2 : a.x1);
+  const bf16_t* dy = static_cast<const bf16_t*>(a.dy);
+  const size_t xpix = (size_t)a.Hx * a.Wx, ypix = (size_t)a.Hy * a.Wy;
+
+  // DMA lane constants: lane L of a piece is 16-byte chunk (L&3) of half (L>>5) of pixel row r = (L>>2)&7 of the 8-row block;
+  // the source chunk is un-swizzled by the block's parity p (rows 8 blk + r: (row>>2)&3 = (2 p + (r>>2)) & 3)
+  const int dr = (lane >> 2) & 7;
+  // (plain scalars, not arrays: a wave-uniform but run-time index sends an array to scratch, whose reload waits vmcnt(0))
+  const int ch8_0 = 4 * (lane >> 5) + ((lane & 3) ^ ((dr >> 2) & 3)), ch8_1 = 4 * (lane >> 5) + ((lane & 3) ^ ((2 + (dr >> 2)) & 3));
+  const unsigned xlane0 = (unsigned)((dr * cs + kloc + ch8_0 * 8) * 2), xlane1 = (unsigned)((dr * cs + kloc + ch8_1 * 8) * 2);
+  const unsigned dlane0 = (unsigned)((dr * a.cdy + n0 + ch8_0 * 8) * 2), dlane1 = (unsigned)((dr * a.cdy + n0 + ch8_1 * 8) * 2);
+  const bool xok0 = kloc + ch8_0 * 8 < cs, xok1 = kloc + ch8_1 * 8 < cs;
+  const bool dok0 = n0 + ch8_0 * 8 < a.cdy, dok1 = n0 + ch8_1 * 8 < a.cdy;
+  const unsigned lds0 = (unsigned)(size_t)(lds_u8*)smem;
+
+  auto issue = [&](int img, int ty, int tx, unsigned stage_base) {
+    const int oy0 = ty * TH, ox0 = tx * 16;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const wi32x4 rx = wmake_rsrc_i(xsrc + (size_t)img * xpix * cs, (unsigned)(xpix * cs * 2));
+    const wi32x4 rd = wmake_rsrc_i(dy + (size_t)img * ypix * a.cdy, (unsigned)(ypix * a.cdy * 2));
+#pragma unroll
+    for (int j = 0; j < MAXOWN; ++j) {
+      const int pc = wave + 4 * j;  // wave-uniform piece index
+      if (pc < XPIECES) {
+        const int iy = pc / 3, xb = pc - 3 * iy;
+        const int gy = iy0 + iy, gx = ix0 + 8 * xb + dr;
+        const bool ok = ((unsigned)gy < (unsigned)a.Hx) & ((unsigned)gx < (unsigned)a.Wx) & (8 * xb + dr < 18) & ((xb & 1) ? xok1 : xok0);
+        const unsigned off = (unsigned)((gy * a.Wx + ix0 + 8 * xb) * cs * 2) + ((xb & 1) ? xlane1 : xlane0);
+        lds_dma16(rx, ok ? off : WSENT, __builtin_amdgcn_readfirstlane(stage_base + iy * XROW + xb * 1024));
+      } else if (pc < PIECES) {
+        const int q = pc - XPIECES;  // 8-pixel block of the dy tile: output row q>>1, pixels 8 (q&1) ..
+        const int gy = oy0 + (q >> 1), gx = ox0 + 8 * (q & 1) + dr;
+        const bool ok = (gy < a.Hy) & (gx < a.Wy) & ((q & 1) ? dok1 : dok0);
+        const unsigned off = (unsigned)((gy * a.Wy + ox0 + 8 * (q & 1)) * a.cdy * 2) + ((q & 1) ? dlane1 : dlane0);
+        lds_dma16(rd, ok ? off : WSENT, __builtin_amdgcn_readfirstlane(stage_base + X_BYTES + q * 1024));
+      }
+    }
+  };
+  // Tiles whose 18 columns lie inside the image (all but the first / last tile of a row): the lane part of every piece's
+  // offset is a constant (kept in registers, padding / channel-tail lanes already pointing out of range), the tile origin
+  // goes into the descriptor base and a piece's rows are valid or not as a whole.  Measured with the stamps build: the
+  // general issue() above costs ~1700 cycles per tile and wave (as long as the tile's MFMAs), this one a fraction.
+  unsigned voffc[MAXOWN];
+#pragma unroll
+  for (int j = 0; j < MAXOWN; ++j) {
+    const int pc = wave + 4 * j;
+    if (pc < XPIECES) {
+      const int iy = pc / 3, xb = pc - 3 * iy, ix = 8 * xb + dr;
+      const bool ok = (ix < 18) & ((xb & 1) ? xok1 : xok0);
+      voffc[j] = ok ? (unsigned)((iy * a.Wx + 8 * xb) * cs * 2) + ((xb & 1) ? xlane1 : xlane0) : WSENT;
+    } else {
+      const int q = pc - XPIECES;
+      const bool ok = (pc < PIECES) & ((q & 1) ? dok1 : dok0);
+      voffc[j] = ok ? (unsigned)(((q >> 1) * a.Wy + 8 * (q & 1)) * a.cdy * 2) + ((q & 1) ? dlane1 : dlane0) : WSENT;
+    }
+  }
+  auto issue_fast = [&](int img, int ty, int tx, unsigned stage_base) {
+    const int oy0 = ty * TH, ox0 = tx * 16;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    // descriptor bases at the tile origin (row iy0 may be -1: its pieces are dropped below, nothing is read through it)
+    const long long xorg = ((long long)(img * a.Hx + iy0) * a.Wx + ix0) * cs;
+    const long long dorg = ((long long)(img * a.Hy + oy0) * a.Wy + ox0) * a.cdy;
+    const wi32x4 rx = wmake_rsrc_i(xsrc + xorg, (unsigned)(XH * a.Wx * cs * 2));
+    const wi32x4 rd = wmake_rsrc_i(dy + dorg, (unsigned)(TH * a.Wy * a.cdy * 2));
+    const unsigned m0base = stage_base + wave * 1024;  // piece pc of the tile image lives at byte 1024 pc
+#pragma unroll
+    for (int j = 0; j < MAXOWN; ++j) {
+      const int pc = wave + 4 * j;
+      const bool is_x = 4 * j + 3 < XPIECES || (4 * j < XPIECES && pc < XPIECES);
+      const bool is_d = !is_x && (4 * j + 3 < PIECES || pc < PIECES);
+      if (is_x) {
+        const bool rowok = (unsigned)(iy0 + pc / 3) < (unsigned)a.Hx;
+        lds_dma16(rx, rowok ? voffc[j] : WSENT, m0base + 4096 * j);
+      } else if (is_d) {
+        const bool rowok = oy0 + ((pc - XPIECES) >> 1) < a.Hy;
+        lds_dma16(rd, rowok ? voffc[j] : WSENT, m0base + 4096 * j);
+      }
+    }
+  };
+  auto issue_any = [&](int img, int ty, int tx, unsigned stage_base) {
+    if (tx > 0 && tx * 16 + 17 <= a.Wx && tx * 16 + 16 <= a.Wy) issue_fast(img, ty, tx, stage_base);
+    else issue(img, ty, tx, stage_base);
+  };
+  // this wave's pieces per tile: waves with wave < PIECES % 4 own one more
+  auto wait_own_in_flight = [&]() {  // all but the newest tile's own pieces have landed
+    if (wave < (PIECES & 3)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXOWN) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXOWN - 1) : "memory");
+  };
+
+  f32x4 acc[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // lane-constant fragment bases (absolute LDS bytes of the CURRENT stage; stepped by one stage per tile)
+  const int g1 = grp >> 1, xb0 = 8 * (grp & 1) + qp, sub = 8 * (pp & 1);
+  unsigned dbase[2][2], xbase[KS][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {  // channel tiles c and c + 2 differ by +512 bytes
+    dbase[c][0] = lds0 + X_BYTES + swz_off(g1 * 16 + xb0, 2 * c + (pp >> 1)) + sub;
+    dbase[c][1] = lds0 + X_BYTES + swz_off(g1 * 16 + xb0 + 4, 2 * c + (pp >> 1)) + sub;
+  }
+#pragma unroll
+  for (int kw = 0; kw < KS; ++kw) {
+    xbase[kw][0] = lds0 + g1 * XROW + swz_off(xb0 + kw, 2 * wave + (pp >> 1)) + sub;
+    xbase[kw][1] = lds0 + g1 * XROW + swz_off(xb0 + kw + 4, 2 * wave + (pp >> 1)) + sub;
+  }
+
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  int tile = blockIdx.y;
+  int t_tx, t_ty, t_img;  // digits of the NEXT tile to issue
+  { int tt = tile; t_tx = tt % a.tiles_x; tt /= a.tiles_x; t_ty = tt % a.tiles_y; t_img = tt / a.tiles_y; }
+  int d_tx, d_ty, d_img;
+  { int tt = a.ksplit; d_tx = tt % a.tiles_x; tt /= a.tiles_x; d_ty = tt % a.tiles_y; d_img = tt / a.tiles_y; }
+  auto advance = [&]() {
+    t_tx += d_tx; if (t_tx >= a.tiles_x) { t_tx -= a.tiles_x; t_ty += 1; }
+    t_ty += d_ty; if (t_ty >= a.tiles_y) { t_ty -= a.tiles_y; t_img += 1; }
+    t_img += d_img;
+  };
+  int issue_tile = tile;       // index of the next tile to issue
+  unsigned issue_stage = 0;    // ring slot it goes to
+  // prologue: two tiles in flight
+#pragma unroll 1
+  for (int s = 0; s < 2; ++s) {
+    if (issue_tile < ntiles) { issue_any(t_img, t_ty, t_tx, lds0 + issue_stage * STAGE); advance(); }
+    issue_tile += a.ksplit;
+    issue_stage = issue_stage == NSTAGE - 1 ? 0 : issue_stage + 1;
+  }
+  if (tile + a.ksplit < ntiles) wait_own_in_flight(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int stage = 0;
+#ifdef CONV64_STAMPS
+  unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, a_i = 0, a_m = 0, a_w = 0, a_b = 0, a_n = 0;
+#endif
+  for (; tile < ntiles; tile += a.ksplit) {
+    WSTAMP(w0);
+    const bool more = issue_tile < ntiles;
+    if (more) { issue_any(t_img, t_ty, t_tx, lds0 + issue_stage * STAGE); advance(); }
+    issue_tile += a.ksplit;
+    issue_stage = issue_stage == NSTAGE - 1 ? 0 : issue_stage + 1;
+
+    WSTAMP(w1);
+    u32x4 af[2][4], bf[3];
+    auto load_a = [&](int kb, int c) -> u32x4 {
+      const s16x4 lo = tr_read_at(dbase[c & 1][0] + 512 * (c >> 1) + 4096 * kb);
+      const s16x4 hi = tr_read_at(dbase[c & 1][1] + 512 * (c >> 1) + 4096 * kb);
+      return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto load_b = [&](int step) -> u32x4 {  // step = kb * 9 + tap
+      const int kb = step / TAPS, t = step % TAPS, kh = t / KS, kw = t % KS;
+      const s16x4 lo = tr_read_at(xbase[kw][0] + XROW * (2 * kb + kh));
+      const s16x4 hi = tr_read_at(xbase[kw][1] + XROW * (2 * kb + kh));
+      return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) af[0][c] = load_a(0, c);
+    bf[0] = load_b(0);
+    bf[1] = load_b(1);
+#pragma unroll
+    for (int step = 0; step < 2 * TAPS; ++step) {
+      const int kb = step / TAPS, t = step % TAPS;
+      if (step + 2 < 2 * TAPS) bf[(step + 2) % 3] = load_b(step + 2);
+      if (kb == 0 && t >= 5 && t <= 8) af[1][t - 5] = load_a(1, t - 5);  // second row block's dy fragments behind the first's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kb][c]), __builtin_bit_cast(bf16x8, bf[step % 3]),
+                                                            acc[t][c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // next stage's fragment bases
+    const int delta = stage == NSTAGE - 1 ? -(NSTAGE - 1) * STAGE : STAGE;
+    stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { dbase[c][0] += delta; dbase[c][1] += delta; }
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw) { xbase[kw][0] += delta; xbase[kw][1] += delta; }
+    WSTAMP(w2);
+    if (more) wait_own_in_flight(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WSTAMP(w3);
+    __builtin_amdgcn_s_barrier();
+    WSTAMP(w4);
+#ifdef CONV64_STAMPS
+    a_i += w1 - w0; a_m += w2 - w1; a_w += w3 - w2; a_b += w4 - w3; a_n += 1;
+#endif
+  }
+#ifdef CONV64_STAMPS
+  if (lane == 0 && blockIdx.x == 0 && blockIdx.y < 512) {
+    unsigned long long* d = wgrad_dbg + ((size_t)blockIdx.y * 4 + wave) * 8;
+    d[0] = a_i; d[1] = a_m; d[2] = a_w; d[3] = a_b; d[4] = 0; d[5] = a_n;
   }
 #endif
   float* slab = a.slabs + (size_t)blockIdx.y * TAPS * a.npad * a.kpad;
@@ -781,13 +1082,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+int g_wgrad_dma = 1;   // mia_set_option("wgrad_dma", v): LDS-DMA ring kernel for the stride-1 3x3 bf16 shape
+int g_wgrad_tab = 1;   // mia_set_option("wgrad_tab", v): A/B switch of the table-driven staging
 int g_wgrad_w8 = -1;  // set through mia_set_option("wgrad_w8", v)
 
 // tile heights (rows of 16 output pixels per split-K step)
 static int wgrad_tile_h(int mode, int dtype, int hy, bool fast) {
   const int s = mode == MODE_W3S1 ? 1 : 2;
   if (dtype != MIA_BF16) return s == 1 ? 4 : 2;
-  (void)hy; (void)fast;  // 16-row tiles measured slower (more VGPRs, partial unroll): 575 vs 621 TFLOP/s at 64ch 512x512
+  (void)hy;  // 16-row tiles measured slower (more VGPRs, partial unroll): 575 vs 621 TFLOP/s at 64ch 512x512
+  if (s == 1 && fast && g_wgrad_dma) return 4;  // wgrad_bf16_dma_kernel
   return s == 1 ? 8 : 4;
 }
 
@@ -798,6 +1102,12 @@ static bool wgrad_two_wg(int mode, int dtype) {
   return on && mode == MODE_W3S1 && dtype == MIA_BF16;
 }
 
+extern "C" int mia_wgrad_dma_occupancy(void) {  // diagnostic: resident workgroups per CU
+  int n = -1;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_bf16_dma_kernel, 256, 0);
+  return n;
+}
+
 /* split-K workgroups to aim for: one per CU, or two where the kernel is built for two workgroups per CU */
 extern "C" int mia_wgrad_target_blocks(int mode, int dtype) {
   if (wgrad_two_wg(mode, dtype)) return 512;
@@ -806,7 +1116,7 @@ extern "C" int mia_wgrad_target_blocks(int mode, int dtype) {
 }
 
 extern "C" int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x) {
-  const int th = wgrad_tile_h(mode, dtype, hy, false);
+  const int th = wgrad_tile_h(mode, dtype, hy, true);  // the finest tiling any kernel of this mode uses (bounds ksplit)
   if (tiles_y) *tiles_y = ceil_div(hy, th);
   if (tiles_x) *tiles_x = ceil_div(wy, 16);
   return MIA_OK;
@@ -831,6 +1141,7 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vec_x = (c1 % epu == 0) && (c2 % epu == 0) && al16(x1) && (x2 == nullptr || al16(x2));
   a.vec_dy = (cdy % epu == 0) && al16(dy);
+  a.opt = g_wgrad_tab ? 1 : 0;
   dim3 grid((npad / 64) * (kpad / 64), ksplit);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t lim = (size_t)1 << 31;
@@ -842,7 +1153,9 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   const int th = wgrad_tile_h(mode, dtype, hy, fast);
   a.tiles_y = ceil_div(hy, th);
   a.tiles_x = ceil_div(wy, 16);
-  if (fast && wgrad_two_wg(mode, dtype)) {  // stride-2 / transposed shapes stay on the one-workgroup-per-CU kernel
+  if (fast && th == 4 && mode == MODE_W3S1) {
+    hipLaunchKernelGGL(wgrad_bf16_dma_kernel, fgrid, dim3(256), 0, st, a);
+  } else if (fast && wgrad_two_wg(mode, dtype)) {  // stride-2 / transposed shapes stay on the one-workgroup-per-CU kernel
     hipLaunchKernelGGL(wgrad_bf16_2wg_kernel<8>, fgrid, dim3(256), 0, st, a);
   } else if (fast) {
     if (mode == MODE_W3S1 && th == 16) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 16>), fgrid, dim3(256), 0, st, a);

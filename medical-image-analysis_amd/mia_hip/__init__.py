@@ -82,6 +82,11 @@ def lib() -> ctypes.CDLL:
             fn = getattr(l, name)
             fn.restype = ret
             fn.argtypes = args
+        # A/B knobs (kernel selection only, never numerics contracts): MIA_OPTIONS="wgrad_dma=0,conv64=1" -> mia_set_option
+        for item in filter(None, os.environ.get("MIA_OPTIONS", "").split(",")):
+            key, _, val = item.partition("=")
+            if l.mia_set_option(key.strip().encode(), int(val or 1)) != 0:
+                raise MiaError(f"MIA_OPTIONS: unknown option {key!r}")
         _lib = l
     return _lib
 

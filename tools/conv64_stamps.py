@@ -45,6 +45,8 @@ def wgrad():
     n = d[..., 5]
     live = n > 0
     names = ["barrier 1 (readers done)", "commit (ds_write)", "barrier 2", "fetch issue", "MFMA loop"]
+    if os.environ.get("MIA_STAMPS_DMA", "1") != "0":  # wgrad_bf16_dma_kernel's phases
+        names = ["DMA issue (tile t+2)", "fragment reads + MFMAs", "vmcnt wait (tile t+1)", "barrier", "-"]
     tot = 0.0
     for i, nm in enumerate(names):
         per = (d[..., i][live] / n[live]).mean()
