@@ -13,6 +13,7 @@ struct ConvArgs {
   int npad, kpad, flip;
   int tiles_x, tiles_y, nblk_n;
   int vec_in, vec_out;
+  int xcd;  // fast kernel: XCD-aware block order (the blocks that share an input tile run on one XCD, back to back)
 };
 
 __device__ __forceinline__ int pi16(int r) {

@@ -290,12 +290,15 @@ static int dispatch(int mode, const ConvArgs& a, int mt, int nt, int grid_y, hip
 // Tile-domain geometry shared with the host (stats buffer sizing): see include/mia_hip.h.
 static int g_big_tiles = -1;  // MIA_CONV_MT8=1: 32-row tiles for bf16 3x3 s1 (experiment knob, default off)
 
-extern int g_wgrad_w8, g_wgrad_tab, g_wgrad_dma;  // conv_wgrad.hip
+extern int g_wgrad_w8, g_wgrad_tab, g_wgrad_dma, g_wgrad_xcd;  // conv_wgrad.hip
+static int g_conv_xcd = 1;  // mia_set_option("conv_xcd", v): XCD-aware block order of the fast kernel (A/B knob)
 static int g_use64 = -1;  // MIA_CONV64=0 / mia_set_option("conv64", 0): 64-channel launches take the generic tile kernel (A/B knob)
 
 extern "C" int mia_set_option(const char* name, int value) {
   MIA_CHECK_ARG(name != nullptr, "mia_set_option: null name");
+  if (strcmp(name, "conv_xcd") == 0) { g_conv_xcd = value ? 1 : 0; return MIA_OK; }
   if (strcmp(name, "conv64") == 0) { g_use64 = value ? 1 : 0; return MIA_OK; }
+  if (strcmp(name, "wgrad_xcd") == 0) { g_wgrad_xcd = value ? 1 : 0; return MIA_OK; }
   if (strcmp(name, "wgrad_dma") == 0) { g_wgrad_dma = value ? 1 : 0; return MIA_OK; }
   if (strcmp(name, "wgrad_tab") == 0) { g_wgrad_tab = value ? 1 : 0; return MIA_OK; }
   if (strcmp(name, "wgrad_w8") == 0) { g_wgrad_w8 = value ? 1 : 0; return MIA_OK; }
@@ -352,6 +355,7 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
   a.vec_in = (c1 % epu == 0) && (c2 % epu == 0) && al16(in1) && (in2 == nullptr || al16(in2));
   a.vec_out = (o1 % epu == 0) && (o2 % epu == 0) && al16(out1) && (out2 == nullptr || al16(out2));
   const bool tmode = (mode == MODE_T3S2 || mode == MODE_T2S2);
+  a.xcd = g_conv_xcd;
   const int grid_y = tmode ? 4 : 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;

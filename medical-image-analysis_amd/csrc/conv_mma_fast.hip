@@ -44,15 +44,26 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
   const int pr = pi16(r16);
   const int g = tid & 3, p4 = tid >> 2;
 
-  int bid = blockIdx.x;
-  const int nb = bid % a.nblk_n; bid /= a.nblk_n;
+  constexpr bool TMODE = (MODE == MODE_T3S2 || MODE == MODE_T2S2);
+  // Block order.  Workgroups are dealt to the 8 XCDs round robin by linear id, and each XCD has its own L2: the blocks that
+  // read the same input tile (the output-channel blocks of a tile, times the 4 output-parity classes of a transposed mode)
+  // take consecutive slots of ONE XCD, so the tile is fetched into one L2 once instead of into up to eight (and, for the
+  // parity classes, instead of once per pass over the whole grid).
+  int bid = blockIdx.x, par = TMODE ? (int)blockIdx.y : 0, nb;
+  if (a.xcd) {
+    const int G = a.nblk_n * (TMODE ? 4 : 1);
+    const int slot = bid >> 3, grp = slot / G, w = slot - grp * G;
+    bid = grp * 8 + (bid & 7);
+    if (bid >= a.N * a.tiles_x * a.tiles_y) return;
+    nb = w % a.nblk_n; par = w / a.nblk_n;
+  } else {
+    nb = bid % a.nblk_n; bid /= a.nblk_n;
+  }
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y; bid /= a.tiles_y;
   const int img = bid;
   const int n0 = nb * BN;
-  constexpr bool TMODE = (MODE == MODE_T3S2 || MODE == MODE_T2S2);
-  const int ph = TMODE ? (int)(blockIdx.y >> 1) : 0;
-  const int pw = TMODE ? (int)(blockIdx.y & 1) : 0;
+  const int ph = par >> 1, pw = par & 1;
   const int oy0 = ty * TH, ox0 = tx * 16;
   const int iy0 = MODE == MODE_G3S1 ? oy0 - 1 : MODE == MODE_G3S2 ? 2 * oy0 - 1 : MODE == MODE_G2S2 ? 2 * oy0 : oy0;
   const int ix0 = MODE == MODE_G3S1 ? ox0 - 1 : MODE == MODE_G3S2 ? 2 * ox0 - 1 : MODE == MODE_G2S2 ? 2 * ox0 : ox0;
@@ -317,7 +328,11 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
 
 template <typename T, int MODE, int MT, int NT>
 static void flaunch(const ConvArgs& a, int grid_y, hipStream_t st) {
-  const int grid_x = a.N * a.tiles_x * a.tiles_y * a.nblk_n;
+  int grid_x = a.N * a.tiles_x * a.tiles_y * a.nblk_n;
+  if (a.xcd) {  // groups of (channel blocks x parity classes) per tile, tiles rounded up to a multiple of 8
+    grid_x = ((a.N * a.tiles_x * a.tiles_y + 7) / 8) * 8 * a.nblk_n * grid_y;
+    grid_y = 1;
+  }
   hipLaunchKernelGGL((conv_mma_fast_kernel<T, MODE, MT, NT>), dim3(grid_x, grid_y), dim3(256), 0, st, a);
 }
 template <typename T, int MODE, int MT>

@@ -215,7 +215,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
   // two tensors of a concatenated input whatever c1 is; a source's last block may be partial (lanes beyond cs read
   // zeros and do not store)
   const int kb1 = (a.c1 + 63) / 64, nkb = kb1 + (a.c2 + 63) / 64;
-  const int kblk = blockIdx.x % nkb, nblk = blockIdx.x / nkb;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (a.opt & 16) {  // XCD-aware order (1-D grid): the column blocks of one split index share their tiles -> one XCD, one L2
+    const int ncol = nkb * (a.npad / 64), slot = bx >> 3;
+    by = (slot / ncol) * 8 + (bx & 7);
+    bx = slot % ncol;
+    if (by >= a.ksplit) return;
+  }
+  const int kblk = bx % nkb, nblk = bx / nkb;
   const bool second = kblk >= kb1;
   const int cs = second ? a.c2 : a.c1, kloc = (second ? kblk - kb1 : kblk) * 64;
   const int n0 = nblk * 64, k0 = (second ? a.c1 : 0) + kloc;
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
     }
   };
 
-  int tile = blockIdx.y;
+  int tile = by;
   if (tile < ntiles) fetch(tile);
   for (; tile < ntiles; tile += a.ksplit) {
     __syncthreads();  // previous tile's fragment reads are done
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
       }
     }
   }
-  float* slab = a.slabs + (size_t)blockIdx.y * TAPS * a.npad * a.kpad;
+  float* slab = a.slabs + (size_t)by * TAPS * a.npad * a.kpad;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -363,7 +370,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) 
   const int grp = lane >> 4, i16 = lane & 15, qp = i16 >> 2, pp = i16 & 3;
   const int ch8 = tid & 7, p8 = tid >> 3;
   const int kb1 = (a.c1 + 63) / 64, nkb = kb1 + (a.c2 + 63) / 64;
-  const int kblk = blockIdx.x % nkb, nblk = blockIdx.x / nkb;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (a.opt & 16) {  // XCD-aware order (1-D grid): the column blocks of one split index share their tiles -> one XCD, one L2
+    const int ncol = nkb * (a.npad / 64), slot = bx >> 3;
+    by = (slot / ncol) * 8 + (bx & 7);
+    bx = slot % ncol;
+    if (by >= a.ksplit) return;
+  }
+  const int kblk = bx % nkb, nblk = bx / nkb;
   const bool second = kblk >= kb1;
   const int cs = second ? a.c2 : a.c1, kloc = (second ? kblk - kb1 : kblk) * 64;
   const int n0 = nblk * 64, k0 = (second ? a.c1 : 0) + kloc;
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) 
   const bool x_chan_ok = kloc + ch8 * 8 < cs, d_chan_ok = n0 + ch8 * 8 < a.cdy;
 
   const int ntiles = a.N * a.tiles_x * a.tiles_y;
-  int tile = blockIdx.y;
+  int tile = by;
   int t_tx, t_ty, t_img;
   { int tt = tile; t_tx = tt % a.tiles_x; tt /= a.tiles_x; t_ty = tt % a.tiles_y; t_img = tt / a.tiles_y; }
   int d_tx, d_ty, d_img;
@@ -536,12 +550,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) 
 #endif
   }
 #ifdef CONV64_STAMPS
-  if (lane == 0 && blockIdx.x == 0 && blockIdx.y < 512) {
-    unsigned long long* d = wgrad_dbg + ((size_t)blockIdx.y * 4 + wave) * 8;
+  if (lane == 0 && bx == 0 && by < 512) {
+    unsigned long long* d = wgrad_dbg + ((size_t)by * 4 + wave) * 8;
     d[0] = a_b1; d[1] = a_c; d[2] = a_b2; d[3] = a_f; d[4] = a_m; d[5] = a_n;
   }
 #endif
-  float* slab = a.slabs + (size_t)blockIdx.y * TAPS * a.npad * a.kpad;
+  float* slab = a.slabs + (size_t)by * TAPS * a.npad * a.kpad;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -596,7 +610,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = lane >> 4, i16 = lane & 15, qp = i16 >> 2, pp = i16 & 3;
   const int kb1 = (a.c1 + 63) / 64, nkb = kb1 + (a.c2 + 63) / 64;
-  const int kblk = blockIdx.x % nkb, nblk = blockIdx.x / nkb;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (a.opt & 16) {  // XCD-aware order (1-D grid): the column blocks of one split index share their tiles -> one XCD, one L2
+    const int ncol = nkb * (a.npad / 64), slot = bx >> 3;
+    by = (slot / ncol) * 8 + (bx & 7);
+    bx = slot % ncol;
+    if (by >= a.ksplit) return;
+  }
+  const int kblk = bx % nkb, nblk = bx / nkb;
   const bool second = kblk >= kb1;
   const int cs = second ? a.c2 : a.c1, kloc = (second ? kblk - kb1 : kblk) * 64;
   const int n0 = nblk * 64, k0 = (second ? a.c1 : 0) + kloc;
@@ -710,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) 
   }
 
   const int ntiles = a.N * a.tiles_x * a.tiles_y;
-  int tile = blockIdx.y;
+  int tile = by;
   int t_tx, t_ty, t_img;  // digits of the NEXT tile to issue
   { int tt = tile; t_tx = tt % a.tiles_x; tt /= a.tiles_x; t_ty = tt % a.tiles_y; t_img = tt / a.tiles_y; }
   int d_tx, d_ty, d_img;
@@ -790,12 +811,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) 
 #endif
   }
 #ifdef CONV64_STAMPS
-  if (lane == 0 && blockIdx.x == 0 && blockIdx.y < 512) {
-    unsigned long long* d = wgrad_dbg + ((size_t)blockIdx.y * 4 + wave) * 8;
+  if (lane == 0 && bx == 0 && by < 512) {
+    unsigned long long* d = wgrad_dbg + ((size_t)by * 4 + wave) * 8;
     d[0] = a_i; d[1] = a_m; d[2] = a_w; d[3] = a_b; d[4] = 0; d[5] = a_n;
   }
 #endif
-  float* slab = a.slabs + (size_t)blockIdx.y * TAPS * a.npad * a.kpad;
+  float* slab = a.slabs + (size_t)by * TAPS * a.npad * a.kpad;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -1082,6 +1103,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+int g_wgrad_xcd = 1;   // mia_set_option("wgrad_xcd", v): XCD-aware block order of the bf16 fast kernels
 int g_wgrad_dma = 1;   // mia_set_option("wgrad_dma", v): LDS-DMA ring kernel for the stride-1 3x3 bf16 shape
 int g_wgrad_tab = 1;   // mia_set_option("wgrad_tab", v): A/B switch of the table-driven staging
 int g_wgrad_w8 = -1;  // set through mia_set_option("wgrad_w8", v)
@@ -1147,9 +1169,13 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   const size_t lim = (size_t)1 << 31;
   // fast paths: channel tails are zero-filled through out-of-range offsets and input-channel blocks are cut per source
   const bool chan_ok = a.vec_x && a.vec_dy;
-  const dim3 fgrid((npad / 64) * (ceil_div(c1, 64) + ceil_div(c2, 64)), ksplit);
+  dim3 fgrid((npad / 64) * (ceil_div(c1, 64) + ceil_div(c2, 64)), ksplit);
   const bool fast = dtype == MIA_BF16 && chan_ok && (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 2 < lim &&
                     (size_t)hy * wy * cdy * 2 < lim;
+  if (fast && g_wgrad_xcd && ksplit % 8 == 0) {  // bf16 fast kernels: 1-D grid in XCD-aware order (a split count below 8 would leave XCDs idle)
+    a.opt |= 16;
+    fgrid = dim3(fgrid.x * (unsigned)(ceil_div(ksplit, 8) * 8), 1);
+  }
   const int th = wgrad_tile_h(mode, dtype, hy, fast);
   a.tiles_y = ceil_div(hy, th);
   a.tiles_x = ceil_div(wy, 16);
