@@ -279,13 +279,43 @@ __global__ __launch_bounds__(256) void head_norm_fwd_kernel(const T* __restrict_
     for (int k = 0; k < K1; ++k) { const float t = group_sum<UPP>(acc[k]); mine = (u == k) ? t : mine; }
     if (u < K1) ob[(int64_t)p * osp] = mine + bu;
   };
-  int p = r0 + pl;
-  for (; p + LANES < r1; p += 2 * LANES) {
-    const u32x4 a0 = *reinterpret_cast<const u32x4*>(yb + (size_t)p * C0);
-    const u32x4 a1 = *reinterpret_cast<const u32x4*>(yb + (size_t)(p + LANES) * C0);
-    body(a0, p); body(a1, p + LANES);
+  // Bulk: a wave takes 64 consecutive pixels per round -- UPP independent 16-byte loads per lane in flight (each load
+  // instruction reads 64 / UPP whole pixels = 1 KB contiguous), the K1 sums of a pixel go through a wave-private LDS
+  // transpose so that the logits leave as one contiguous 256-byte run per class plane (NCHW fp32 logits: the per-pixel
+  // store of K1 lanes per pixel group wrote 32-byte pieces, 1.8 TB/s on the cfg3 launch).
+  constexpr int GP = 64 / UPP;  // pixels per load instruction and wave
+  __shared__ float tbuf[4][K1][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gl = lane / UPP;
+  float* tb = &tbuf[wave][0][0];
+  const int nbulk = (r1 - r0) / 256 * 256;
+  for (int q0 = r0 + wave * 64; q0 < r0 + nbulk; q0 += 256) {
+    u32x4 raw[UPP];
+#pragma unroll
+    for (int j = 0; j < UPP; ++j) raw[j] = *reinterpret_cast<const u32x4*>(yb + (size_t)(q0 + j * GP + gl) * C0);
+#pragma unroll
+    for (int j = 0; j < UPP; ++j) {
+      alignas(16) T v[EPU];
+      *reinterpret_cast<u32x4*>(v) = raw[j];
+      float acc[K1];
+#pragma unroll
+      for (int k = 0; k < K1; ++k) acc[k] = 0.f;
+#pragma unroll
+      for (int e = 0; e < EPU; ++e) {
+        float xv = sc[e] * Elem<T>::ld(v + e) + sf[e];
+        xv = xv > 0.f ? xv : xv * slope;
+#pragma unroll
+        for (int k = 0; k < K1; ++k) acc[k] += xv * wr[k][e];
+      }
+      float mine = 0.f;
+#pragma unroll
+      for (int k = 0; k < K1; ++k) { const float t = group_sum<UPP>(acc[k]); mine = (u == k) ? t : mine; }
+      if (u < K1) tb[u * 64 + j * GP + gl] = mine + bu;
+    }
+    float* on = out + (int64_t)n * osn + (int64_t)(q0 + lane) * osp;
+#pragma unroll
+    for (int k = 0; k < K1; ++k) on[k * osk] = tb[k * 64 + lane];
   }
-  if (p < r1) body(*reinterpret_cast<const u32x4*>(yb + (size_t)p * C0), p);
+  for (int p = r0 + nbulk + pl; p < r1; p += LANES) body(*reinterpret_cast<const u32x4*>(yb + (size_t)p * C0), p);
 }
 
 // part: [gridDim.x][K1][C0 + 1] like head_bwd_weight_fast_kernel, with x = lrelu(scale*y + shift) recomputed
@@ -313,12 +343,11 @@ __global__ __launch_bounds__(256) void head_norm_wgrad_kernel(const float* __res
   }
   const T* yb = y + (size_t)n * hw * C0 + u * EPU;
   const float* gb = dl + (int64_t)n * gsn;
-  for (int p = r0 + pl; p < r1; p += LANES) {
+  auto body = [&](const u32x4& raw, const float (&gv)[K1]) {
     alignas(16) T v[EPU];
-    *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(yb + (size_t)p * C0);
-    float gv[K1];
+    *reinterpret_cast<u32x4*>(v) = raw;
 #pragma unroll
-    for (int k = 0; k < K1; ++k) { gv[k] = gb[(int64_t)p * gsp + k * gsk]; bacc[k] += gv[k]; }
+    for (int k = 0; k < K1; ++k) bacc[k] += gv[k];
 #pragma unroll
     for (int e = 0; e < EPU; ++e) {
       float xv = sc[e] * Elem<T>::ld(v + e) + sf[e];
@@ -326,6 +355,25 @@ __global__ __launch_bounds__(256) void head_norm_wgrad_kernel(const float* __res
 #pragma unroll
       for (int k = 0; k < K1; ++k) acc[k][e] += gv[k] * xv;
     }
+  };
+  int p = r0 + pl;
+  for (; p + 3 * LANES < r1; p += 4 * LANES) {  // four pixels' loads in flight per thread
+    u32x4 raw[4];
+    float gv[4][K1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) raw[j] = *reinterpret_cast<const u32x4*>(yb + (size_t)(p + j * LANES) * C0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < K1; ++k) gv[j][k] = gb[(int64_t)(p + j * LANES) * gsp + k * gsk];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) body(raw[j], gv[j]);
+  }
+  for (; p < r1; p += LANES) {
+    float gv[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) gv[k] = gb[(int64_t)p * gsp + k * gsk];
+    body(*reinterpret_cast<const u32x4*>(yb + (size_t)p * C0), gv);
   }
 #pragma unroll
   for (int k = 0; k < K1; ++k) {

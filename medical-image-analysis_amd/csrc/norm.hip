@@ -793,12 +793,9 @@ __global__ __launch_bounds__(256) void colreduce_head_kernel(const float* __rest
   }
   const T* yb = y + (size_t)n * hw * c + ch0;
   const float* gb = dl + (int64_t)n * gsn;
-  for (int r = r0 + pl; r < r1; r += LANES) {
+  auto body = [&](const u32x4& raw, const float (&gv)[K1]) {
     alignas(16) T v[EPU];
-    *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(yb + (size_t)r * c);
-    float gv[K1];
-#pragma unroll
-    for (int k = 0; k < K1; ++k) gv[k] = gb[(int64_t)r * gsp + k * gsk];
+    *reinterpret_cast<u32x4*>(v) = raw;
 #pragma unroll
     for (int e = 0; e < EPU; ++e) {
       const float yv = Elem<T>::ld(v + e);
@@ -808,6 +805,25 @@ __global__ __launch_bounds__(256) void colreduce_head_kernel(const float* __rest
       if (!(sc[e] * yv + sf[e] > 0.f)) g *= slope;
       s1[e] += g; s2[e] += g * (ka[e] * yv + kb[e]);
     }
+  };
+  int r = r0 + pl;
+  for (; r + 3 * LANES < r1; r += 4 * LANES) {  // four pixels' loads in flight per thread (one was 2.3 TB/s on the cfg3 launch)
+    u32x4 raw[4];
+    float gv[4][K1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) raw[j] = *reinterpret_cast<const u32x4*>(yb + (size_t)(r + j * LANES) * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < K1; ++k) gv[j][k] = gb[(int64_t)(r + j * LANES) * gsp + k * gsk];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) body(raw[j], gv[j]);
+  }
+  for (; r < r1; r += LANES) {
+    float gv[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) gv[k] = gb[(int64_t)r * gsp + k * gsk];
+    body(*reinterpret_cast<const u32x4*>(yb + (size_t)r * c), gv);
   }
 #pragma unroll
   for (int e = 0; e < EPU; ++e) { sh[0][pl][u * EPU + e] = s1[e]; sh[1][pl][u * EPU + e] = s2[e]; }
@@ -847,12 +863,9 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stream_head_kernel(const flo
   }
   const size_t base = (size_t)n * hw * c + (size_t)u * EPU;
   const float* gb = dl + (int64_t)n * gsn;
-  for (int r = r0 + pl; r < r1; r += lanes) {
+  auto body = [&](const u32x4& raw, const float (&gv)[K1], int r) {
     alignas(16) T yin[EPU]; alignas(16) T out[EPU];
-    *reinterpret_cast<u32x4*>(yin) = *reinterpret_cast<const u32x4*>(y + base + (size_t)r * c);
-    float gv[K1];
-#pragma unroll
-    for (int k = 0; k < K1; ++k) gv[k] = gb[(int64_t)r * gsp + k * gsk];
+    *reinterpret_cast<u32x4*>(yin) = raw;
 #pragma unroll
     for (int e = 0; e < EPU; ++e) {
       const float yv = Elem<T>::ld(yin + e);
@@ -863,6 +876,25 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stream_head_kernel(const flo
       out[e] = Elem<T>::cvt(sc[e] * g + ka[e] * yv + kb[e]);
     }
     *reinterpret_cast<u32x4*>(dy + base + (size_t)r * c) = *reinterpret_cast<const u32x4*>(out);
+  };
+  int r = r0 + pl;
+  for (; r + 3 * lanes < r1; r += 4 * lanes) {  // four pixels' loads in flight per thread
+    u32x4 raw[4];
+    float gv[4][K1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) raw[j] = *reinterpret_cast<const u32x4*>(y + base + (size_t)(r + j * lanes) * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < K1; ++k) gv[j][k] = gb[(int64_t)(r + j * lanes) * gsp + k * gsk];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) body(raw[j], gv[j], r + j * lanes);
+  }
+  for (; r < r1; r += lanes) {
+    float gv[K1];
+#pragma unroll
+    for (int k = 0; k < K1; ++k) gv[k] = gb[(int64_t)r * gsp + k * gsk];
+    body(*reinterpret_cast<const u32x4*>(y + base + (size_t)r * c), gv, r);
   }
 }
 

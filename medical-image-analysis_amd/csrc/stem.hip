@@ -205,9 +205,9 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
 // partial[blk][9][c0] = sum over the block's pixels of x[p + t] * dy[p][co]
 template <typename T, typename TI>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TI* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
-                                                         int slabs, int h, int wd, int c0) {
+                                                         int slabs, int h, int wd, int c0, int win_rows) {
   constexpr int EPU = Elem<T>::EPU;
-  extern __shared__ float red[];  // [lanes][c0 + 1]
+  extern __shared__ float red[];  // [lanes][c0 + 1], then (win_rows > 0) the slab's image window [win_rows][wd + 2]
   const int upp = c0 / EPU, lanes = 256 / upp;
   const int u = threadIdx.x % upp, pl = threadIdx.x / upp;
   const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;  // block = one pixel slab of one image
@@ -217,7 +217,50 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TI* __restrict__ 
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int e = 0; e < EPU; ++e) acc[t][e] = 0.f;
-  if (pl < lanes && r0 + pl < r1) {
+  if (win_rows > 0 && r0 < r1) {
+    // The nine image taps of a pixel come from LDS: the slab's rows (one above, one below, a zero column either side) are
+    // staged once per block, so a tap is a broadcast ds_read with no bounds test.  As nine global loads per pixel group
+    // (eight lanes, same address) the kernel was bound by load-instruction issue: 0.30 ms for the 570 MB it streams.
+    float* win = red + lanes * (c0 + 1);
+    const int wp = wd + 2, py0 = r0 / wd;
+    const TI* img = x + (size_t)n * hw;
+    for (int i = threadIdx.x; i < win_rows * wp; i += 256) {
+      const int wy = i / wp, wx = i - wy * wp;
+      const int yy = py0 - 1 + wy, xx = wx - 1;
+      win[i] = ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)wd) ? Elem<TI>::ld(img + (size_t)yy * wd + xx) : 0.f;
+    }
+    __syncthreads();
+    if (pl < lanes) {
+      const T* grow = dy + ((size_t)n * hw) * c0 + u * EPU;
+      int p = r0 + pl;
+      int py = p / wd, px = p - py * wd;
+      auto body = [&](const u32x4& raw, int wy, int wx) {  // (wy, wx): window coordinates of the pixel's top-left tap
+        alignas(16) T g[EPU];
+        *reinterpret_cast<u32x4*>(g) = raw;
+        float gf[EPU];
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) gf[e] = Elem<T>::ld(g + e);
+        const float* wrow = win + wy * wp + wx;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float xv = wrow[(t / 3) * wp + t % 3];
+#pragma unroll
+          for (int e = 0; e < EPU; ++e) acc[t][e] += xv * gf[e];
+        }
+      };
+      for (; p + lanes < r1; p += 2 * lanes) {  // two dy loads in flight
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(grow + (size_t)p * c0);
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(grow + (size_t)(p + lanes) * c0);
+        body(a0, py - py0, px);
+        px += lanes;
+        while (px >= wd) { px -= wd; ++py; }
+        body(a1, py - py0, px);
+        px += lanes;
+        while (px >= wd) { px -= wd; ++py; }
+      }
+      if (p < r1) body(*reinterpret_cast<const u32x4*>(grow + (size_t)p * c0), py - py0, px);
+    }
+  } else if (pl < lanes && r0 + pl < r1) {
     const TI* img = x + (size_t)n * hw;
     const T* grow = dy + ((size_t)n * hw) * c0 + u * EPU;
     int p = r0 + pl;
@@ -329,8 +372,13 @@ extern "C" int mia_stem_wgrad(const void* x, int x_dtype, const void* dy, int dt
   if (slabs < 1) slabs = 1;
   const int blocks = n * slabs;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t shb = (size_t)lanes * (c0 + 1) * 4;
-#define SW(T, TI) hipLaunchKernelGGL((stem_wgrad_kernel<T, TI>), dim3(blocks), dim3(256), shb, st, static_cast<const TI*>(x), static_cast<const T*>(dy), workspace, slabs, h, wd, c0)
+  size_t shb = (size_t)lanes * (c0 + 1) * 4;
+  // image window in LDS when a slab's rows (+ halo) fit next to the reduction buffer
+  const int64_t per = (hw + slabs - 1) / slabs;
+  int win_rows = (int)((per + wd - 1) / wd) + 3;  // rows a slab can touch (it may start mid-row) + one above and below
+  if ((size_t)win_rows * (wd + 2) * 4 + shb <= 60 * 1024) shb += (size_t)win_rows * (wd + 2) * 4;
+  else win_rows = 0;
+#define SW(T, TI) hipLaunchKernelGGL((stem_wgrad_kernel<T, TI>), dim3(blocks), dim3(256), shb, st, static_cast<const TI*>(x), static_cast<const T*>(dy), workspace, slabs, h, wd, c0, win_rows)
   if (dtype == MIA_BF16 && x_dtype == MIA_F32) SW(bf16_t, float);
   else if (dtype == MIA_BF16) SW(bf16_t, bf16_t);
   else if (x_dtype == MIA_F32) SW(float, float);
