@@ -66,8 +66,11 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
 #define MIA_CONV_G1 5   /* 1x1: ResidualBlock skip conv (blocks.py:147-153) */
 /* Tuning / A-B knobs (process-wide, not part of any reference interface): "conv64" = 1 (default) lets 64 -> 64 channel
  * bf16 3x3 stride-1 launches take the persistent register-weight kernel, 0 sends them through the generic tile kernel;
- * "wgrad_w8" = 1 (default) runs bf16 3x3 stride-1 weight gradients on the two-workgroups-per-CU kernel, 0 on the
- * one-workgroup-per-CU kernel. */
+ * "wgrad_dma" = 1 (default) runs bf16 3x3 stride-1 weight gradients on the LDS-DMA ring kernel; with 0, "wgrad_w8" = 1
+ * (default) picks the register-staged two-workgroups-per-CU kernel ("wgrad_tab": its LDS staging table) and 0 the
+ * one-workgroup-per-CU kernel; "conv_xcd" / "wgrad_xcd" = 1 (default) order the blocks of the bf16 fast kernels so that the
+ * blocks sharing an input tile run on one XCD (0: plain grid order).  Results never depend on a knob beyond fp32 summation
+ * order.  The Python loader applies MIA_OPTIONS="name=value,..." through this call. */
 int mia_set_option(const char* name, int value);
 /* out[p][n] = bias[n] + sum_taps sum_k in[p*s + tap - pad][k] * wpack[tap][n][k].
  * in1|in2 are concatenated along channels (c1 + c2) -- this is how torch.cat([skip, up], 1)

@@ -1124,12 +1124,6 @@ static bool wgrad_two_wg(int mode, int dtype) {
   return on && mode == MODE_W3S1 && dtype == MIA_BF16;
 }
 
-extern "C" int mia_wgrad_dma_occupancy(void) {  // diagnostic: resident workgroups per CU
-  int n = -1;
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_bf16_dma_kernel, 256, 0);
-  return n;
-}
-
 /* split-K workgroups to aim for: one per CU, or two where the kernel is built for two workgroups per CU */
 extern "C" int mia_wgrad_target_blocks(int mode, int dtype) {
   if (wgrad_two_wg(mode, dtype)) return 512;
