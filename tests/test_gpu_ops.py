@@ -566,3 +566,45 @@ def test_plain_block_two_output_gradients_are_summed_on_load(norm, dtype, c):
     tol = 1e-5 if dtype == torch.float32 else 2e-2  # bf16: the reference rounds g1 + g2 to bf16, the kernels sum in fp32
     for a_, b_ in zip(got, want):
         assert relerr(a_, b_) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob", ["conv_xcd", "conv64", "wgrad_xcd", "wgrad_dma"])
+def test_kernel_selection_knobs_do_not_change_results(knob):
+    """mia_set_option knobs pick kernels / block orders only: the forward and input-gradient results are bit-identical either
+    way (same per-element operation order), the weight gradient agrees to fp32 summation order."""
+    import mia_hip
+    from mia_hip import BF16, CONV_G3S1, CONV_T2S2, WGRAD_3S1, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 40, 72, 64, generator=g).to(dev).to(torch.bfloat16)
+    dy = torch.randn(2, 40, 72, 64, generator=g).to(dev).to(torch.bfloat16)
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(dev)
+    wt = (torch.randn(64, 32, 2, 2, generator=g) / 16).to(dev)  # ConvTranspose2d(64 -> 32)
+    b = torch.randn(64, generator=g).to(dev)
+    bt = torch.randn(32, generator=g).to(dev)
+    pc, pct = ops.PackCache(), ops.PackCache()
+    wp, npad, kpad = pc.get(w, BF16, True)
+    wtp, npt, kpt = pct.get(wt, BF16, False)
+    lib = mia_hip.lib()
+
+    def run():
+        y, _, st = ops.conv_mma(CONV_G3S1, x, None, wp, npad, kpad, False, b, 64, (40, 72), want_stats=True)
+        up, _, _ = ops.conv_mma(CONV_T2S2, x, None, wtp, npt, kpt, False, bt, 32, (80, 144))
+        dw = ops.conv_wgrad(WGRAD_3S1, x, None, dy, w.shape, 64, 64)
+        return y.float().clone(), st.sum(1).clone(), up.float().clone(), dw.clone()
+
+    try:
+        lib.mia_set_option(knob.encode(), 1)
+        on = run()
+        lib.mia_set_option(knob.encode(), 0)
+        off = run()
+    finally:
+        lib.mia_set_option(knob.encode(), 1)
+    if knob != "conv64":  # the persistent 64-channel kernel accumulates taps in another order than the tile kernel
+        assert torch.equal(on[0], off[0])
+    else:
+        assert (on[0] - off[0]).abs().max().item() <= 2e-2 * off[0].abs().max().item()
+    assert torch.allclose(on[1], off[1], rtol=1e-4, atol=1e-2)
+    assert torch.equal(on[2], off[2])
+    assert torch.allclose(on[3], off[3], rtol=1e-4, atol=1e-4 * off[3].abs().max().item())
