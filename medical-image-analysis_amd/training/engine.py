@@ -19,6 +19,8 @@ clip_grad_norm_(10), optimizer step -- but with
 """
 from __future__ import annotations
 
+import os
+import time
 from typing import Dict, List, Optional
 
 import torch
@@ -35,7 +37,7 @@ class FlatOptimizer:
     betas=(0.9, 0.999), no lr at construction -> torch default 1e-3 until the scheduler overwrites it)."""
 
     def __init__(self, model: torch.nn.Module, name: str = "adamw", lr: float = 1e-3, weight_decay: float = 0.0,
-                 betas=(0.9, 0.999), eps: float = 1e-8, momentum: float = 0.9, bucket_bytes: int = 32 << 20):
+                 betas=(0.9, 0.999), eps: float = 1e-8, momentum: float = 0.9, bucket_bytes: int = 16 << 20):
         if name not in _KIND:
             raise ValueError(f'Optimizer "{name}" not supported')
         self.kind = _KIND[name]
@@ -193,6 +195,7 @@ class GradBucketReducer:
             self.counts[bi] += 1
         self.works = []
         self.handles = []
+        self.trace = [] if os.environ.get("MIA_DP_TRACE") else None
         if self.world > 1:
             for p, bi in zip(opt.params, opt.param_bucket):
                 self.handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
@@ -204,17 +207,27 @@ class GradBucketReducer:
             self.pending[bi] += 1
             if self.pending[bi] == self.counts[bi]:
                 s, e = self.opt.buckets[bi]
+                if self.trace is not None:
+                    self.trace.append((bi, time.perf_counter()))
                 self.works.append(dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         return hook
 
     def start_step(self):
         self.pending = [0] * len(self.pending)
         self.works = []
+        if self.trace is not None:
+            self.trace = [(-1, time.perf_counter())]
 
     def finish(self):
         """Join every in-flight bucket; launch buckets whose hooks never fired (unused parameters)."""
         if self.world == 1:
             return
+        if self.trace is not None and dist.get_rank(self.pg) == 0:
+            # MIA_DP_TRACE=1: host-side issue times of the bucket all-reduces relative to the start of backward -- buckets leave
+            # while backward is still being issued (the collective itself runs on the backend's own stream / thread)
+            t0, tend = self.trace[0][1], time.perf_counter()
+            print("[dp-trace] backward issued in %.2f ms; buckets issued at %s ms (bucket id: offset)" % (
+                1e3 * (tend - t0), ", ".join("%d: %.2f" % (bi, 1e3 * (t - t0)) for bi, t in self.trace[1:])), flush=True)
         for bi, (s, e) in enumerate(self.opt.buckets):
             if self.pending[bi] != self.counts[bi]:
                 self.works.append(dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
@@ -233,7 +246,7 @@ class TrainEngine:
 
     def __init__(self, model, loss_fn, optimizer_name: str = "adam", optimizer_kwargs: Optional[dict] = None,
                  start_lr: float = 1e-3, num_iters: int = 4000, lr_warmup_iter: int = 250, lr_interval: int = 1,
-                 lr_scheduler_name: str = "poly", grad_norm: float = 10.0, process_group=None, bucket_bytes: int = 32 << 20,
+                 lr_scheduler_name: str = "poly", grad_norm: float = 10.0, process_group=None, bucket_bytes: int = 16 << 20,
                  sync_batchnorm: Optional[bool] = None):
         """sync_batchnorm: None (default) = ON whenever the model holds batch-norm blocks and the process group has more
         than one rank, so N ranks x bs reproduce one process at N*bs (`normalization="batch"` is the al_train
