@@ -343,8 +343,11 @@ def _take_colsum(t: torch.Tensor) -> Optional[torch.Tensor]:
     return None
 
 
+_COL_SLABS = int(__import__('os').environ.get('MIA_COL_SLABS', '64'))
+
+
 def _slabs_for(hw: int) -> int:
-    return max(1, min(64, hw // 1024))
+    return max(1, min(_COL_SLABS, hw // 1024))
 
 
 # ------------------------------------------------------------------ Dropout2d masks
