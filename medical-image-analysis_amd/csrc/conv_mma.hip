@@ -292,12 +292,14 @@ static int g_big_tiles = -1;  // MIA_CONV_MT8=1: 32-row tiles for bf16 3x3 s1 (e
 
 extern int g_wgrad_w8, g_wgrad_tab, g_wgrad_dma, g_wgrad_xcd;  // conv_wgrad.hip
 static int g_conv_xcd = 1;  // mia_set_option("conv_xcd", v): XCD-aware block order of the fast kernel (A/B knob)
+static int g_use_bt = 1;  // mia_set_option("conv_bt", v): big-tile LDS-DMA kernel for the wide stride-1 3x3 bf16 convs (A/B knob)
 static int g_use64 = -1;  // MIA_CONV64=0 / mia_set_option("conv64", 0): 64-channel launches take the generic tile kernel (A/B knob)
 
 extern "C" int mia_set_option(const char* name, int value) {
   MIA_CHECK_ARG(name != nullptr, "mia_set_option: null name");
   if (strcmp(name, "conv_xcd") == 0) { g_conv_xcd = value ? 1 : 0; return MIA_OK; }
   if (strcmp(name, "conv64") == 0) { g_use64 = value ? 1 : 0; return MIA_OK; }
+  if (strcmp(name, "conv_bt") == 0) { g_use_bt = value ? 1 : 0; return MIA_OK; }
   if (strcmp(name, "wgrad_xcd") == 0) { g_wgrad_xcd = value ? 1 : 0; return MIA_OK; }
   if (strcmp(name, "wgrad_dma") == 0) { g_wgrad_dma = value ? 1 : 0; return MIA_OK; }
   if (strcmp(name, "wgrad_tab") == 0) { g_wgrad_tab = value ? 1 : 0; return MIA_OK; }
@@ -366,6 +368,7 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
   }
   if (g_use64 < 0) { const char* e = getenv("MIA_CONV64"); g_use64 = (e && e[0] == '0') ? 0 : 1; }
   if (g_use64 && mt == 4 && conv64_eligible(mode, dtype, a)) rc = conv64_launch(a, st);
+  else if (g_use_bt && mt == 4 && conv_bt_eligible(mode, dtype, a)) rc = conv_bt_launch(a, st);
   else if (fast) rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
   else rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);
   if (rc != MIA_OK) return rc;
