@@ -26,6 +26,7 @@
 // Contract (conv_bt_eligible, otherwise conv_mma_fast runs): bf16, MODE_G3S1, Hout > 8, c1 % 32 == 0, c2 in {0, c1},
 // (o1 + o2) % NCH == 0 and o1 % NCH == 0, 16-byte aligned pointers, per-image tensors and the packed weights < 2 GiB.
 #include "conv_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -80,143 +81,197 @@ struct BtGeo {
   static constexpr int WPIECES = 3 * NCH / 16;
   static constexpr int WPW = (WPIECES + 7) / 8;        // pieces per wave and step (padded with a dummy piece)
   static constexpr bool WDUMMY = (WPIECES % 8) != 0;
+  static constexpr int MAXP = WPW + 3;                  // most pieces a wave issues in one step
   static constexpr int RING = 2 * IMG_BYTES;           // byte offset of the weight ring
   static constexpr int DUMP = RING + 3 * SLOT;         // 1 KB target of dummy pieces
-  static constexpr int LDS = DUMP + (WDUMMY ? 1024 : 0);
+  static constexpr int BIAS = DUMP + (WDUMMY ? 1024 : 0);  // bias of the current channel block (1 KB piece)
+  static constexpr int RED = BIAS + 1024;                  // [8 waves][16 NCT channels][2] statistics exchange
+  static constexpr int LDS = RED + 8 * NCT * 16 * 8;
   static_assert((8 / WC) * MT * 16 == TW * TH, "tile = 512 pixels");
+  static_assert(WPW + 3 <= MT + 1, "one piece per MFMA row");
 };
 
 }  // namespace
 
+// Diagnostic build only (-DCONV64_STAMPS, tools/conv64_stamps.py bt): per-wave cycle sums of the phases.  The shipped library
+// executes no stamp.
+#ifdef CONV64_STAMPS
+__device__ unsigned long long conv_bt_dbg[256 * 8 * 8];
+#define BSTAMP(var)                                                                       \
+  do {                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+#define BACC(dst, t1, t0) dst += (t1) - (t0)
+extern "C" int mia_conv_bt_debug_read(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(conv_bt_dbg), sizeof(conv_bt_dbg));
+}
+#else
+#define BSTAMP(var) do { } while (0)
+#define BACC(dst, t1, t0) do { } while (0)
+#endif
+
+// wait until at most N vector-memory operations of this wave are outstanding
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+struct BtWork { int img, ty, tx, n0; };
+
 template <int WC, int NCT, int MT>
-__global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int ptiles, int ptx, int tx32) {
+__global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int ptiles, int tx32, int nwork) {
   using G = BtGeo<WC, NCT, MT>;
   constexpr int NCH = G::NCH, SLOT = G::SLOT, WPW = G::WPW;
+  constexpr int NSTORE = (MT / 2) * NCT;  // tile stores per wave (every wave issues all of them, masked lanes out of range)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[G::LDS];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int q = lane >> 4, n16 = lane & 15;
-  const int pr = pi16(n16);
+  // Every lane-dependent constant below (fragment addresses, DMA lane offsets, store offsets) is RECOMPUTED where it is used
+  // from an opaque copy of the thread id: hipcc otherwise keeps each of them (and their sub-expressions) in a register for
+  // the whole kernel -- at 128 accumulator + 60 fragment registers per lane that spills, and a spill breaks the hand-counted
+  // vmcnt (the build checks for zero scratch).
+  auto lane_id = [&]() __attribute__((always_inline)) -> int {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    return t & 63;
+  };
   const int wc = wave % WC, wp = wave / WC;
   const int wpx = wp & 1, wpy = wp >> 1;
 
-  // ---- block -> (channel block, pixel tile): every XCD (blocks b, b + 8, ...) walks the pixel tiles == xcd (mod 8) with the
-  // channel block as the slow index, so the workgroups resident at one time stream the SAME weight chunks (L2 / MALL hits)
-  const int b = blockIdx.x, slot_id = b >> 3;
-  const int cb = slot_id / ptx;
-  const int tile = (slot_id - cb * ptx) * 8 + (b & 7);
-  if (tile >= ptiles) return;  // uniform
+  // ---- work list: item w = (channel block, pixel tile), channel block slow -- the workgroups resident at one time stream the
+  // SAME weight chunks (one fetch from HBM / MALL, the rest L2 hits); a workgroup walks items b, b + grid, b + 2 grid, ...
   const int per_img = a.tiles_y * tx32;
-  const int img = tile / per_img;
-  const int trem = tile - img * per_img;
-  const int ty = trem / tx32, tx = trem - ty * tx32;
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int n0 = cb * NCH;
+  auto decode = [&](int w) __attribute__((always_inline)) -> BtWork {
+    BtWork t;
+    const int cb = w / ptiles, tile = w - cb * ptiles;
+    t.img = tile / per_img;
+    const int trem = tile - t.img * per_img;
+    t.ty = trem / tx32;
+    t.tx = trem - t.ty * tx32;
+    t.n0 = cb * NCH;
+    return t;
+  };
 
   const int ctot = a.c1 + a.c2, nchunks = ctot >> 5;
   const size_t ipix = (size_t)a.Hin * a.Win;
   const unsigned img_bytes = (unsigned)(ipix * a.c1 * 2);
   const bf16_t* in1 = static_cast<const bf16_t*>(a.in1);
   const bf16_t* in2 = static_cast<const bf16_t*>(a.c2 ? a.in2 : a.in1);
-  const i32x4 rs1 = rsrc_words(in1 + (size_t)img * ipix * a.c1, img_bytes);
-  const i32x4 rs2 = rsrc_words(in2 + (size_t)img * ipix * a.c1, img_bytes);  // c2 == c1 (contract)
   const i32x4 rsw = rsrc_words(a.wp, (unsigned)((size_t)9 * a.npad * a.kpad * 2));
+  const bool has_bias = a.bias != nullptr;  // uniform
+  const i32x4 rsb = rsrc_words(has_bias ? a.bias : (const float*)a.wp, (unsigned)((a.o1 + a.o2) * 4));
 
-  // ---- DMA lane constants.  Image piece k = wave + 8 j covers halo pixels 16 k .. 16 k + 15; lane L = (pixel L >> 2, slot L & 3)
-  unsigned ioff[IPW];
+  // ---- issue state: the tile whose input image is being fetched (the NEXT tile during the last chunk of the current one)
+  i32x4 irs1, irs2;
+  unsigned ioff[IPW];  // image piece k = wave + 8 j covers halo pixels 16 k .. 16 k + 15; lane L = (pixel L >> 2, slot L & 3)
+  auto set_img_state = [&](const BtWork& t) __attribute__((always_inline)) {
+    irs1 = rsrc_words(in1 + (size_t)t.img * ipix * a.c1, img_bytes);
+    irs2 = rsrc_words(in2 + (size_t)t.img * ipix * a.c1, img_bytes);  // c2 == c1 (contract)
+    const int oy0 = t.ty * TH, ox0 = t.tx * TW;
+    // opaque copy of the lane id: hipcc would otherwise hoist the tile-independent parts of the five offsets (row, column,
+    // swizzled chunk of every piece) out of the tile loop and keep them in ~15 registers
+    const int lv = lane_id();
 #pragma unroll
-  for (int j = 0; j < IPW; ++j) {
-    const int p = 16 * (wave + 8 * j) + (lane >> 2);
-    const int row = p / IW, col = p - row * IW;
-    const int gy = oy0 - 1 + row, gx = ox0 - 1 + col;
-    const bool ok = (p < NPIX) & ((unsigned)gy < (unsigned)a.Hin) & ((unsigned)gx < (unsigned)a.Win);
-    const int chunk = (lane & 3) ^ ((col >> 2) & 3);
-    ioff[j] = ok ? (unsigned)(((gy * a.Win + gx) * a.c1 + chunk * 8) * 2) : BT_SENT;
-  }
-  // weight piece i = wave + 8 jj = (tap row ta, 16-channel block j): lane L = (channel L >> 2, slot L & 3)
-  const int hsw = (0x1E >> (2 * ((lane >> 4) & 3))) & 3;  // h = {0, 2, 3, 1}
-  const unsigned wlane = (unsigned)(((lane >> 2) * a.kpad + ((lane & 3) ^ hsw) * 8) * 2);
-  int w_ta[WPW], w_row[WPW];   // uniform: tap row and first weight row (n0 + 16 j) of this wave's pieces
+    for (int j = 0; j < IPW; ++j) {
+      const int p = 16 * (wave + 8 * j) + (lv >> 2);
+      const int row = p / IW, col = p - row * IW;
+      const int gy = oy0 - 1 + row, gx = ox0 - 1 + col;
+      const bool ok = (p < NPIX) & ((unsigned)gy < (unsigned)a.Hin) & ((unsigned)gx < (unsigned)a.Win);
+      const int chunk = (lv & 3) ^ ((col >> 2) & 3);
+      ioff[j] = ok ? (unsigned)(((gy * a.Win + gx) * a.c1 + chunk * 8) * 2) : BT_SENT;
+    }
+  };
+  // weight piece i = wave + 8 jj = (tap row ta, 16-channel block j): lane L = (channel L >> 2, slot L & 3).  wsoff[tb][jj] =
+  // byte offset of the piece's first weight row in the packed tensor [tap][npad][kpad] for the channel block being fetched
+  auto make_wlane = [&]() __attribute__((always_inline)) -> unsigned {
+    const int lane = lane_id();
+    const int hsw = (0x1E >> (2 * ((lane >> 4) & 3))) & 3;  // h = {0, 2, 3, 1}
+    return (unsigned)(((lane >> 2) * a.kpad + ((lane & 3) ^ hsw) * 8) * 2);
+  };
+  unsigned wsoff[3][WPW];
   bool w_ok[WPW];
-#pragma unroll
-  for (int jj = 0; jj < WPW; ++jj) {
-    const int i = wave + 8 * jj;
-    w_ok[jj] = i < G::WPIECES;
-    w_ta[jj] = i / (NCH / 16);
-    w_row[jj] = n0 + 16 * (i - w_ta[jj] * (NCH / 16));
-  }
-  auto issue_w = [&](int chunk, int tb) __attribute__((always_inline)) {
+  auto set_w_state = [&](int n0) __attribute__((always_inline)) {
 #pragma unroll
     for (int jj = 0; jj < WPW; ++jj) {
-      if (!G::WDUMMY || w_ok[jj]) {
-        const int t = w_ta[jj] * 3 + tb;
+      const int i = wave + 8 * jj;
+      w_ok[jj] = i < G::WPIECES;
+      const int ta = i / (NCH / 16), j16 = 16 * (i - ta * (NCH / 16));
+#pragma unroll
+      for (int tb = 0; tb < 3; ++tb) {
+        const int t = ta * 3 + tb;
         const int tw = a.flip ? 8 - t : t;
-        const unsigned soff = (unsigned)(((tw * a.npad + w_row[jj]) * a.kpad + chunk * 32) * 2);
-        dma16(rsw, wlane, __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane(lds0 + G::RING + tb * SLOT + (wave + 8 * jj) * 1024));
-      } else {
-        dma16(rsw, BT_SENT, 0, __builtin_amdgcn_readfirstlane(lds0 + G::DUMP));
+        wsoff[tb][jj] = __builtin_amdgcn_readfirstlane((unsigned)(((tw * a.npad + n0 + j16) * a.kpad) * 2));
       }
     }
   };
-  auto issue_img = [&](int chunk, int j) __attribute__((always_inline)) {
+  auto issue_w1 = [&](unsigned wlane, int chunk, int tb, int jj) __attribute__((always_inline)) {
+    if (!G::WDUMMY || w_ok[jj])
+      dma16(rsw, wlane, wsoff[tb][jj] + (unsigned)(chunk * 64), __builtin_amdgcn_readfirstlane(lds0 + G::RING + tb * SLOT + (wave + 8 * jj) * 1024));
+    else
+      dma16(rsw, BT_SENT, 0, __builtin_amdgcn_readfirstlane(lds0 + G::DUMP));
+  };
+  auto issue_w = [&](int chunk, int tb) __attribute__((always_inline)) {
+    const unsigned wlane = make_wlane();
+#pragma unroll
+    for (int jj = 0; jj < WPW; ++jj) issue_w1(wlane, chunk, tb, jj);
+  };
+  auto issue_img = [&](int chunk, int buf, int j) __attribute__((always_inline)) {
     const int c0 = chunk * 32;
     const bool second = c0 >= a.c1;  // uniform: chunks never straddle the two sources
     const unsigned soff = (unsigned)((second ? c0 - a.c1 : c0) * 2);
-    const unsigned dst = lds0 + (chunk & 1) * IMG_BYTES + (wave + 8 * j) * 1024;
-    dma16(second ? rs2 : rs1, ioff[j], __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane(dst));
+    const unsigned dst = lds0 + buf * IMG_BYTES + (wave + 8 * j) * 1024;
+    dma16(second ? irs2 : irs1, ioff[j], __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane(dst));
+  };
+  // bias of a channel block: NCH floats, lanes 0 .. NCH / 4 - 1 (every wave writes the same bytes; a wave reads them after
+  // its OWN piece has landed)
+  auto issue_bias = [&](int n0) __attribute__((always_inline)) {
+    const int lane = lane_id();
+    const unsigned blane = lane < NCH / 4 ? (unsigned)(lane * 16) : BT_SENT;
+    dma16(rsb, blane, __builtin_amdgcn_readfirstlane((unsigned)(n0 * 4)), __builtin_amdgcn_readfirstlane(lds0 + G::BIAS));
   };
 
-  // ---- fragment read addresses (bytes from the start of LDS)
-  // B (pixels): column n of the MFMA <-> pixel pr of the wave's 16-pixel strip; halo column = 16 wpx + pr + tb, halo row = MT wpy + r
-  unsigned bbase[3];
-#pragma unroll
-  for (int tb = 0; tb < 3; ++tb) {
-    const int col = 16 * wpx + pr + tb;
-    bbase[tb] = (unsigned)(((MT * wpy) * IW + col) * 64 + ((q ^ ((col >> 2) & 3)) * 16));
-  }
-  // A (weights): row m of the MFMA = output channel 16 (NCT wc + ct) + n16
-  const int hrd = (0x1E >> (2 * ((n16 >> 2) & 3))) & 3;
-  const unsigned abase = (unsigned)(G::RING + (wc * NCT * 16 + n16) * 64 + ((q ^ hrd) * 16));
-
-  // ---- accumulators start at the bias (lane: channels 16 ct + 4 q .. + 3 of its wave's channel range)
+  // ---- fragment read addresses (bytes from the start of LDS), computed per step in compute()
+  // B (pixels): column n of the MFMA <-> pixel pi16(n) of the wave's 16-pixel strip; halo column = 16 wpx + pixel + tb, halo row
+  // = MT wpy + r
+  // A (weights): which output channel (within the wave's 16 NCT) row i = n16 of tile ct is.  Even NCT: channel = 32 (ct >> 1) +
+  // 8 (i >> 2) + 4 (ct & 1) + (i & 3), so a lane's accumulators of the tile pair (2 k, 2 k + 1) are EIGHT consecutive channels
+  // of its pixel = one 16-byte store, and the four lanes of a pixel write 64 contiguous bytes.  Odd NCT: channel = 16 ct + i
+  // (four consecutive channels per tile; rows are paired by v_permlane16_swap in the epilogue).
+  constexpr bool PAIRCT = (NCT % 2) == 0;
+  auto ch_local = [&](int ct, int i) __attribute__((always_inline)) -> int {
+    return PAIRCT ? 32 * (ct >> 1) + 8 * (i >> 2) + 4 * (ct & 1) + (i & 3) : 16 * ct + i;
+  };
   f32x4 acc[MT][NCT];
-  {
-    f32x4 bv[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[ct][r] = a.bias ? a.bias[n0 + (wc * NCT + ct) * 16 + 4 * q + r] : 0.f;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) acc[m][ct] = bv[ct];
-  }
-  // the bias loads are the only compiler-visible vector-memory loads before the epilogue: retire them here so that no
-  // compiler-inserted wait lands inside the counted DMA pipeline
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-  // ---- prologue: image of chunk 0 and the weights of steps 0 and 1
-#pragma unroll
-  for (int j = 0; j < IPW; ++j) issue_img(0, j);
-  issue_w(0, 0);
-  issue_w(0, 1);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-  __builtin_amdgcn_s_barrier();
-
-  auto compute = [&](auto tbc, unsigned imgoff) __attribute__((always_inline)) {
+  // one step: fragment reads + MFMAs of tap column tb; piece(k) (k = 0 .. 5) issues the k-th LDS-DMA piece of the step, placed
+  // behind the MFMAs of row k + 1 so that its scalar work and issue slot hide under the matrix pipe
+  // fin = the last step of a tile: every piece is issued behind row 1 (so that all of them are OLDER than the tile stores) and
+  // fin_row(m) runs as soon as output row m is complete (behind the MFMAs of input row m + 2)
+  auto compute = [&](auto tbc, auto finc, unsigned imgoff, auto&& piece, auto&& fin_row) __attribute__((always_inline)) {
     constexpr int tb = decltype(tbc)::value;
-    // opaque copies: hipcc would otherwise hoist one address register per (ta, ct) fragment out of the chunk loop (36 VGPRs)
-    // instead of folding the constants into the ds_read offset fields
-    unsigned ab = abase, bb = bbase[tb] + imgoff;
-    asm volatile("" : "+v"(ab), "+v"(bb));
-    const unsigned char* ap = smem + ab + tb * SLOT;
+    constexpr bool fin = decltype(finc)::value;
+    const int lane = lane_id(), q = lane >> 4, n16 = lane & 15;
+    const int col = 16 * wpx + pi16(n16) + tb;
+    unsigned bb = (unsigned)(((MT * wpy) * IW + col) * 64 + ((q ^ ((col >> 2) & 3)) * 16)) + imgoff;
+    unsigned ab[2];  // weight rows of this lane in the even / odd channel tiles
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int chl = ch_local(par, n16);
+      const int hrd = (0x1E >> (2 * ((chl >> 2) & 3))) & 3;
+      ab[par] = (unsigned)(G::RING + tb * SLOT + (wc * NCT * 16 + chl) * 64 + ((q ^ hrd) * 16));
+    }
+    // opaque: the constants below must fold into the ds_read offset fields, not into one hoisted register per fragment
+    asm volatile("" : "+v"(ab[0]), "+v"(ab[1]), "+v"(bb));
+    const unsigned char* ap0 = smem + ab[0];
+    const unsigned char* ap1 = smem + ab[1];
     const unsigned char* bp = smem + bb;
     u32x4 wf[3][NCT], fr[3];
     auto load_w = [&](int ta) __attribute__((always_inline)) {
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) wf[ta][ct] = *reinterpret_cast<const u32x4*>(ap + (ta * NCH + ct * 16) * 64);
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int step = (PAIRCT ? 32 * (ct >> 1) : 16 * (ct & ~1)) * 64;  // bytes from tile (ct & 1) to tile ct
+        wf[ta][ct] = *reinterpret_cast<const u32x4*>(((ct & 1) ? ap1 : ap0) + ta * NCH * 64 + step);
+      }
     };
     auto load_row = [&](int r) __attribute__((always_inline)) { fr[r % 3] = *reinterpret_cast<const u32x4*>(bp + r * ROW_BYTES); };
     load_w(0); load_row(0);
@@ -238,73 +293,110 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (tb == 2) {  // only W pieces in this step
+        if (fin) {
+          if (r == 1) {
+#pragma unroll
+            for (int k = 0; k < WPW; ++k) piece(k);
+          }
+          if (r >= 2) fin_row(r - 2);
+        } else if (r >= 1 && r - 1 < WPW) {
+          piece(r - 1);
+        }
+      } else if (r >= 1 && r - 1 < G::MAXP) {
+        piece(r - 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   using TB0 = std::integral_constant<int, 0>;
   using TB1 = std::integral_constant<int, 1>;
   using TB2 = std::integral_constant<int, 2>;
 
-  for (int c = 0; c < nchunks; ++c) {
-    const bool more = c + 1 < nchunks;  // uniform
-    const unsigned imgoff = (c & 1) * IMG_BYTES;
-    // step (c, 0): issue W(c, 2) and the first three image pieces of chunk c + 1
-    issue_w(c, 2);
-    if (more) { issue_img(c + 1, 0); issue_img(c + 1, 1); issue_img(c + 1, 2); }
-    compute(TB0{}, imgoff);
-    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 3) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-    __builtin_amdgcn_s_barrier();
-    // step (c, 1): issue W(c + 1, 0) and the last two image pieces
-    if (more) { issue_w(c + 1, 0); issue_img(c + 1, 3); issue_img(c + 1, 4); }
-    compute(TB1{}, imgoff);
-    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 2) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // step (c, 2): issue W(c + 1, 1)
-    if (more) issue_w(c + 1, 1);
-    compute(TB2{}, imgoff);
-    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-
-  // ---- epilogue: statistics partials + 16-byte stores straight from the accumulators
+  // ---- output of one tile.  store_row(m): 16-byte stores of output row m straight from the accumulators (called from the final
+  // step as rows complete, so the ~70 cycles the texture path spends on every store instruction overlap the remaining MFMAs
+  // and the statistics below).  The accumulators are left intact.
   const int nout = a.o1 + a.o2;
-  const bool to2 = n0 >= a.o1;  // uniform: a channel block lies in one destination (contract)
-  const int cn = to2 ? a.o2 : a.o1;
-  const int nloc = (to2 ? n0 - a.o1 : n0) + wc * NCT * 16;
-  bf16_t* obase_p = static_cast<bf16_t*>(to2 ? a.out2 : a.out1);
-  const size_t opix = (size_t)a.Hout * a.Wout;
-  const rsrc_t rso = make_rsrc(obase_p + (size_t)img * opix * cn, (unsigned)(opix * cn * 2));
-  const int wy0 = oy0 + MT * wpy, wx = ox0 + 16 * wpx + pr;  // first output row of the wave, this lane's output column
-  const bool colok = wx < a.Wout;
-  const bool full = (oy0 + TH <= a.Hout) && (ox0 + TW <= a.Wout);  // uniform
-
-  if (a.stats != nullptr) {
-    float* red = reinterpret_cast<float*>(smem);  // [wave][16 NCT channels][2]; the K loop's last barrier has passed
+  struct OutState { rsrc_t rso; unsigned obase; int row_bytes, wy0; bool colok, full; };
+  auto out_state = [&](const BtWork& t) __attribute__((always_inline)) -> OutState {
+    OutState o;
+    const int oy0 = t.ty * TH, ox0 = t.tx * TW;
+    const bool to2 = t.n0 >= a.o1;  // uniform: a channel block lies in one destination (contract)
+    const int cn = to2 ? a.o2 : a.o1;
+    const int nloc = (to2 ? t.n0 - a.o1 : t.n0) + wc * NCT * 16;
+    bf16_t* obase_p = static_cast<bf16_t*>(to2 ? a.out2 : a.out1);
+    const size_t opix = (size_t)a.Hout * a.Wout;
+    o.rso = make_rsrc(obase_p + (size_t)t.img * opix * cn, (unsigned)(opix * cn * 2));
+    o.wy0 = oy0 + MT * wpy;
+    const int lane = lane_id(), lq = lane >> 4;
+    const int wx = ox0 + 16 * wpx + pi16(lane & 15);  // this lane's output column
+    o.colok = wx < a.Wout;
+    o.full = (oy0 + TH <= a.Hout) && (ox0 + TW <= a.Wout);  // uniform
+    o.row_bytes = a.Wout * cn * 2;
+    if (PAIRCT) o.obase = (unsigned)(((o.wy0 * a.Wout) + wx) * cn * 2 + (nloc + 8 * lq) * 2);
+    else o.obase = (unsigned)((((o.wy0 + (lq & 1)) * a.Wout) + wx) * cn * 2 + (nloc + 8 * (lq >> 1)) * 2);
+    return o;
+  };
+  auto store_row = [&](const OutState& o, int m) __attribute__((always_inline)) {
+    if constexpr (PAIRCT) {
+      // a lane's tile pair (2 k, 2 k + 1) = channels 32 k + 8 q .. + 7 of its pixel: one 16-byte store per row and pair
+#pragma unroll
+      for (int k = 0; k < NCT / 2; ++k) {
+        const u32x4 d = {pack_bf16x2(acc[m][2 * k][0], acc[m][2 * k][1]), pack_bf16x2(acc[m][2 * k][2], acc[m][2 * k][3]),
+                         pack_bf16x2(acc[m][2 * k + 1][0], acc[m][2 * k + 1][1]), pack_bf16x2(acc[m][2 * k + 1][2], acc[m][2 * k + 1][3])};
+        const bool ok = o.full || (o.colok && (o.wy0 + m < a.Hout));
+        const unsigned voff = ok ? o.obase + (unsigned)(m * o.row_bytes + k * 64) : BT_SENT;
+        __builtin_amdgcn_raw_buffer_store_b128(d, o.rso, (int)voff, 0, 0);
+      }
+    } else {
+      if (m & 1) {  // rows are stored in pairs (m - 1, m): v_permlane16_swap trades the 8-byte halves of the lane pairs (q, q ^ 1)
+        const int qodd = (lane_id() >> 4) & 1;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const unsigned x0 = pack_bf16x2(acc[m - 1][ct][0], acc[m - 1][ct][1]), x1 = pack_bf16x2(acc[m - 1][ct][2], acc[m - 1][ct][3]);
+          const unsigned y0 = pack_bf16x2(acc[m][ct][0], acc[m][ct][1]), y1 = pack_bf16x2(acc[m][ct][2], acc[m][ct][3]);
+          // even q gets its partner's row-(m-1) half (8 consecutive channels), odd q the same 8 channels of row m
+          const auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+          const auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+          const u32x4 d = {r0[0], r1[0], r0[1], r1[1]};
+          const bool ok = o.full || (o.colok && (o.wy0 + m - 1 + qodd < a.Hout));
+          const unsigned voff = ok ? o.obase + (unsigned)((m - 1) * o.row_bytes + ct * 32) : BT_SENT;
+          __builtin_amdgcn_raw_buffer_store_b128(d, o.rso, (int)voff, 0, 0);
+        }
+      }
+    }
+  };
+  // statistics partials of the tile (after its last step): per-channel sum and sum of squares over the valid pixels
+  auto tile_stats = [&](const BtWork& t, const OutState& o) __attribute__((always_inline)) {
+    float* red = reinterpret_cast<float*>(smem + G::RED);  // [wave][16 NCT channels][2]
+    const int lane = lane_id(), q = lane >> 4, n16 = lane & 15;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      if (o.full) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const float wgt = (full || (colok && wy0 + m < a.Hout)) ? 1.f : 0.f;
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = acc[m][ct][r], vm = v * wgt;
-          s1[r] += vm; s2[r] += vm * v;
+          for (int r = 0; r < 4; ++r) { const float v = acc[m][ct][r]; s1[r] += v; s2[r] += v * v; }
+      } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float wgt = (o.colok && o.wy0 + m < a.Hout) ? 1.f : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = acc[m][ct][r], vm = v * wgt; s1[r] += vm; s2[r] += vm * v; }
         }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
       if (n16 == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          red[(wave * NCT * 16 + ct * 16 + 4 * q + r) * 2 + 0] = s1[r];
-          red[(wave * NCT * 16 + ct * 16 + 4 * q + r) * 2 + 1] = s2[r];
-        }
+        const int chl = ch_local(ct, 4 * q);
+        *reinterpret_cast<f32x4*>(red + (wave * NCT * 16 + chl) * 2) = f32x4{s1[0], s2[0], s1[1], s2[1]};
+        *reinterpret_cast<f32x4*>(red + (wave * NCT * 16 + chl + 2) * 2) = f32x4{s1[2], s2[2], s1[3], s2[3]};
       }
     }
-    __syncthreads();
+    // raw barrier (no fence): __syncthreads() would make hipcc drain the vector-memory queue, i.e. the prefetched DMA
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     // one 16 x 16 statistics tile per x strip: sum the waves stacked in y (same strip, same channel group)
     constexpr int NWY = (8 / WC) / 2;
     constexpr int ENT = 2 * NCH;  // (strip, channel) entries of the workgroup
@@ -315,35 +407,130 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
 #pragma unroll
       for (int y = 0; y < NWY; ++y) {
         const int w = (2 * y + strip) * WC + wcc;
-        t1 += red[(w * NCT * 16 + chl) * 2 + 0];
-        t2 += red[(w * NCT * 16 + chl) * 2 + 1];
+        const f32x2_t v = *reinterpret_cast<const f32x2_t*>(red + (w * NCT * 16 + chl) * 2);
+        t1 += v[0]; t2 += v[1];
       }
-      const int stx = 2 * tx + strip;
+      const int stx = 2 * t.tx + strip;
       if (stx < a.tiles_x) {
-        const size_t st = ((size_t)img * a.tiles_y + ty) * a.tiles_x + stx;
-        float* dst = a.stats + (st * nout + n0 + ch) * 2;
-        dst[0] = t1; dst[1] = t2;
+        const size_t st = ((size_t)t.img * a.tiles_y + t.ty) * a.tiles_x + stx;
+        typedef __attribute__((address_space(1))) f32x2_t gf32x2;  // global (not flat) store: see conv_mma_fast.hip
+        *(gf32x2*)(a.stats + (st * nout + t.n0 + ch) * 2) = f32x2_t{t1, t2};
       }
     }
-  }
-
-  const int qodd = q & 1;
-  const int row_bytes = a.Wout * cn * 2;
-  const unsigned obase = (unsigned)((((wy0 + qodd) * a.Wout) + wx) * cn * 2 + (nloc + 8 * (q >> 1)) * 2);
+  };
+  // accumulators of a new tile = the bias of the channel block (LDS copy fetched with the tile's first pieces)
+  auto init_acc = [&]() __attribute__((always_inline)) {
+    const int q = lane_id() >> 4;
 #pragma unroll
-  for (int ct = 0; ct < NCT; ++ct) {
+    for (int ct = 0; ct < NCT; ++ct) {
+      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (has_bias) bv = *reinterpret_cast<const f32x4*>(smem + G::BIAS + (wc * NCT * 16 + ch_local(ct, 4 * q)) * 4);
 #pragma unroll
-    for (int m = 0; m < MT; m += 2) {
-      const unsigned x0 = pack_bf16x2(acc[m][ct][0], acc[m][ct][1]), x1 = pack_bf16x2(acc[m][ct][2], acc[m][ct][3]);
-      const unsigned y0 = pack_bf16x2(acc[m + 1][ct][0], acc[m + 1][ct][1]), y1 = pack_bf16x2(acc[m + 1][ct][2], acc[m + 1][ct][3]);
-      // even q gets its partner's row-m half (8 consecutive channels of row m), odd q the same 8 channels of row m + 1
-      const auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-      const auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-      const u32x4 d = {r0[0], r1[0], r0[1], r1[1]};
-      const bool ok = full || (colok && (wy0 + m + qodd < a.Hout));
-      const unsigned voff = ok ? obase + (unsigned)(m * row_bytes + ct * 32) : BT_SENT;
-      __builtin_amdgcn_raw_buffer_store_b128(d, rso, (int)voff, 0, 0);
+      for (int m = 0; m < MT; ++m) acc[m][ct] = bv;
     }
+  };
+
+  // ---- prologue of the workgroup: image of chunk 0, bias and the weights of steps 0 and 1 of its first item
+  int w = blockIdx.x;
+  BtWork cur = decode(w);
+  set_img_state(cur);
+  set_w_state(cur.n0);
+  int gchunk = 0;     // chunks issued so far: image buffer = parity
+#pragma unroll
+  for (int j = 0; j < IPW; ++j) issue_img(0, 0, j);
+  if (has_bias) issue_bias(cur.n0);
+  issue_w(0, 0);
+  issue_w(0, 1);
+  wait_vm<WPW>();
+  __builtin_amdgcn_s_barrier();
+
+#ifdef CONV64_STAMPS
+  unsigned long long z0 = 0, z1 = 0, z3 = 0, z4 = 0, d_cmp = 0, d_wait = 0, d_bar = 0, d_epi = 0, d_prep = 0, d_fin = 0, d_steps = 0, d_tiles = 0;
+#endif
+  auto no_row = [&](int) __attribute__((always_inline)) {};
+  using F = std::false_type;
+  using T = std::true_type;
+  bool first = true;
+  while (true) {
+    const int wnext = w + (int)gridDim.x;
+    const bool has_next = wnext < nwork;  // uniform
+    BtWork nxt = cur;
+    init_acc();
+
+    // one 32-channel chunk = three steps.  LAST = the tile's last chunk: the "following chunk" is chunk 0 of the next item (if
+    // any), the bias of that item rides along, and the final step stores the tile row by row.
+    auto chunk = [&](int c, auto lastc) __attribute__((always_inline)) {
+      constexpr bool last = decltype(lastc)::value;
+      const bool pre = !last || has_next;  // a following chunk exists
+      const int cn = last ? 0 : c + 1;
+      BSTAMP(z0);
+      if (last && has_next) { nxt = decode(wnext); set_img_state(nxt); }
+      BSTAMP(z1); BACC(d_prep, z1, z0);
+      const unsigned imgoff = (gchunk & 1) * IMG_BYTES;
+      const int nbuf = (gchunk + 1) & 1;
+      const unsigned wlane = make_wlane();
+      // step (c, 0): weights of (c, 2); first three image pieces of the following chunk
+      compute(TB0{}, F{}, imgoff, [&](int k) __attribute__((always_inline)) {
+        if (k < WPW) issue_w1(wlane, c, 2, k);
+        else if (pre) issue_img(cn, nbuf, k - WPW);
+      }, no_row);
+      BSTAMP(z3); BACC(d_cmp, z3, z1);
+      // the tile stores of the previous item (issued after everything this step reads) may stay in flight
+      if (c == 0 && !first) { if (pre) wait_vm<WPW + 3 + NSTORE>(); else wait_vm<WPW + NSTORE>(); }
+      else { if (pre) wait_vm<WPW + 3>(); else wait_vm<WPW>(); }
+      BSTAMP(z4); BACC(d_wait, z4, z3);
+      __builtin_amdgcn_s_barrier();
+      BSTAMP(z1); BACC(d_bar, z1, z4);
+      // step (c, 1): weights of (following chunk, 0), last two image pieces; in the last chunk the bias of the next item
+      if (last && has_next && nxt.n0 != cur.n0) set_w_state(nxt.n0);
+      const bool wbias = last && has_next && has_bias;
+      compute(TB1{}, F{}, imgoff, [&](int k) __attribute__((always_inline)) {
+        if (k < WPW) { if (pre) issue_w1(wlane, cn, 0, k); }
+        else if (k < WPW + 2) { if (pre) issue_img(cn, nbuf, 3 + k - WPW); }
+        else if (wbias) issue_bias(nxt.n0);
+      }, no_row);
+      BSTAMP(z3); BACC(d_cmp, z3, z1);
+      if (!pre) wait_vm<0>(); else if (wbias) wait_vm<WPW + 3>(); else wait_vm<WPW + 2>();
+      BSTAMP(z4); BACC(d_wait, z4, z3);
+      __builtin_amdgcn_s_barrier();
+      BSTAMP(z1); BACC(d_bar, z1, z4);
+      // step (c, 2): weights of (following chunk, 1); in the last chunk the tile is stored row by row as its rows complete
+      OutState os;
+      if (last) os = out_state(cur);
+      compute(TB2{}, lastc, imgoff, [&](int k) __attribute__((always_inline)) {
+        if (k < WPW && pre) issue_w1(wlane, cn, 1, k);
+      }, [&](int m) __attribute__((always_inline)) { store_row(os, m); });
+      BSTAMP(z3);
+#ifdef CONV64_STAMPS
+      if (last) d_fin += z3 - z1; else d_cmp += z3 - z1;
+#endif
+      // (last chunk) the tile stores are younger than every piece
+      if (last) { if (pre) wait_vm<WPW + NSTORE>(); else wait_vm<NSTORE>(); }
+      else wait_vm<WPW>();
+      BSTAMP(z4); BACC(d_wait, z4, z3);
+      __builtin_amdgcn_s_barrier();
+      BSTAMP(z1); BACC(d_bar, z1, z4);
+#ifdef CONV64_STAMPS
+      d_steps += 3;
+#endif
+      ++gchunk;
+      if (last) {
+        BSTAMP(z0);
+        if (a.stats != nullptr) tile_stats(cur, os);
+        BSTAMP(z1); BACC(d_epi, z1, z0);
+      }
+    };
+    for (int c = 0; c + 1 < nchunks; ++c) chunk(c, F{});
+    chunk(nchunks - 1, T{});
+#ifdef CONV64_STAMPS
+    d_tiles += 1;
+    if (!has_next && (tid & 63) == 0 && blockIdx.x < 256) {
+      unsigned long long* d = conv_bt_dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+      d[0] = d_fin; d[1] = d_cmp; d[2] = d_wait; d[3] = d_bar; d[4] = d_epi; d[5] = d_prep; d[6] = d_steps; d[7] = d_tiles;
+    }
+#endif
+    if (!has_next) break;
+    cur = nxt; w = wnext; first = false;
   }
 }
 
@@ -368,13 +555,22 @@ bool conv_bt_eligible(int mode, int dtype, const ConvArgs& a) {
   return true;
 }
 
+static int bt_num_cus() {  // one persistent workgroup per CU (device-properties cache: read once)
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
+
 template <int WC, int NCT, int MT>
 static void bt_launch(const ConvArgs& a, int nch, hipStream_t st) {
   const int tx32 = (a.tiles_x + 1) / 2;
   const int ptiles = a.N * a.tiles_y * tx32;
-  const int ptx = (ptiles + 7) / 8;
-  const int nb = (a.o1 + a.o2) / nch;
-  hipLaunchKernelGGL((conv_bt_kernel<WC, NCT, MT>), dim3(8 * ptx * nb), dim3(512), 0, st, a, ptiles, ptx, tx32);
+  const int nwork = ptiles * ((a.o1 + a.o2) / nch);
+  const int ncu = bt_num_cus();
+  hipLaunchKernelGGL((conv_bt_kernel<WC, NCT, MT>), dim3(nwork < ncu ? nwork : ncu), dim3(512), 0, st, a, ptiles, tx32, nwork);
 }
 
 int conv_bt_launch(const ConvArgs& a, hipStream_t st) {

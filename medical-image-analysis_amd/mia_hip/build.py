@@ -11,6 +11,9 @@ CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 LIB = os.path.join(HERE, "libmia_hip.so")
 OBJ = os.path.join(HERE, "_obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
+# Kernels that issue LDS-DMA in inline asm and count `vmcnt` by hand: a register spill would add compiler-made scratch
+# traffic to the same counter and break the count, so the build fails unless their scratch size is 0.
+COUNTED_VMCNT = {"conv_bt.hip": ("conv_bt_kernel",), "conv_wgrad.hip": ("wgrad_bf16_dma_kernel",)}
 
 
 def sources():
@@ -22,6 +25,25 @@ def _stale(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def check_no_scratch(src, remarks, kernels, obj):
+    """Parse hipcc's kernel-resource-usage remarks: every kernel whose mangled name contains one of `kernels` must report
+    `ScratchSize [bytes/lane]: 0` (and must be present at all)."""
+    name, seen = None, set()
+    for line in remarks.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split()[0]
+        elif "ScratchSize" in line and name and any(k in name for k in kernels):
+            seen.add(name)
+            size = int(line.split("ScratchSize [bytes/lane]:")[1].split()[0])
+            if size != 0:
+                if os.path.exists(obj):
+                    os.remove(obj)
+                raise RuntimeError(f"{os.path.basename(src)}: {name} spills {size} bytes/lane to scratch; its hand-counted "
+                                   f"vmcnt pipeline would be wrong")
+    if not seen:
+        raise RuntimeError(f"{os.path.basename(src)}: no resource-usage remark found for {kernels}")
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -37,12 +59,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def cc(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        guarded = COUNTED_VMCNT.get(os.path.basename(s), ())
+        cmd = [hipcc] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if guarded else []) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr}")
+        if guarded:
+            check_no_scratch(s, r.stderr, guarded, o)
         return o
 
     if jobs:

@@ -55,7 +55,48 @@ def wgrad():
     print(f"{'sum':26s} {tot:9.0f}   (tiles per workgroup {n[live].mean():.1f}; MFMA issue floor 144 x 16 = 2304)")
 
 
+def bt():
+    """Phases of the big-tile kernel (conv_bt.hip): python tools/conv64_stamps.py bt [channels]"""
+    os.environ["MIA_HIP_LIB"] = os.path.join(OUT, "libmia_hip_stamps.so")
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import numpy as np
+    import torch
+    import mia_hip
+    from mia_hip import CONV_G3S1, ops
+    dev = torch.device("cuda:0")
+    cs = [int(v) for v in sys.argv[sys.argv.index("bt") + 1:]] or [128, 256, 1024]
+    for c in cs:
+        s = 32768 // c
+        x = torch.randn(32, s, s, c, device=dev).to(torch.bfloat16)
+        w = (torch.randn(c, c, 3, 3, device=dev) / (3 * c ** 0.5))
+        b = torch.randn(c, device=dev)
+        wp, npad, kpad = ops.PackCache().get(w, mia_hip.BF16, True)
+        for _ in range(3):
+            ops.conv_mma(CONV_G3S1, x, None, wp, npad, kpad, False, b, c, (s, s), want_stats=True)
+        torch.cuda.synchronize()
+        l = ctypes.CDLL(os.environ["MIA_HIP_LIB"])
+        buf = np.zeros(256 * 8 * 8, dtype=np.uint64)
+        assert l.mia_conv_bt_debug_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+        d = buf.reshape(256, 8, 8).astype(np.float64)
+        steps, tiles = d[..., 6], d[..., 7]
+        live = steps > 0
+        print(f"--- conv_bt c={c} {s}x{s} x32: steps/wg {steps[live].mean():.0f}, tiles/wg {tiles[live].mean():.1f}  (MFMA floor per step and wave: 96 x 16 = 1536 cycles)")
+        nfin = 3.0 * tiles  # steps that are a tile's final step: 1 per tile (d[6] counts all steps)
+        print(f"{'final step (MFMAs + stores)':26s} {(d[..., 0][live] / tiles[live]).mean():9.0f} cycles / tile / wave   (waves 0-3 {(d[:, :4, 0][live[:, :4]] / tiles[:, :4][live[:, :4]]).mean():.0f}, 4-7 {(d[:, 4:, 0][live[:, 4:]] / tiles[:, 4:][live[:, 4:]]).mean():.0f})")
+        for i, nm in enumerate(["-", "fragment reads + MFMAs", "vmcnt wait", "barrier"]):
+            if i == 0:
+                continue
+            den = steps - (tiles if i == 1 else 0)
+            print(f"{nm:26s} {(d[..., i][live] / den[live]).mean():9.0f} cycles / step / wave   (waves 0-3 {(d[:, :4, i][live[:, :4]] / den[:, :4][live[:, :4]]).mean():.0f}, 4-7 {(d[:, 4:, i][live[:, 4:]] / den[:, 4:][live[:, 4:]]).mean():.0f})")
+        for i, nm in ((4, "statistics epilogue"), (5, "next-tile prep")):
+            print(f"{nm:26s} {(d[..., i][live] / tiles[live]).mean():9.0f} cycles / tile / wave")
+
+
 def main():
+    if "bt" in sys.argv:
+        return bt()
     if "build" in sys.argv:
         print(build())
         return
