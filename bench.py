@@ -210,6 +210,7 @@ def main():
 
     from losses.compound_losses import DiceAndCELoss
     from losses.dice_loss import DiceLoss
+    import mia_hip
     from mia_hip import CONV_G3S1, ops
     from models.unet import UNet
     from training.engine import TrainEngine
@@ -312,7 +313,7 @@ def main():
             abytes = 2.0 * c0 * size * size * batch * esz + 9 * c0 * c0 * esz
             ach = flops / (avg_ms * 1e-3) / 1e12
             traffic = pmc_traffic(args.config, batch, dt)
-            persistent = dt == "bf16" and c0 == 64 and os.environ.get("MIA_CONV64", "1") != "0"
+            persistent = dt == "bf16" and c0 == 64 and mia_hip.get_option("conv64") != 0
             kname = (f"conv64_persist_kernel {c0}->{c0} 3x3 @{size}x{size} x{batch}" if persistent else
                      f"conv_mma_fast_kernel<{dt},G3S1,MT4,NT4> {c0}->{c0} 3x3 @{size}x{size} x{batch}") + " (encoder.levels.0.1 / decoder.levels.3.1)"
             gbs = abytes / (avg_ms * 1e-3) / 1e9

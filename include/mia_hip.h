@@ -64,14 +64,24 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
 #define MIA_CONV_T3S2 3 /* transposed 3x3 s2: strided Conv2d input gradient */
 #define MIA_CONV_T2S2 4 /* transposed 2x2 s2: ConvTranspose2d fwd (unet.py:142, :212) */
 #define MIA_CONV_G1 5   /* 1x1: ResidualBlock skip conv (blocks.py:147-153) */
-/* Tuning / A-B knobs (process-wide, not part of any reference interface): "conv64" = 1 (default) lets 64 -> 64 channel
- * bf16 3x3 stride-1 launches take the persistent register-weight kernel, 0 sends them through the generic tile kernel;
- * "wgrad_dma" = 1 (default) runs bf16 3x3 stride-1 weight gradients on the LDS-DMA ring kernel; with 0, "wgrad_w8" = 1
- * (default) picks the register-staged two-workgroups-per-CU kernel ("wgrad_tab": its LDS staging table) and 0 the
- * one-workgroup-per-CU kernel; "conv_xcd" / "wgrad_xcd" = 1 (default) order the blocks of the bf16 fast kernels so that the
- * blocks sharing an input tile run on one XCD (0: plain grid order).  Results never depend on a knob beyond fp32 summation
- * order.  The Python loader applies MIA_OPTIONS="name=value,..." through this call. */
+/* Library options: kernel-selection / launch-shape knobs for A/B measurements (process-wide, not part of any reference
+ * interface; results never depend on one beyond fp32 summation order).  ONE table (csrc/options.h), each entry read from its
+ * environment variable once at first use, stored in an atomic, changed only by mia_set_option; every entry point takes one
+ * snapshot per call.  Thread-safe.  Names (env var, default):
+ *   conv_bt (MIA_CONV_BT, 1)       wide stride-1 3x3 bf16 convs on the 512-thread big-tile LDS-DMA kernel (0: tile kernel)
+ *   conv64 (MIA_CONV64, 1)         64 -> 64 channel bf16 3x3 stride-1 launches on the persistent register-weight kernel
+ *   conv64_blocks (MIA_CONV64_BLOCKS, 0 = 512)   its workgroup count (diagnostics)
+ *   conv_xcd / wgrad_xcd (MIA_CONV_XCD / MIA_WGRAD_XCD, 1)   blocks sharing an input tile run on one XCD (0: plain grid order)
+ *   conv_mt8 (MIA_CONV_MT8, 0)     32-row tiles of the tile kernel (experiment)
+ *   wgrad_dma (MIA_WGRAD_DMA, 1)   bf16 3x3 stride-1 weight gradients on the LDS-DMA ring kernel; with 0, wgrad_w8
+ *                                  (MIA_WGRAD_W8, 1) picks the register-staged two-workgroups-per-CU kernel (wgrad_tab: its
+ *                                  LDS staging table) and 0 the one-workgroup-per-CU kernel
+ *   stream_blocks (MIA_STREAM_BLOCKS, 32768)   target block count of the norm / activation streaming passes
+ *   stem_mfma (MIA_STEM_MFMA, 1)   matrix-core stem kernel for fp32 images
+ * Do not change wgrad_* between mia_wgrad_geometry and the mia_conv_wgrad it sizes.  The Python loader applies
+ * MIA_OPTIONS="name=value,..." through mia_set_option.  Unknown name: MIA_EARG. */
 int mia_set_option(const char* name, int value);
+int mia_get_option(const char* name, int* value);
 /* out[p][n] = bias[n] + sum_taps sum_k in[p*s + tap - pad][k] * wpack[tap][n][k].
  * in1|in2 are concatenated along channels (c1 + c2) -- this is how torch.cat([skip, up], 1)
  * (unet.py:213) is eliminated; out1|out2 are split along channels (o1 + o2) for its gradient.
@@ -173,8 +183,9 @@ int mia_head_bwd(const float* dlogits, const void* x, int dtype, const float* w,
                            * `const long long*`; same strides as the logits (sn, sk, sp). */
 /* out[0] = ce_w*CE + dice_w*Dice, out[1] = CE (mean over pixels), out[2] = Dice
  * (DiceLoss.forward dice_loss.py:32-76, DiceAndCELoss.forward compound_losses.py:33-49).
- * sums [B][K1][3] = (I, sum p, sum t); coef [B][K1][2] feeds the backward; bad_label = int[2], zero before the first call: [1] = 1 after a call that met a label
- * outside [0,K1) (loss and coef are NaN then), [0] = scratch re-armed by every call. */
+ * sums [B][K1][3] = (I, sum p, sum t); coef [B][K1][2] feeds the backward; bad_label = int[2], zero before the first call: [1] is SET (never
+ * cleared by the library: sticky until the caller zeroes it) by a call that met a label outside [0,K1) (loss and coef of THAT call are
+ * NaN), [0] = scratch re-armed by every call. */
 int mia_dice_ce_workspace(int nb, int k1, int slabs); /* floats */
 int mia_dice_ce_fwd(const float* logits, const long long* labels, int nb, int64_t hw, int k1, int64_t sn, int64_t sk,
                     int64_t sp, int flags, float smooth, float dice_w, float ce_w, int slabs, float* workspace, float* sums,

@@ -323,12 +323,12 @@ bool conv64_eligible(int mode, int dtype, const ConvArgs& a) {
   return true;
 }
 
-int conv64_launch(const ConvArgs& a, hipStream_t st) {
+int conv64_launch(const ConvArgs& a, int blocks_override, hipStream_t st) {
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   const int total = a.N * tiles_per_img;
   // two workgroups per CU (256 CUs); a multiple of 8 so the per-XCD runs tile the step exactly
   int nblk = total < 512 ? ((total + 7) / 8) * 8 : 512;
-  if (const char* e = getenv("MIA_CONV64_BLOCKS")) { const int v = atoi(e); if (v >= 8 && v % 8 == 0 && v <= nblk) nblk = v; }  // diagnostics
+  if (blocks_override >= 8 && blocks_override % 8 == 0 && blocks_override <= nblk) nblk = blocks_override;  // option conv64_blocks (diagnostics)
   const int run = nblk / 8;
   hipLaunchKernelGGL(conv64_persist_kernel, dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, 0);
   if (a.o2 == C)  // second destination (e.g. the up-sampled half of a decoder block's input gradient): same input, next 64 filters

@@ -59,7 +59,7 @@ int conv_mma_fast_launch(int mode, int dtype, const ConvArgs& a, int mt, int nt,
 // conv64.hip: persistent 64 -> 64 channel 3x3 / stride-1 bf16 kernel with register-resident weights (the canonical block
 // launch of the benchmark and its input gradient); false = shape outside its contract.
 bool conv64_eligible(int mode, int dtype, const ConvArgs& a);
-int conv64_launch(const ConvArgs& a, hipStream_t st);
+int conv64_launch(const ConvArgs& a, int blocks_override, hipStream_t st);
 
 // conv_bt.hip: 512-thread "big tile" LDS-DMA kernel for the stride-1 3x3 bf16 convs with >= 64-channel blocks (levels >= 1
 // of the network, the decoder's two-source convs, cfg5's 96-multiples); false = shape outside its contract.

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "conv_common.h"
+#include "options.h"
 
 template <typename T, int MODE, int MT, int NT>
 __global__ __launch_bounds__(256, 2) void conv_mma_kernel(const ConvArgs a) {
@@ -288,32 +289,11 @@ static int dispatch(int mode, const ConvArgs& a, int mt, int nt, int grid_y, hip
 }
 
 // Tile-domain geometry shared with the host (stats buffer sizing): see include/mia_hip.h.
-static int g_big_tiles = -1;  // MIA_CONV_MT8=1: 32-row tiles for bf16 3x3 s1 (experiment knob, default off)
-
-extern int g_wgrad_w8, g_wgrad_tab, g_wgrad_dma, g_wgrad_xcd;  // conv_wgrad.hip
-static int g_conv_xcd = 1;  // mia_set_option("conv_xcd", v): XCD-aware block order of the fast kernel (A/B knob)
-static int g_use_bt = 1;  // mia_set_option("conv_bt", v): big-tile LDS-DMA kernel for the wide stride-1 3x3 bf16 convs (A/B knob)
-static int g_use64 = -1;  // MIA_CONV64=0 / mia_set_option("conv64", 0): 64-channel launches take the generic tile kernel (A/B knob)
-
-extern "C" int mia_set_option(const char* name, int value) {
-  MIA_CHECK_ARG(name != nullptr, "mia_set_option: null name");
-  if (strcmp(name, "conv_xcd") == 0) { g_conv_xcd = value ? 1 : 0; return MIA_OK; }
-  if (strcmp(name, "conv64") == 0) { g_use64 = value ? 1 : 0; return MIA_OK; }
-  if (strcmp(name, "conv_bt") == 0) { g_use_bt = value ? 1 : 0; return MIA_OK; }
-  if (strcmp(name, "wgrad_xcd") == 0) { g_wgrad_xcd = value ? 1 : 0; return MIA_OK; }
-  if (strcmp(name, "wgrad_dma") == 0) { g_wgrad_dma = value ? 1 : 0; return MIA_OK; }
-  if (strcmp(name, "wgrad_tab") == 0) { g_wgrad_tab = value ? 1 : 0; return MIA_OK; }
-  if (strcmp(name, "wgrad_w8") == 0) { g_wgrad_w8 = value ? 1 : 0; return MIA_OK; }
-  mia_set_error("mia_set_option: unknown option '%s'", name);
-  return MIA_EARG;
-}
-
 extern "C" int mia_conv_mma_tiles(int mode, int hout, int wout, int* tiles_y, int* tiles_x, int* tile_h) {
   const bool tmode = (mode == MODE_T3S2 || mode == MODE_T2S2);
   const int hd = tmode ? (hout + 1) / 2 : hout, wd = tmode ? (wout + 1) / 2 : wout;
-  if (g_big_tiles < 0) { const char* e = getenv("MIA_CONV_MT8"); g_big_tiles = (e && e[0] == '1') ? 1 : 0; }
   int mt = (mode == MODE_G3S2 || mode == MODE_G2S2) ? 2 : (hd > 8 ? 4 : 2);
-  if (g_big_tiles && mode == MODE_G3S1 && hd >= 32) mt = 8;
+  if (mia_options().conv_mt8 && mode == MODE_G3S1 && hd >= 32) mt = 8;
   const int th = 4 * mt;
   if (tiles_y) *tiles_y = ceil_div(hd, th);
   if (tiles_x) *tiles_x = ceil_div(wd, 16);
@@ -342,6 +322,7 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
     case MODE_T2S2: ok = (hout == 2 * hin && wout == 2 * win); break;
   }
   MIA_CHECK_ARG(ok, "mia_conv_mma: mode %d shape mismatch in %dx%d out %dx%d", mode, hin, win, hout, wout);
+  const MiaOptions opt = mia_options();  // one snapshot per call
   ConvArgs a;
   a.in1 = in1; a.in2 = in2; a.c1 = c1; a.c2 = c2; a.wp = wpack; a.bias = bias;
   a.out1 = out1; a.out2 = out2; a.o1 = o1; a.o2 = o2; a.stats = stat_partials;
@@ -357,7 +338,7 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
   a.vec_in = (c1 % epu == 0) && (c2 % epu == 0) && al16(in1) && (in2 == nullptr || al16(in2));
   a.vec_out = (o1 % epu == 0) && (o2 % epu == 0) && al16(out1) && (out2 == nullptr || al16(out2));
   const bool tmode = (mode == MODE_T3S2 || mode == MODE_T2S2);
-  a.xcd = g_conv_xcd;
+  a.xcd = opt.conv_xcd;
   const int grid_y = tmode ? 4 : 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;
@@ -366,9 +347,8 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
     mia_set_error("mia_conv_mma: MIA_CONV_MT8 tiles need the bf16 fast path with >= 64 output channels");
     return MIA_EUNSUPPORTED;
   }
-  if (g_use64 < 0) { const char* e = getenv("MIA_CONV64"); g_use64 = (e && e[0] == '0') ? 0 : 1; }
-  if (g_use64 && mt == 4 && conv64_eligible(mode, dtype, a)) rc = conv64_launch(a, st);
-  else if (g_use_bt && mt == 4 && conv_bt_eligible(mode, dtype, a)) rc = conv_bt_launch(a, st);
+  if (opt.conv64 && mt == 4 && conv64_eligible(mode, dtype, a)) rc = conv64_launch(a, opt.conv64_blocks, st);
+  else if (opt.conv_bt && mt == 4 && conv_bt_eligible(mode, dtype, a)) rc = conv_bt_launch(a, st);
   else if (fast) rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
   else rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);
   if (rc != MIA_OK) return rc;

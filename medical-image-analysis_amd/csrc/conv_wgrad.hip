@@ -17,6 +17,7 @@
 //   MODE_W3S1: 3x3 stride 1 pad 1;  MODE_W3S2: 3x3 stride 2 pad 1;  MODE_W2S2: 2x2 stride 2 pad 0
 //   (MODE_W2S2 is ConvTranspose2d's wgrad with x := grad_output (fine grid), dy := input (coarse)).
 #include "common.h"
+#include "options.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1103,36 +1104,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-int g_wgrad_xcd = 1;   // mia_set_option("wgrad_xcd", v): XCD-aware block order of the bf16 fast kernels
-int g_wgrad_dma = 1;   // mia_set_option("wgrad_dma", v): LDS-DMA ring kernel for the stride-1 3x3 bf16 shape
-int g_wgrad_tab = 1;   // mia_set_option("wgrad_tab", v): A/B switch of the table-driven staging
-int g_wgrad_w8 = -1;  // set through mia_set_option("wgrad_w8", v)
-
 // tile heights (rows of 16 output pixels per split-K step)
-static int wgrad_tile_h(int mode, int dtype, int hy, bool fast) {
+static int wgrad_tile_h(const MiaOptions& o, int mode, int dtype, int hy, bool fast) {
   const int s = mode == MODE_W3S1 ? 1 : 2;
   if (dtype != MIA_BF16) return s == 1 ? 4 : 2;
   (void)hy;  // 16-row tiles measured slower (more VGPRs, partial unroll): 575 vs 621 TFLOP/s at 64ch 512x512
-  if (s == 1 && fast && g_wgrad_dma) return 4;  // wgrad_bf16_dma_kernel
+  if (s == 1 && fast && o.wgrad_dma) return 4;  // wgrad_bf16_dma_kernel
   return s == 1 ? 8 : 4;
 }
 
-static bool wgrad_two_wg(int mode, int dtype) {
-  static int w8 = -1;  // MIA_WGRAD_W8=0 / mia_set_option("wgrad_w8", 0): the one-workgroup-per-CU kernel (A/B knob)
-  if (w8 < 0) { const char* e = getenv("MIA_WGRAD_W8"); w8 = (e && e[0] == '0') ? 0 : 1; }
-  const int on = g_wgrad_w8 >= 0 ? g_wgrad_w8 : w8;
-  return on && mode == MODE_W3S1 && dtype == MIA_BF16;
+static bool wgrad_two_wg(const MiaOptions& o, int mode, int dtype) {  // option wgrad_w8 = 0: the one-workgroup-per-CU kernel (A/B knob)
+  return o.wgrad_w8 && mode == MODE_W3S1 && dtype == MIA_BF16;
 }
 
 /* split-K workgroups to aim for: one per CU, or two where the kernel is built for two workgroups per CU */
 extern "C" int mia_wgrad_target_blocks(int mode, int dtype) {
-  if (wgrad_two_wg(mode, dtype)) return 512;
-  if (mode == MODE_W2S2 && dtype == MIA_BF16 && g_wgrad_w8 != 0) return 512;  // 4 taps: 172 registers, 40 KB LDS -> two workgroups fit a CU
+  const MiaOptions o = mia_options();
+  if (wgrad_two_wg(o, mode, dtype)) return 512;
+  if (mode == MODE_W2S2 && dtype == MIA_BF16 && o.wgrad_w8 != 0) return 512;  // 4 taps: 172 registers, 40 KB LDS -> two workgroups fit a CU
   return 256;
 }
 
 extern "C" int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x) {
-  const int th = wgrad_tile_h(mode, dtype, hy, true);  // the finest tiling any kernel of this mode uses (bounds ksplit)
+  const int th = wgrad_tile_h(mia_options(), mode, dtype, hy, true);  // the finest tiling any kernel of this mode uses (bounds ksplit)
   if (tiles_y) *tiles_y = ceil_div(hy, th);
   if (tiles_x) *tiles_x = ceil_div(wy, 16);
   return MIA_OK;
@@ -1150,6 +1144,7 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   bool ok = mode == MODE_W3S1 ? (hx == hy && wx == wy)
           : mode == MODE_W3S2 ? (hy == (hx + 1) / 2 && wy == (wx + 1) / 2) : (hx == 2 * hy && wx == 2 * wy);
   MIA_CHECK_ARG(ok, "mia_conv_wgrad: mode %d shape mismatch x %dx%d dy %dx%d", mode, hx, wx, hy, wy);
+  const MiaOptions o = mia_options();  // one snapshot per call
   WgArgs a;
   a.x1 = x1; a.x2 = x2; a.c1 = c1; a.c2 = c2; a.dy = dy; a.cdy = cdy; a.slabs = slabs;
   a.N = n; a.Hx = hx; a.Wx = wx; a.Hy = hy; a.Wy = wy; a.npad = npad; a.kpad = kpad; a.ksplit = ksplit;
@@ -1157,7 +1152,7 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vec_x = (c1 % epu == 0) && (c2 % epu == 0) && al16(x1) && (x2 == nullptr || al16(x2));
   a.vec_dy = (cdy % epu == 0) && al16(dy);
-  a.opt = g_wgrad_tab ? 1 : 0;
+  a.opt = o.wgrad_tab ? 1 : 0;
   dim3 grid((npad / 64) * (kpad / 64), ksplit);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t lim = (size_t)1 << 31;
@@ -1166,16 +1161,16 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   dim3 fgrid((npad / 64) * (ceil_div(c1, 64) + ceil_div(c2, 64)), ksplit);
   const bool fast = dtype == MIA_BF16 && chan_ok && (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 2 < lim &&
                     (size_t)hy * wy * cdy * 2 < lim;
-  if (fast && g_wgrad_xcd && ksplit % 8 == 0) {  // bf16 fast kernels: 1-D grid in XCD-aware order (a split count below 8 would leave XCDs idle)
+  if (fast && o.wgrad_xcd && ksplit % 8 == 0) {  // bf16 fast kernels: 1-D grid in XCD-aware order (a split count below 8 would leave XCDs idle)
     a.opt |= 16;
     fgrid = dim3(fgrid.x * (unsigned)(ceil_div(ksplit, 8) * 8), 1);
   }
-  const int th = wgrad_tile_h(mode, dtype, hy, fast);
+  const int th = wgrad_tile_h(o, mode, dtype, hy, fast);
   a.tiles_y = ceil_div(hy, th);
   a.tiles_x = ceil_div(wy, 16);
   if (fast && th == 4 && mode == MODE_W3S1) {
     hipLaunchKernelGGL(wgrad_bf16_dma_kernel, fgrid, dim3(256), 0, st, a);
-  } else if (fast && wgrad_two_wg(mode, dtype)) {  // stride-2 / transposed shapes stay on the one-workgroup-per-CU kernel
+  } else if (fast && wgrad_two_wg(o, mode, dtype)) {  // stride-2 / transposed shapes stay on the one-workgroup-per-CU kernel
     hipLaunchKernelGGL(wgrad_bf16_2wg_kernel<8>, fgrid, dim3(256), 0, st, a);
   } else if (fast) {
     if (mode == MODE_W3S1 && th == 16) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 16>), fgrid, dim3(256), 0, st, a);

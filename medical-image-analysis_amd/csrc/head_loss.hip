@@ -935,12 +935,13 @@ __global__ void dice_ce_finalize_kernel(const float* __restrict__ part, const fl
   // in CrossEntropyLoss).  A device kernel cannot raise, so the result is made unusable instead of silently training on
   // such masks: loss values and the backward coefficients (hence every gradient) become NaN; ops.DiceCEFn.check_labels()
   // turns the flag into an exception at the caller's next host sync.
-  // bad_label[0] is the working flag the pixel kernels raise; it is copied to bad_label[1] (the verdict of THIS forward, read by
-  // check_labels) and re-armed here, so the caller never has to clear it between calls.
+  // bad_label[0] is the working flag the pixel kernels raise; it is OR-ed into bad_label[1] -- the STICKY verdict that
+  // check_labels reads and clears, so a clean forward (validation, a second loss term, a deep-supervision head) between the
+  // offending call and the check cannot erase it -- and re-armed here, so the caller never has to clear it between calls.
   __syncthreads();
   const int bad = bad_label[0];
   __syncthreads();
-  if (threadIdx.x == 0) { bad_label[1] = bad; bad_label[0] = 0; }
+  if (threadIdx.x == 0) { if (bad) bad_label[1] = 1; bad_label[0] = 0; }
   if (bad) {
     const float qn = __builtin_nanf("");
     if (threadIdx.x < 3) out[threadIdx.x] = qn;

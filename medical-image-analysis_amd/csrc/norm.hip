@@ -9,6 +9,7 @@
 // statistics cost no extra pass over the activation; the apply passes are pure HBM streams with
 // 16-byte accesses, reductions use wave shuffles + one LDS hop, and no float atomics are used.
 #include "common.h"
+#include "options.h"
 #include <stdlib.h>
 
 #define NORM_INSTANCE 0
@@ -425,8 +426,7 @@ static void stream_geometry(int n, int64_t hw, int c, int epu, int* slabs, int* 
   // ~32768 blocks in total (swept 1k .. 128k on the cfg3 step, MIA_STREAM_BLOCKS: 4096 -> 32768 blocks = 5.60 -> 5.85 TB/s on
   // the forward apply, 5.39 -> 5.55 on the backward; flat beyond), each lane streaming >= 8 pixels
   const int lanes = 256 / ub;
-  static int target = 0;
-  if (!target) { const char* e = getenv("MIA_STREAM_BLOCKS"); target = e ? atoi(e) : 32768; if (target < 256) target = 32768; }
+  const int target = mia_options().stream_blocks;
   int64_t sl = target / ((int64_t)n * *gy);
   const int64_t maxsl = hw / (lanes * 8) > 0 ? hw / (lanes * 8) : 1;
   if (sl > maxsl) sl = maxsl;

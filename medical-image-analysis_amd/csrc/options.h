@@ -1,0 +1,23 @@
+// Library options (kernel-selection / launch-shape knobs for A/B measurements; never numerics contracts).
+//
+// ONE table, read from the environment ONCE (first use, std::call_once), changed only through mia_set_option; every C-ABI
+// entry point takes ONE snapshot (`const MiaOptions o = mia_options();`) and passes it down, so a call never sees two values
+// of an option.  The fields are atomics: set / get / snapshot are safe from any thread.  Nothing else in the library reads
+// getenv or keeps a lazily-initialised knob.
+#pragma once
+
+struct MiaOptions {
+  int conv_xcd;       // XCD-aware block order of conv_mma_fast_kernel                         env MIA_CONV_XCD      default 1
+  int conv64;         // persistent register-weight kernel for 64 -> 64 3x3 bf16               env MIA_CONV64        default 1
+  int conv_bt;        // big-tile LDS-DMA kernel for the wide stride-1 3x3 bf16 convs          env MIA_CONV_BT       default 1
+  int conv_mt8;       // 32-row tiles of the tile kernel (experiment)                          env MIA_CONV_MT8      default 0
+  int conv64_blocks;  // workgroups of conv64_persist_kernel, 0 = library default (512)        env MIA_CONV64_BLOCKS default 0
+  int wgrad_xcd;      // XCD-aware block order of the bf16 weight-gradient kernels             env MIA_WGRAD_XCD     default 1
+  int wgrad_dma;      // LDS-DMA ring weight-gradient kernel (3x3 stride 1 bf16)               env MIA_WGRAD_DMA     default 1
+  int wgrad_tab;      // table-driven staging of wgrad_bf16_2wg_kernel                         env MIA_WGRAD_TAB     default 1
+  int wgrad_w8;       // two-workgroups-per-CU weight-gradient kernels                         env MIA_WGRAD_W8      default 1
+  int stream_blocks;  // target block count of the norm / activation streaming passes          env MIA_STREAM_BLOCKS default 32768
+  int stem_mfma;      // matrix-core stem kernel for fp32 images                               env MIA_STEM_MFMA     default 1
+};
+
+MiaOptions mia_options();  // consistent snapshot, by value

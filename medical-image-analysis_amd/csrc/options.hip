@@ -1,0 +1,71 @@
+// Option table of libmia_hip (see options.h): environment read once, atomics, mia_set_option / mia_get_option.
+#include "options.h"
+#include "common.h"
+#include <atomic>
+#include <mutex>
+#include <stdlib.h>
+
+namespace {
+
+struct Entry { const char* name; const char* env; int def; int lo; int hi; std::atomic<int> value; };
+
+Entry g_table[] = {
+    {"conv_xcd", "MIA_CONV_XCD", 1, 0, 1, {1}},
+    {"conv64", "MIA_CONV64", 1, 0, 1, {1}},
+    {"conv_bt", "MIA_CONV_BT", 1, 0, 1, {1}},
+    {"conv_mt8", "MIA_CONV_MT8", 0, 0, 1, {0}},
+    {"conv64_blocks", "MIA_CONV64_BLOCKS", 0, 0, 1 << 20, {0}},
+    {"wgrad_xcd", "MIA_WGRAD_XCD", 1, 0, 1, {1}},
+    {"wgrad_dma", "MIA_WGRAD_DMA", 1, 0, 1, {1}},
+    {"wgrad_tab", "MIA_WGRAD_TAB", 1, 0, 1, {1}},
+    {"wgrad_w8", "MIA_WGRAD_W8", 1, 0, 1, {1}},
+    {"stream_blocks", "MIA_STREAM_BLOCKS", 32768, 256, 1 << 24, {32768}},
+    {"stem_mfma", "MIA_STEM_MFMA", 1, 0, 1, {1}},
+};
+constexpr int N_OPT = (int)(sizeof(g_table) / sizeof(g_table[0]));
+std::once_flag g_env_once;
+
+int clampv(const Entry& e, int v) { return v < e.lo ? e.lo : (v > e.hi ? e.hi : v); }
+
+void read_env() {
+  for (int i = 0; i < N_OPT; ++i) {
+    const char* s = getenv(g_table[i].env);
+    if (s && *s) g_table[i].value.store(clampv(g_table[i], atoi(s)), std::memory_order_relaxed);
+  }
+}
+
+Entry* find(const char* name) {
+  std::call_once(g_env_once, read_env);
+  for (int i = 0; i < N_OPT; ++i)
+    if (strcmp(name, g_table[i].name) == 0) return &g_table[i];
+  return nullptr;
+}
+
+int get(int i) { return g_table[i].value.load(std::memory_order_relaxed); }
+
+}  // namespace
+
+MiaOptions mia_options() {
+  std::call_once(g_env_once, read_env);
+  MiaOptions o;
+  o.conv_xcd = get(0); o.conv64 = get(1); o.conv_bt = get(2); o.conv_mt8 = get(3); o.conv64_blocks = get(4);
+  o.wgrad_xcd = get(5); o.wgrad_dma = get(6); o.wgrad_tab = get(7); o.wgrad_w8 = get(8); o.stream_blocks = get(9);
+  o.stem_mfma = get(10);
+  return o;
+}
+
+extern "C" int mia_set_option(const char* name, int value) {
+  MIA_CHECK_ARG(name != nullptr, "mia_set_option: null name");
+  Entry* e = find(name);
+  MIA_CHECK_ARG(e != nullptr, "mia_set_option: unknown option '%s'", name);
+  e->value.store(clampv(*e, value), std::memory_order_relaxed);
+  return MIA_OK;
+}
+
+extern "C" int mia_get_option(const char* name, int* value) {
+  MIA_CHECK_ARG(name != nullptr && value != nullptr, "mia_get_option: null argument");
+  Entry* e = find(name);
+  MIA_CHECK_ARG(e != nullptr, "mia_get_option: unknown option '%s'", name);
+  *value = e->value.load(std::memory_order_relaxed);
+  return MIA_OK;
+}

@@ -8,6 +8,7 @@
 // an LDS reduction.  Weight gradient: dW[co][t] = sum_p x[p+t] * dy[p][co], a 9 x C0 reduction over all
 // pixels, two-stage (block partials, then the generic slab reduce); no float atomics.
 #include "common.h"
+#include "options.h"
 #include <stdlib.h>
 
 template <typename T, typename TI>
@@ -336,8 +337,7 @@ extern "C" int mia_stem_fwd(const void* x, int x_dtype, const float* w, const fl
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(n * STEM_SLABS);
   // fp32 image, channel count a multiple of 16: the matrix-core kernel (exact fp32 arithmetic, HBM-bound)
-  static int use_mfma = -1;
-  if (use_mfma < 0) { const char* e = getenv("MIA_STEM_MFMA"); use_mfma = (e && e[0] == '0') ? 0 : 1; }
+  const int use_mfma = mia_options().stem_mfma;
   const bool al16 = (reinterpret_cast<uintptr_t>(y) & 15) == 0;
   if (use_mfma && x_dtype == MIA_F32 && al16 && (c0 == 16 || c0 == 32 || c0 == 64 || c0 == 96 || c0 == 128) && (int64_t)h * wd * 4 < ((int64_t)1 << 31)) {
 #define SM(T, MT) hipLaunchKernelGGL((stem_fwd_mfma_kernel<T, MT>), grid, dim3(256), 0, st, static_cast<const float*>(x), w, bias, static_cast<T*>(y), h, wd, STEM_SLABS, stat_partials)

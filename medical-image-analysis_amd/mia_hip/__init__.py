@@ -91,6 +91,17 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+def set_option(name: str, value: int) -> None:
+    """Library option (include/mia_hip.h: mia_set_option) -- kernel selection / launch shape for A/B runs, thread-safe."""
+    check(lib().mia_set_option(name.encode(), int(value)), "mia_set_option")
+
+
+def get_option(name: str) -> int:
+    v = ctypes.c_int(0)
+    check(lib().mia_get_option(name.encode(), ctypes.byref(v)), "mia_get_option")
+    return v.value
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().mia_last_error()

@@ -807,12 +807,16 @@ DiceCEFn.last_sums = None
 
 
 def check_labels() -> None:
-    """Raise if the most recent Dice/CE forward met a label outside [0, K1) (host sync: call it where you already sync,
-    e.g. next to the `loss.item()` you log).  The reference raises at that point (scatter index error in
-    `DiceLoss._one_hot_encoder`, dice_loss.py:25-30, and the target bound check of CrossEntropyLoss); the kernels cannot,
-    so they return NaN losses / NaN gradients for such a batch and keep the flag for this check."""
+    """Raise if ANY Dice/CE forward on this device since the previous check met a label outside [0, K1) (host sync: call it
+    where you already sync, e.g. next to the `loss.item()` you log).  The reference raises at the offending call (scatter
+    index error in `DiceLoss._one_hot_encoder`, dice_loss.py:25-30, and the target bound check of CrossEntropyLoss); the
+    kernels cannot, so they return NaN losses / NaN gradients for such a batch and keep a STICKY per-device verdict: a clean
+    forward in between (validation, a second loss term) does not erase it; this call reads it and clears it.
+    Ordering contract: every loss forward whose labels you want checked must have been ISSUED on the current stream before
+    this call; losses running on other streams of the same device share the flag (their verdicts OR together)."""
     bad = DiceCEFn.last_bad_label
     if bad is not None and int(bad[1].item()) != 0:
+        bad[1].zero_()
         raise MiaError("Dice/CE loss: a label lies outside [0, num_classes] (e.g. 255-valued masks or ignore_index -100); "
                        "the reference raises an index error for such targets")
 

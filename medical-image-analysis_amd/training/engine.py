@@ -185,10 +185,14 @@ class FlatOptimizer:
 class GradBucketReducer:
     """Bucketed all-reduce of FlatOptimizer.flat_grad overlapped with backward (one process per GPU)."""
 
-    def __init__(self, opt: FlatOptimizer, process_group=None):
+    def __init__(self, opt: FlatOptimizer, process_group=None, force: bool = False):
+        """force (or MIA_DP_FORCE=1): register the hooks and issue the bucketed all-reduces even when the group has ONE
+        rank -- a sum over one rank is the identity, so results are bit-identical to the reducer-less path, but the whole
+        RCCL branch (ProcessGroupNCCL's stream handshake against the custom kernels' stream) runs on a one-GPU box."""
         self.opt = opt
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force = bool(force or os.environ.get("MIA_DP_FORCE") == "1") and dist.is_initialized()
         self.pending = [0] * len(opt.buckets)
         self.counts = [0] * len(opt.buckets)
         for bi in opt.param_bucket:
@@ -196,7 +200,7 @@ class GradBucketReducer:
         self.works = []
         self.handles = []
         self.trace = [] if os.environ.get("MIA_DP_TRACE") else None
-        if self.world > 1:
+        if self.world > 1 or self.force:
             for p, bi in zip(opt.params, opt.param_bucket):
                 self.handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
 
@@ -220,7 +224,7 @@ class GradBucketReducer:
 
     def finish(self):
         """Join every in-flight bucket; launch buckets whose hooks never fired (unused parameters)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.trace is not None and dist.get_rank(self.pg) == 0:
             # MIA_DP_TRACE=1: host-side issue times of the bucket all-reduces relative to the start of backward -- buckets leave
@@ -247,15 +251,19 @@ class TrainEngine:
     def __init__(self, model, loss_fn, optimizer_name: str = "adam", optimizer_kwargs: Optional[dict] = None,
                  start_lr: float = 1e-3, num_iters: int = 4000, lr_warmup_iter: int = 250, lr_interval: int = 1,
                  lr_scheduler_name: str = "poly", grad_norm: float = 10.0, process_group=None, bucket_bytes: int = 16 << 20,
-                 sync_batchnorm: Optional[bool] = None):
-        """sync_batchnorm: None (default) = ON whenever the model holds batch-norm blocks and the process group has more
+                 sync_batchnorm: Optional[bool] = None, force_reducer: bool = False):
+        """force_reducer: see GradBucketReducer(force=...).
+        sync_batchnorm: None (default) = ON whenever the model holds batch-norm blocks and the process group has more
         than one rank, so N ranks x bs reproduce one process at N*bs (`normalization="batch"` is the al_train
         default, train.py:25); False keeps per-rank statistics (DDP-without-SyncBN behaviour) and says so once."""
         self.model = model
         world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         if world > 1:
-            from models.unet.blocks import PlainBlock, convert_sync_batchnorm
-            has_bn = any(isinstance(m, PlainBlock) and m.normalization == "batch" for m in model.modules())
+            from models.unet.blocks import PlainBlock, ResidualBlock, convert_sync_batchnorm
+            # ResidualBlock counts too: convert_sync_batchnorm raises NotImplementedError for it, which is the honest
+            # answer to "N ranks x bs reproduce one process at N*bs" for that block type (never a silent per-rank fallback)
+            has_bn = any(isinstance(m, (PlainBlock, ResidualBlock)) and getattr(m, "normalization", None) == "batch"
+                         for m in model.modules())
             if has_bn and (sync_batchnorm is None or sync_batchnorm):
                 convert_sync_batchnorm(model, process_group)
             elif has_bn:
@@ -273,7 +281,7 @@ class TrainEngine:
         else:
             raise ValueError(f'Learning rate scheduler "{lr_scheduler_name}" not supported')
         self.grad_norm = grad_norm
-        self.reducer = GradBucketReducer(self.optimizer, process_group)
+        self.reducer = GradBucketReducer(self.optimizer, process_group, force=force_reducer)
         self.current_iter = 0
         self._one = None
 

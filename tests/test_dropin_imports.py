@@ -91,3 +91,25 @@ print(u.__file__); print(d.__file__); print(b.__file__); print(r.__file__)
     lines = r.stdout.strip().splitlines()[-4:]
     assert lines[0].startswith(PKG) and lines[1].startswith(PKG)
     assert lines[2].startswith(REF_SRC) and lines[3].startswith(REF_SRC)
+
+
+def test_decoy_packages_on_the_path_are_not_merged(tmp_path):
+    """A foreign `transforms` / `models` package on sys.path (site-packages, a working directory) must not be merged into the
+    drop-in: only the reference's src/ (marker training/al_trainer.py, or MIA_REFERENCE_SRC) is."""
+    decoy = tmp_path / "decoy"
+    for pkg, mod in (("transforms", "common"), ("models", "_unet"), ("training", "base_trainer")):
+        d = decoy / pkg
+        d.mkdir(parents=True)
+        (d / "__init__.py").write_text("")
+        (d / (mod + ".py")).write_text("DECOY = True\n")
+    names = ["transforms.common", "models._unet", "training.base_trainer", "training.al_trainer"]
+    # decoy in front of the reference on the path (a decoy in the WORKING directory of `python -c` shadows every PYTHONPATH
+    # entry by Python's own rules, before any of this repo's code runs -- not something a package can defend against)
+    got = _resolve(names, [PKG, str(decoy), REF_SRC])
+    assert got["transforms.common"].startswith(REF_SRC + os.sep), got
+    assert got["models._unet"].startswith(REF_SRC + os.sep), got
+    assert got["training.base_trainer"].startswith(REF_SRC + os.sep), got
+    # without the reference, the decoy is still ignored: this repo's alias module serves transforms.common, the others are absent
+    got = _resolve(["transforms.common", "models._unet"], [PKG, str(decoy)])
+    assert got["transforms.common"].startswith(PKG + os.sep), got
+    assert got["models._unet"] is None, got

@@ -398,6 +398,15 @@ def test_out_of_range_label_poisons_loss_and_is_reported(layout):
         assert math.isnan(v.item()) and bool(torch.isnan(logits.grad).any())
         with pytest.raises(mia_hip.MiaError):
             ops.check_labels()
+        ops.check_labels()  # the check clears the verdict it has reported
+    # sticky verdict: a CLEAN forward between the offending one and the check must not erase it
+    lab = labels.clone()
+    lab[0, 3, 3] = 7
+    assert math.isnan(fn(logits, lab).item())
+    assert math.isfinite(fn(logits, labels).item())  # e.g. a validation forward, a second loss term
+    with pytest.raises(mia_hip.MiaError):
+        ops.check_labels()
+    ops.check_labels()
     with pytest.raises(NotImplementedError):
         fn2 = DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss, ce_kwargs=dict(ignore_index=1))
         fn2.get_ce_loss(logits, labels)
@@ -608,3 +617,61 @@ def test_kernel_selection_knobs_do_not_change_results(knob):
     assert torch.allclose(on[1], off[1], rtol=1e-4, atol=1e-2)
     assert torch.equal(on[2], off[2])
     assert torch.allclose(on[3], off[3], rtol=1e-4, atol=1e-4 * off[3].abs().max().item())
+
+
+BT_CASES = [
+    # n, c1, c2, cout, h, w  -- conv_bt.hip: 128 / 96 / 64-channel blocks, ragged 16 x 32 tiles, two sources, two destinations,
+    # one tile per workgroup and several (persistent work list: more items than CUs), maps of one tile row
+    (2, 128, 0, 128, 40, 72), (1, 256, 0, 128, 17, 33), (1, 128, 128, 128, 48, 48), (1, 96, 0, 192, 24, 40),
+    (1, 96, 96, 96, 33, 70), (2, 64, 64, 64, 40, 56), (3, 128, 0, 256, 96, 160), (1, 512, 0, 512, 9, 31),
+    (1, 64, 0, 128, 16, 32), (1, 160, 0, 384, 20, 20),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", BT_CASES)
+def test_conv_bt_matches_tile_kernel_and_reference(case):
+    """The big-tile LDS-DMA kernel (csrc/conv_bt.hip; option conv_bt) against the tile kernel it replaces and against fp32-CPU
+    F.conv2d on shared bf16 operands: forward (+ epilogue statistics) and input gradient (two destinations for two sources).
+    The two kernels differ only by where the bias enters the fp32 sum (first vs last) and the final bf16 rounding."""
+    import mia_hip
+    from mia_hip import BF16, CONV_G3S1, ops
+    dev = _dev()
+    n, c1, c2, cout, h, w = case
+    cin = c1 + c2
+    g = torch.Generator().manual_seed(c1 * 7 + cout + h)
+    x = q(torch.randn(n, cin, h, w, generator=g), torch.bfloat16)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    dy = q(torch.randn(n, cout, h, w, generator=g), torch.bfloat16)
+    xr, wr = x.clone().requires_grad_(True), q(wt, torch.bfloat16).clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b, padding=1)
+    yr.backward(dy)
+    x1 = nhwc(x[:, :c1], torch.bfloat16, dev)
+    x2 = nhwc(x[:, c1:], torch.bfloat16, dev) if c2 else None
+    dyd = nhwc(dy, torch.bfloat16, dev)
+    pc = ops.PackCache()
+    wp, npad, kpad = pc.get(wt.to(dev), BF16, True)
+    wb, npb, kpb = pc.get(wt.to(dev), BF16, False)
+
+    def run():
+        y, _, st = ops.conv_mma(CONV_G3S1, x1, x2, wp, npad, kpad, False, b.to(dev), cout, (h, w), want_stats=True)
+        dx1, dx2, dst = ops.conv_mma(CONV_G3S1, dyd, None, wb, npb, kpb, True, None, cin, (h, w), want_stats=True,
+                                     out_split=c1 if c2 else None)
+        dx = nchw(dx1) if dx2 is None else torch.cat([nchw(dx1), nchw(dx2)], 1)
+        return nchw(y), st.sum(1).cpu(), dx, dst.sum(1).cpu()
+
+    try:
+        mia_hip.set_option("conv_bt", 1)
+        on = run()
+        mia_hip.set_option("conv_bt", 0)
+        off = run()
+    finally:
+        mia_hip.set_option("conv_bt", 1)
+    assert relerr(on[0], yr) < 6e-3 and relerr(on[2], xr.grad) < 6e-3
+    assert relerr(on[1][..., 0], yr.detach().sum((2, 3))) < 1e-3 and relerr(on[1][..., 1], (yr.detach() ** 2).sum((2, 3))) < 1e-3
+    assert relerr(on[3][..., 0], xr.grad.sum((2, 3))) < 2e-3
+    # kernel vs kernel: at most one bf16 rounding step apart (2^-8 relative per element), statistics to fp32 summation order
+    assert (on[0] - off[0]).abs().max().item() <= 2 ** -7 * off[0].abs().max().item()
+    assert (on[2] - off[2]).abs().max().item() <= 2 ** -7 * off[2].abs().max().item()
+    assert torch.allclose(on[1], off[1], rtol=1e-4, atol=1e-3 * off[1].abs().max().item())
