@@ -160,6 +160,67 @@ def parity_gate_benchmarked(dev, channels, dt):
             "ok": bool(err < tol and mism == 0)}
 
 
+def ellipse_set(n, s, seed=1337):
+    """Learnable synthetic set: images whose intensity follows two nested ellipses (classes 1, 2) + noise."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(s), torch.arange(s), indexing="ij")
+    img = torch.zeros(n, 1, s, s)
+    lab = torch.zeros(n, s, s, dtype=torch.long)
+    for i in range(n):
+        cy, cx, ry, rx = (torch.rand(4, generator=g) * torch.tensor([s / 2, s / 2, s / 6, s / 6]) +
+                          torch.tensor([s / 4, s / 4, s / 10, s / 10])).tolist()
+        m1 = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1
+        m2 = ((yy - cy - 0.6 * ry) / (0.5 * ry)) ** 2 + ((xx - cx) / (0.5 * rx)) ** 2 < 1
+        lab[i][m1] = 1
+        lab[i][m2] = 2
+        img[i, 0] = 0.25 + 0.35 * m1.float() + 0.3 * m2.float() + 0.08 * torch.randn(s, s, generator=g)
+    return img.clamp(0, 1), lab
+
+
+def parity_gate_trained(dev, channels, dt, steps=60, size=128, nimg=16, batch=8, neval=4):
+    """Dice gate on a TRAINED net (north_star: "Dice within ... of CPU reference"; a random-init net's label maps sit on
+    near-ties and say little): train the benchmarked widths `steps` engine steps in the benchmarked compute dtype on a small
+    learnable set, then compare the eval-mode label maps of the HIP path with the fp32 CPU oracle run on the SAME trained
+    weights, per class (medpy-form hard Dice, al_trainer.py:1539-1556), and both against the ground truth.  Reported, not
+    timed; tests/test_gpu_configs.py asserts on the same record."""
+    from losses.compound_losses import DiceAndCELoss
+    from models.unet import UNet
+    from oracle import losses_ref, unet_ref
+    from training.engine import TrainEngine
+    torch.manual_seed(1337)
+    model = UNet(2, 1, 3, channels, normalization="instance", dropout_prob=None).to(dev)
+    model.set_compute_dtype(torch.bfloat16 if dt == "bf16" else torch.float32)
+    loss_fn = DiceAndCELoss(dice_kwargs=dict(num_classes=2, smooth=1e-5, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss)
+    eng = TrainEngine(model, loss_fn, "adam", {"weight_decay": 5e-4}, start_lr=1e-3, num_iters=steps, lr_warmup_iter=max(1, steps // 10))
+    img, lab = ellipse_set(nimg, size)
+    gi, gl = img.to(dev), lab.to(dev)
+    g = torch.Generator().manual_seed(7)
+    first = last = None
+    for it in range(steps):
+        idx = torch.randperm(nimg, generator=g)[:batch].to(dev)
+        loss = eng.train_step({"image": gi[idx], "label": gl[idx]})
+        if it == 0:
+            first = loss.item()
+    last = loss.item()
+    model.eval()
+    with torch.no_grad():
+        out = model(gi[:neval]).float().cpu()
+        params = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        ref = unet_ref.unet_forward(params, img[:neval], "instance", False)
+    pg, pc = out.argmax(1), ref.argmax(1)
+    vs_cpu = [losses_ref.hard_dice(pg == k, pc == k) if (pc == k).any() else 1.0 for k in range(3)]
+    gt_gpu = [losses_ref.hard_dice(pg == k, lab[:neval] == k) for k in (1, 2)]
+    gt_cpu = [losses_ref.hard_dice(pc == k, lab[:neval] == k) for k in (1, 2)]
+    rng = float(ref.max() - ref.min())
+    return {"config": f"UNet {channels} {size}x{size} {dt}: {steps} engine steps (batch {batch}) on {nimg} synthetic ellipse images, then eval "
+                      f"on {neval}: HIP label maps vs the fp32 CPU oracle on the same trained weights",
+            "loss_first": first, "loss_last": last, "max_abs_logit_diff_over_range": float((out - ref).abs().max()) / rng,
+            "label_map_mismatch_px": int((pg != pc).sum()), "pixels": int(pg.numel()),
+            "hard_dice_gpu_vs_cpu_labelmaps": min(vs_cpu), "hard_dice_vs_ground_truth_gpu": sum(gt_gpu) / 2,
+            "hard_dice_vs_ground_truth_cpu": sum(gt_cpu) / 2,
+            "dice_gap_gpu_vs_cpu": abs(sum(gt_gpu) / 2 - sum(gt_cpu) / 2)}
+
+
 def pmc_traffic(config, batch, dt):
     """HBM bytes per canonical conv launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_canonical_conv.json:
     2 x FETCH_SIZE -- gfx950 half-count correction -- + WRITE_SIZE, separate --pmc passes, tools/pmc_conv64.sh)."""
@@ -377,6 +438,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(channels, size)
             out["parity"] = parity_gate_benchmarked(dev, channels, dt)
             out["parity_cfg1"] = parity_gate(dev)
+            if len(channels) <= 5:
+                out["parity_trained"] = parity_gate_trained(dev, channels, dt)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

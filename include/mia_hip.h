@@ -69,6 +69,7 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
  * environment variable once at first use, stored in an atomic, changed only by mia_set_option; every entry point takes one
  * snapshot per call.  Thread-safe.  Names (env var, default):
  *   conv_bt (MIA_CONV_BT, 1)       wide stride-1 3x3 bf16 convs on the 512-thread big-tile LDS-DMA kernel (0: tile kernel)
+ *   conv_bt_order (MIA_CONV_BT_ORDER, 1)   its work-item order: 1 = the channel blocks of a pixel tile run together on one XCD
  *   conv64 (MIA_CONV64, 1)         64 -> 64 channel bf16 3x3 stride-1 launches on the persistent register-weight kernel
  *   conv64_blocks (MIA_CONV64_BLOCKS, 0 = 512)   its workgroup count (diagnostics)
  *   conv_xcd / wgrad_xcd (MIA_CONV_XCD / MIA_WGRAD_XCD, 1)   blocks sharing an input tile run on one XCD (0: plain grid order)
@@ -271,7 +272,8 @@ int mia_resize_nearest(const void* in, void* out, int elem_bytes, int64_t planes
 /* ------------------------------------------------------------------ validation / selection reductions */
 /* pred = output.softmax(1).argmax(1) (al_trainer.py:1430-1431) + per-(image, class) hard Dice of calculate_metric_percase
  * (:1539-1556, medpy.metric.dc: 2|A&B|/(|A|+|B|), 0 for an empty prediction).  pred / (labels, workspace, counts[B][K1][3],
- * dice[B][K1]) are each optional. */
+ * dice[B][K1]) are each optional.  logits == NULL = label-map mode: `pred` is an INPUT label map (the post-processed
+ * prediction of valid_slices, al_trainer.py:1442-1446) and only the counts / Dice against `labels` are computed. */
 int mia_argmax_dice_workspace(int nb, int k1, int slabs); /* floats */
 int mia_argmax_dice(const float* logits, const long long* labels, long long* pred, int nb, int64_t hw, int k1, int64_t sn, int64_t sk,
                     int64_t sp, int slabs, float* workspace, float* counts, float* dice, void* stream);

@@ -118,7 +118,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 struct BtWork { int img, ty, tx, n0; };
 
 template <int WC, int NCT, int MT>
-__global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int ptiles, int tx32, int nwork) {
+__global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int ptiles, int tx32, int nwork, int nb_tile_major) {
   using G = BtGeo<WC, NCT, MT>;
   constexpr int NCH = G::NCH, SLOT = G::SLOT, WPW = G::WPW;
   constexpr int NSTORE = (MT / 2) * NCT;  // tile stores per wave (every wave issues all of them, masked lanes out of range)
@@ -139,12 +139,26 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
   const int wc = wave % WC, wp = wave / WC;
   const int wpx = wp & 1, wpy = wp >> 1;
 
-  // ---- work list: item w = (channel block, pixel tile), channel block slow -- the workgroups resident at one time stream the
-  // SAME weight chunks (one fetch from HBM / MALL, the rest L2 hits); a workgroup walks items b, b + grid, b + 2 grid, ...
+  // ---- work list: a workgroup walks items b, b + grid, b + 2 grid, ...; all workgroups run in step, so at any time they stream
+  // the same K chunk.  Item -> (channel block, pixel tile):
+  //   nb_tile_major = NB > 0 (tile count a multiple of 8): w = ((tile / 8) * NB + cb) * 8 + tile % 8 -- the NB channel blocks of
+  //     a tile run at the same time on ONE XCD (blocks b, b + 8, ... share an XCD and its L2), so the tile's input is fetched
+  //     into that L2 once instead of NB times a whole pass apart (PMC at 256 ch: 1.11 GB -> see profiles/), and every XCD
+  //     streams all NB weight blocks (NB x 74 KB per chunk);
+  //   nb_tile_major = 0: channel block slow, w = cb * tiles + tile.
   const int per_img = a.tiles_y * tx32;
   auto decode = [&](int w) __attribute__((always_inline)) -> BtWork {
     BtWork t;
-    const int cb = w / ptiles, tile = w - cb * ptiles;
+    int cb, tile;
+    if (nb_tile_major > 0) {
+      const int slot = w >> 3;
+      const int grp = slot / nb_tile_major;
+      cb = slot - grp * nb_tile_major;
+      tile = grp * 8 + (w & 7);
+    } else {
+      cb = w / ptiles;
+      tile = w - cb * ptiles;
+    }
     t.img = tile / per_img;
     const int trem = tile - t.img * per_img;
     t.ty = trem / tx32;
@@ -565,19 +579,21 @@ static int bt_num_cus() {  // one persistent workgroup per CU (device-properties
 }
 
 template <int WC, int NCT, int MT>
-static void bt_launch(const ConvArgs& a, int nch, hipStream_t st) {
+static void bt_launch(const ConvArgs& a, int nch, int order, hipStream_t st) {
   const int tx32 = (a.tiles_x + 1) / 2;
   const int ptiles = a.N * a.tiles_y * tx32;
-  const int nwork = ptiles * ((a.o1 + a.o2) / nch);
+  const int nb = (a.o1 + a.o2) / nch;
+  const int nwork = ptiles * nb;
   const int ncu = bt_num_cus();
-  hipLaunchKernelGGL((conv_bt_kernel<WC, NCT, MT>), dim3(nwork < ncu ? nwork : ncu), dim3(512), 0, st, a, ptiles, tx32, nwork);
+  const int tile_major = (order != 0 && nb > 1 && ptiles % 8 == 0) ? nb : 0;
+  hipLaunchKernelGGL((conv_bt_kernel<WC, NCT, MT>), dim3(nwork < ncu ? nwork : ncu), dim3(512), 0, st, a, ptiles, tx32, nwork, tile_major);
 }
 
-int conv_bt_launch(const ConvArgs& a, hipStream_t st) {
+int conv_bt_launch(const ConvArgs& a, int order, hipStream_t st) {
   const int nch = bt_nch(a);
-  if (nch == 128) bt_launch<2, 4, 8>(a, nch, st);
-  else if (nch == 96) bt_launch<2, 3, 8>(a, nch, st);
-  else if (nch == 64) bt_launch<1, 4, 4>(a, nch, st);
+  if (nch == 128) bt_launch<2, 4, 8>(a, nch, order, st);
+  else if (nch == 96) bt_launch<2, 3, 8>(a, nch, order, st);
+  else if (nch == 64) bt_launch<1, 4, 4>(a, nch, order, st);
   else return MIA_EARG;
   return MIA_OK;
 }

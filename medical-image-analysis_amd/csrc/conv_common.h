@@ -64,4 +64,4 @@ int conv64_launch(const ConvArgs& a, int blocks_override, hipStream_t st);
 // conv_bt.hip: 512-thread "big tile" LDS-DMA kernel for the stride-1 3x3 bf16 convs with >= 64-channel blocks (levels >= 1
 // of the network, the decoder's two-source convs, cfg5's 96-multiples); false = shape outside its contract.
 bool conv_bt_eligible(int mode, int dtype, const ConvArgs& a);
-int conv_bt_launch(const ConvArgs& a, hipStream_t st);
+int conv_bt_launch(const ConvArgs& a, int order /* option conv_bt_order: 1 = tile-major item order */, hipStream_t st);

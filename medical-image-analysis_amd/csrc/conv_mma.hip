@@ -348,7 +348,7 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
     return MIA_EUNSUPPORTED;
   }
   if (opt.conv64 && mt == 4 && conv64_eligible(mode, dtype, a)) rc = conv64_launch(a, opt.conv64_blocks, st);
-  else if (opt.conv_bt && mt == 4 && conv_bt_eligible(mode, dtype, a)) rc = conv_bt_launch(a, st);
+  else if (opt.conv_bt && mt == 4 && conv_bt_eligible(mode, dtype, a)) rc = conv_bt_launch(a, opt.conv_bt_order, st);
   else if (fast) rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
   else rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);
   if (rc != MIA_OK) return rc;

@@ -311,9 +311,13 @@ __global__ __launch_bounds__(256) void head_norm_fwd_kernel(const T* __restrict_
       for (int k = 0; k < K1; ++k) { const float t = group_sum<UPP>(acc[k]); mine = (u == k) ? t : mine; }
       if (u < K1) tb[u * 64 + j * GP + gl] = mine + bu;
     }
+    // wave-private transpose: other lanes read what this lane wrote.  The wave barrier (free at run time) states the
+    // write -> read and, for the next round, read -> write order in the program instead of leaving it to in-order DS issue.
+    __builtin_amdgcn_wave_barrier();
     float* on = out + (int64_t)n * osn + (int64_t)(q0 + lane) * osp;
 #pragma unroll
     for (int k = 0; k < K1; ++k) on[k * osk] = tb[k * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
   }
   for (int p = r0 + nbulk + pl; p < r1; p += LANES) body(*reinterpret_cast<const u32x4*>(yb + (size_t)p * C0), p);
 }

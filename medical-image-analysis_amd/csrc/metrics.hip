@@ -26,10 +26,14 @@ __global__ void argmax_dice_kernel(const float* __restrict__ logits, const long 
   for (int64_t p = r0 + threadIdx.x; p < r1; p += blockDim.x) {
     float best = -INFINITY;
     int arg = 0;
+    if (logits != nullptr) {
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k)
-      if (k < k1) { const float v = base[p * g.sp + k * g.sk]; if (v > best) { best = v; arg = k; } }
-    if (pred) pred[(int64_t)b * hw + p] = arg;
+      for (int k = 0; k < MAXK; ++k)
+        if (k < k1) { const float v = base[p * g.sp + k * g.sk]; if (v > best) { best = v; arg = k; } }
+      if (pred) pred[(int64_t)b * hw + p] = arg;
+    } else {
+      arg = (int)pred[(int64_t)b * hw + p];  // label-map mode: `pred` is an INPUT (e.g. the post-processed prediction)
+    }
     const int lab = labels ? (int)labels[(int64_t)b * hw + p] : -1;
 #pragma unroll
     for (int k = 0; k < MAXK; ++k)
@@ -69,7 +73,8 @@ extern "C" int mia_argmax_dice_workspace(int nb, int k1, int slabs) { return nb 
 
 extern "C" int mia_argmax_dice(const float* logits, const long long* labels, long long* pred, int nb, int64_t hw, int k1, int64_t sn,
                                int64_t sk, int64_t sp, int slabs, float* workspace, float* counts, float* dice, void* stream) {
-  MIA_CHECK_ARG(logits && nb > 0 && hw > 0 && slabs > 0, "mia_argmax_dice: bad arguments");
+  MIA_CHECK_ARG(nb > 0 && hw > 0 && slabs > 0, "mia_argmax_dice: bad arguments");
+  MIA_CHECK_ARG(logits || (pred && labels), "mia_argmax_dice: label-map mode (logits == NULL) needs pred (input) and labels");
   MIA_CHECK_ARG(k1 >= 1 && k1 <= MAXK, "mia_argmax_dice: k1=%d not in [1,%d]", k1, MAXK);
   MIA_CHECK_ARG((labels == nullptr) == (counts == nullptr) && (counts == nullptr) == (dice == nullptr) &&
                 (counts == nullptr || workspace != nullptr), "mia_argmax_dice: labels, workspace, counts and dice go together");

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
 #pragma unroll
         for (int m = 0; m < MT; ++m)
           *reinterpret_cast<u32x2*>(t + c16 * PITCH + 32 * m + 8 * q) = u32x2{pk(acc[m][0], acc[m][1]), pk(acc[m][2], acc[m][3])};
+        __builtin_amdgcn_wave_barrier();  // wave-private transpose: write -> cross-lane read order stated in the program
         constexpr int UPP = 2 * MT;  // 16-byte units per pixel
 #pragma unroll
         for (int it = 0; it < UPP * 16 / 64; ++it) {
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
           const u32x4 d = *reinterpret_cast<const u32x4*>(t + pxl * PITCH + 16 * ch);
           if (x0 + pxl < wd) *reinterpret_cast<u32x4*>(yimg + ((size_t)row * wd + x0 + pxl) * C0 + 8 * ch) = d;
         }
+        __builtin_amdgcn_wave_barrier();  // ... and read -> next round's write
       } else {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {

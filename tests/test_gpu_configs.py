@@ -324,3 +324,26 @@ def test_cfg5_full_size_bf16_properties():
     del grads
     losses = [eng.train_step(batch).item() for _ in range(5)]
     assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+
+
+def test_trained_bf16_label_maps_match_fp32_cpu_oracle():
+    """Dice gate of the bf16 headline on a TRAINED net (VERDICT r2 missing #7 / weak #3): the benchmarked widths, trained 60
+    engine steps in bf16, evaluated by the HIP path (bf16) and by the fp32 CPU oracle on the same weights.  Label-map Dice
+    per class >= 0.995 and the Dice-vs-ground-truth gap < 5e-3; the same routine in fp32 must be exact off ties.  bench.py
+    reports this record as `parity_trained`."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    dev = torch.device("cuda:0")
+    r = bench.parity_gate_trained(dev, [64, 128, 256, 512, 1024], "bf16")
+    print("parity_trained bf16:", r)
+    assert r["loss_last"] < 0.6 * r["loss_first"]          # it trains
+    assert r["hard_dice_vs_ground_truth_gpu"] > 0.8
+    assert r["hard_dice_gpu_vs_cpu_labelmaps"] >= 0.995
+    assert r["dice_gap_gpu_vs_cpu"] < 5e-3
+    r32 = bench.parity_gate_trained(dev, [64, 128, 256, 512, 1024], "f32", steps=20)
+    print("parity_trained f32:", r32)
+    assert r32["hard_dice_gpu_vs_cpu_labelmaps"] >= 0.9999 and r32["dice_gap_gpu_vs_cpu"] < 1e-4
