@@ -242,7 +242,11 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"])
-    ap.add_argument("--norm", default="instance", choices=["instance", "batch"])
+    ap.add_argument("--norm", default=None, choices=["instance", "batch"],
+                    help="default: instance (DP-exact, SURVEY 8d) -- batch for cfg4, the al_train default (train.py:25)")
+    ap.add_argument("--augment", default=None, choices=["on", "off"],
+                    help="cfg4 default on: native-resolution BUSI-shaped inputs resident in HBM -> on-GPU elastic + affine + "
+                         "intensity pipeline (al_trainer.py:670-697 + RandomElastic) -> JointResize -> train step, all timed")
     ap.add_argument("--dropout", type=float, default=0.1,
                     help="Dropout2d probability of every PlainBlock (al_train default 0.1, al_trainer.py:109); 0 = None")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -279,6 +283,8 @@ def main():
     channels, size, batch, dt = CONFIGS[args.config]
     batch = args.batch or batch
     dt = args.dtype or dt
+    args.norm = args.norm or ("batch" if args.config == "cfg4" else "instance")
+    augment = (args.augment or ("on" if args.config == "cfg4" else "off")) == "on"
     torch.manual_seed(1337)  # identical weights on every rank
     drop = args.dropout if args.dropout > 0 else None
     model = UNet(2, 1, 3, channels, normalization=args.norm, dropout_prob=drop).to(dev)
@@ -290,6 +296,34 @@ def main():
     eng = TrainEngine(model, loss_fn, "adam", {"weight_decay": 5e-4}, start_lr=1e-3, num_iters=4000, lr_warmup_iter=250)
     img, lab = synth_batch(batch, size, 1337 + rank)
     batch_d = {"image": img.to(dev), "label": lab.to(dev)}  # resident in HBM before timing
+    aug = aug_in = None
+    aug_log = []
+    if augment:
+        # BASELINE.json configs[3]: "BUSI 3-class 256x256 with full on-GPU elastic+affine+intensity augmentation pipeline".
+        # Native-resolution inputs (BUSI-like ~500x600) resident in HBM; every step draws fresh parameters in the
+        # reference's order (host, global torch CPU generator) and runs the batched kernels + JointResize in the timed region.
+        from transforms.gpu_pipeline import BatchedAugment, al_train_transforms
+        H0, W0 = 496, 608
+        g0 = torch.Generator().manual_seed(4242 + rank)
+        nat_img = torch.rand(batch, 1, H0, W0, generator=g0)
+        _, nat_lab = synth_batch(batch, max(H0, W0), 77 + rank)
+        nat_lab = nat_lab[:, :H0, :W0].contiguous()
+        aug = BatchedAugment(al_train_transforms("busi", elastic=True), image_size=size, do_normalize=False)
+        aug_in = (nat_img.to(dev), nat_lab.to(dev))
+
+    def one_step():
+        if aug is None:
+            return eng.train_step(batch_d)
+        if stream_on[0]:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            th = time.perf_counter()
+            e0.record()
+            b = aug(*aug_in)
+            e1.record()
+            aug_log.append((e0, e1, time.perf_counter() - th, b.get("_bytes", 0)))
+        else:
+            b = aug(*aug_in)
+        return eng.train_step(b)
 
     c0 = channels[0]
     def _match(mode, c1, c2, nout, h, w, flip):
@@ -345,17 +379,28 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        loss = eng.train_step(batch_d)
+        loss = one_step()
     sync()
     probe.enabled = True
     stream_on[0] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = eng.train_step(batch_d)
+        loss = one_step()
     sync()
     elapsed = time.perf_counter() - t0
     probe.enabled = False
     stream_on[0] = False
+    elapsed_noaug = None
+    if aug is not None:  # the same step on a fixed, already augmented batch: what the pipeline costs (reported, not `value`)
+        fixed = aug(*aug_in)
+        for _ in range(2):
+            eng.train_step(fixed)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            loss2 = eng.train_step(fixed)
+        sync()
+        elapsed_noaug = time.perf_counter() - t1
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -427,6 +472,22 @@ def main():
                     hbm[key] = {"launches": len(recs), "achieved": round(by / tm / 1e9, 1), "unit": "GB/s", "peak": PEAK_HBM_GBS,
                                 "frac": round(by / tm / 1e9 / PEAK_HBM_GBS, 4)}
             roof["hbm_streams"] = hbm
+        if aug is not None and aug_log:
+            # every stage reads its image (+ label) once and writes it once; `_bytes` is counted by BatchedAugment
+            # from the stages that actually ran on this batch (per-sample stages still stream the whole batch through)
+            torch.cuda.synchronize()
+            tg = sum(a.elapsed_time(b) for a, b, _, _ in aug_log) * 1e-3
+            th = sum(h for _, _, h, _ in aug_log)
+            by = sum(n for _, _, _, n in aug_log)
+            aug_rec = {"bound": "hbm", "launches": len(aug_log), "avg_ms_device_span": round(1e3 * tg / len(aug_log), 4),
+                       "avg_ms_host_issue": round(1e3 * th / len(aug_log), 4), "algorithmic_bytes_per_batch": by / len(aug_log),
+                       "achieved": round(by / tg / 1e9, 1), "unit": "GB/s", "peak": PEAK_HBM_GBS, "frac": round(by / tg / 1e9 / PEAK_HBM_GBS, 4),
+                       "share_of_step": round((elapsed - elapsed_noaug) / elapsed, 4) if elapsed_noaug else None,
+                       "pipeline": "RandomElastic(p .2) + al_train busi stages (affine scale / rotate, noise, blur, 2 x contrast, low-res, gamma) at "
+                                   f"{aug_in[0].shape[-2]}x{aug_in[0].shape[-1]} -> JointResize({size}) (al_trainer.py:670-697, fugc_dataset.py:140-164)"}
+            if roof is None:
+                roof = {}
+            roof["augment"] = aug_rec
         out = {"metric": f"training images/sec (whole node), UNet {size}x{size} 1ch bs={batch}/GPU", "value": round(value, 2),
                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
@@ -434,6 +495,10 @@ def main():
                                       f"dropout {drop}, Dice+CE, Adam(wd 5e-4), clip 10 ({args.config})",
                           "global_batch": world * batch, "parallelism": f"dp{world}"},
                "final_loss": round(loss_v, 6), "roofline": roof}
+        if elapsed_noaug is not None:
+            out["value_without_augmentation"] = round(world * batch * args.steps / elapsed_noaug, 2)
+            out["ms_per_step_without_augmentation"] = round(1e3 * elapsed_noaug / args.steps, 3)
+            out["config"]["workload"] += "; inputs: native-resolution batch resident in HBM -> on-GPU elastic+affine+intensity pipeline -> resize, inside the timed step"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(channels, size)
             out["parity"] = parity_gate_benchmarked(dev, channels, dt)

@@ -13,22 +13,107 @@ import torch
 from mia_hip import MiaError, call, lib
 from mia_hip.ops import _c_float, _c_i64, _need_dev, _p, _stream
 
+import numpy as np
+
 EW_GAMMA, EW_CONTRAST, EW_NOISE, EW_ZSCORE = 0, 1, 2, 3
 
 
+class ParamArena:
+    """ONE host -> device parameter upload per augmented batch.
+
+    The per-sample parameters of a pipeline (affine matrices, sigmas, kernel sizes, apply flags, displacement grids ...) are
+    produced stage by stage inside ``apply_batch``; uploaded one by one (`torch.tensor(list, device=...)`) each is a pageable,
+    SYNCHRONOUS copy that also makes the host wait for everything queued on the stream -- 17 copies per batch and a host
+    that can never run ahead of the GPU.  With an arena the pipeline runs twice: a DRY pass on `meta` tensors (no memory,
+    no launch) in which every parameter array is only registered, then all arrays travel in one pinned, asynchronous copy,
+    and the REAL pass hands each request its slice of the device buffer in the same order."""
+
+    RING = 4  # pinned staging buffers in flight (the host may run this many batches ahead of the device)
+
+    def __init__(self, device):
+        self.device = device
+        self.dry = False
+        self.items = []
+        self.views = []
+        self.k = 0
+        self._slots = [None] * self.RING  # (pinned host uint8, device uint8, event)
+        self._turn = 0
+
+    def begin_dry(self):
+        self.dry, self.items, self.views, self.k = True, [], [], 0
+
+    def upload(self):
+        """End of the dry pass: pack the registered arrays (16-byte aligned) and issue the one copy."""
+        self.dry = False
+        offs, total = [], 0
+        for a in self.items:
+            offs.append(total)
+            total += (a.nbytes + 15) // 16 * 16
+        if total == 0:
+            return
+        slot = self._slots[self._turn]
+        if slot is None or slot[0].numel() < total:
+            cap = max(4096, 2 * total)
+            slot = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device),
+                    torch.cuda.Event())
+            self._slots[self._turn] = slot
+        else:
+            slot[2].synchronize()  # the copy that last read this pinned buffer has completed (normally long ago)
+        host, dev, ev = slot
+        hv = host.numpy()
+        for a, o in zip(self.items, offs):
+            hv[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+        dev[:total].copy_(host[:total], non_blocking=True)
+        ev.record()
+        self._turn = (self._turn + 1) % self.RING
+        td = {np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32}
+        self.views = [dev[o:o + a.nbytes].view(td[a.dtype]).reshape(a.shape) for a, o in zip(self.items, offs)]
+        self.k = 0
+
+    def take(self, arr: np.ndarray) -> torch.Tensor:
+        if self.dry:
+            self.items.append(np.ascontiguousarray(arr))
+            return torch.empty(arr.shape, dtype=torch.float32 if arr.dtype == np.float32 else torch.int32, device="meta")
+        v = self.views[self.k]
+        if tuple(v.shape) != tuple(arr.shape):
+            raise MiaError("ParamArena: the real pass asked for a different parameter array than the dry pass")
+        self.k += 1
+        return v
+
+
+_ARENA: Optional[ParamArena] = None  # set by transforms.gpu_pipeline.BatchedAugment around one batch
+
+
+def set_arena(arena: Optional[ParamArena]) -> None:
+    global _ARENA
+    _ARENA = arena
+
+
+def _dry() -> bool:
+    return _ARENA is not None and _ARENA.dry
+
+
+def dev_array(arr: np.ndarray, dev) -> torch.Tensor:
+    """float32 / int32 host array -> device tensor: a slice of the batch's single upload when an arena is active."""
+    if _ARENA is not None:
+        return _ARENA.take(arr)
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+
+
 def _f32(x: torch.Tensor) -> torch.Tensor:
-    _need_dev(x)
+    if not (_dry() and x.is_meta):
+        _need_dev(x)
     if x.dtype != torch.float32:
         x = x.float()
     return x.contiguous()
 
 
 def _dev_f(vals, dev):
-    return torch.tensor(list(vals), dtype=torch.float32, device=dev)
+    return dev_array(np.asarray(list(vals), dtype=np.float32), dev)
 
 
 def _dev_i(vals, dev):
-    return torch.tensor([int(v) for v in vals], dtype=torch.int32, device=dev)
+    return dev_array(np.asarray([int(v) for v in vals], dtype=np.int32), dev)
 
 
 def _apply(apply, dev):
@@ -46,11 +131,14 @@ def affine_nearest(img: Optional[torch.Tensor], lab: Optional[torch.Tensor], mat
         io = _f32(img)
         oi = torch.empty_like(io)
     if lab is not None:
-        _need_dev(lab)
+        if not _dry():
+            _need_dev(lab)
         lo = lab.long().contiguous()
         ol = torch.empty_like(lo)
-    m = torch.tensor([list(r) for r in mats], dtype=torch.float32, device=dev).reshape(b, 6)
+    m = dev_array(np.asarray([list(r) for r in mats], dtype=np.float32).reshape(b, 6), dev)
     ap = _apply(apply, dev)
+    if _dry():
+        return oi, ol
     call("mia_affine_nearest", _p(io), _p(oi), _p(lo), _p(ol), b, c, h, w, _p(m), _p(ap), _stream())
     return oi, ol
 
@@ -62,8 +150,11 @@ def elastic_warp(img: Optional[torch.Tensor], lab: Optional[torch.Tensor], disp:
     dev = ref.device
     b, h, w = ref.shape[0], ref.shape[-2], ref.shape[-1]
     c = img.shape[1] if img is not None else 1
-    _need_dev(disp)
-    d = disp.to(device=dev, dtype=torch.float32).contiguous()
+    if isinstance(disp, np.ndarray):
+        d = dev_array(disp.astype(np.float32), dev)
+    else:
+        _need_dev(disp)
+        d = disp.to(device=dev, dtype=torch.float32).contiguous()
     if d.ndim != 4 or d.shape[0] != b or d.shape[1] != 2 or d.shape[2] < 2 or d.shape[3] < 2:
         raise MiaError(f"elastic_warp: displacement grid must be [B, 2, gh >= 2, gw >= 2], got {tuple(d.shape)}")
     io = oi = lo = ol = None
@@ -71,17 +162,21 @@ def elastic_warp(img: Optional[torch.Tensor], lab: Optional[torch.Tensor], disp:
         io = _f32(img)
         oi = torch.empty_like(io)
     if lab is not None:
-        _need_dev(lab)
+        if not _dry():
+            _need_dev(lab)
         lo = lab.long().contiguous()
         ol = torch.empty_like(lo)
     ap = _apply(apply, dev)
+    if _dry():
+        return oi, ol
     call("mia_elastic_warp", _p(io), _p(oi), _p(lo), _p(ol), b, c, h, w, _p(d), d.shape[2], d.shape[3], _p(ap), _stream())
     return oi, ol
 
 
 def rot90_flip(x: torch.Tensor, k: int = 0, flip_h: bool = False, flip_w: bool = False) -> torch.Tensor:
     """torch.rot90(x, k, (-2, -1)) followed by optional flips of H / W, for 4- or 8-byte dtypes."""
-    _need_dev(x)
+    if not _dry():
+        _need_dev(x)
     x = x.contiguous()
     if x.element_size() not in (4, 8):
         raise MiaError("rot90_flip supports 4- or 8-byte element types")
@@ -91,13 +186,16 @@ def rot90_flip(x: torch.Tensor, k: int = 0, flip_h: bool = False, flip_w: bool =
     if k % 2:
         oshape[-2], oshape[-1] = w, h
     out = torch.empty(oshape, device=x.device, dtype=x.dtype)
+    if _dry():
+        return out
     call("mia_rot90_flip", _p(x), _p(out), x.element_size(), 1, planes, h, w, int(k) % 4, int(flip_h), int(flip_w), _stream())
     return out
 
 
 def crop(x: torch.Tensor, top: Sequence[int], left: Sequence[int], oh: int, ow: int) -> torch.Tensor:
     """x [B, ..., H, W] (4- or 8-byte dtype) -> [B, ..., oh, ow]: per-sample window x[b, ..., top[b]:top[b]+oh, left[b]:left[b]+ow]."""
-    _need_dev(x)
+    if not _dry():
+        _need_dev(x)
     x = x.contiguous()
     if x.element_size() not in (4, 8):
         raise MiaError("crop supports 4- or 8-byte element types")
@@ -107,6 +205,8 @@ def crop(x: torch.Tensor, top: Sequence[int], left: Sequence[int], oh: int, ow: 
     planes = x.numel() // (b * h * w)
     out = torch.empty(tuple(x.shape[:-2]) + (oh, ow), device=x.device, dtype=x.dtype)
     tp, lf = _dev_i(top, x.device), _dev_i(left, x.device)
+    if _dry():
+        return out
     call("mia_crop", _p(x), _p(out), x.element_size(), b, planes, h, w, oh, ow, _p(tp), _p(lf), _stream())
     return out
 
@@ -116,6 +216,8 @@ def gaussian_blur(img: torch.Tensor, sigma: Sequence[float], ksize: Sequence[int
     b, c, h, w = x.shape
     out = torch.empty_like(x)
     sg, ks, ap = _dev_f(sigma, x.device), _dev_i(ksize, x.device), _apply(apply, x.device)  # keep alive across the launch
+    if _dry():
+        return out
     call("mia_gaussian_blur", _p(x), _p(out), b, c, h, w, _p(sg), _p(ks), int(max(ksize)), _p(ap), _stream())
     return out
 
@@ -126,6 +228,8 @@ def sample_stats(img: torch.Tensor, gray: bool = False) -> torch.Tensor:
     b, c, h, w = x.shape
     ws = torch.empty(lib().mia_sample_stats_workspace(b), device=x.device, dtype=torch.float32)
     out = torch.empty((b, 2), device=x.device, dtype=torch.float32)
+    if _dry():
+        return out
     call("mia_sample_stats", _p(x), b, c, _c_i64(h * w), int(gray), _p(ws), _p(out), _stream())
     return out
 
@@ -139,6 +243,8 @@ def elementwise(img: torch.Tensor, op: int, p0=None, mean_std: Optional[torch.Te
     if aux is not None:
         aux = _f32(aux)
     ap = _apply(apply, x.device)
+    if _dry():
+        return out
     call("mia_elementwise", _p(x), _p(out), _c_i64(x.numel() // b), b, op, _p(pp), _p(mean_std), _p(aux), _p(ap), _stream())
     return out
 
@@ -148,6 +254,8 @@ def noise_clip(img: torch.Tensor, sigma: Sequence[float], seed: int, offset: int
     b = x.shape[0]
     out = torch.empty_like(x)
     sg, ap = _dev_f(sigma, x.device), _apply(apply, x.device)
+    if _dry():
+        return out
     call("mia_noise_clip", _p(x), _p(out), _c_i64(x.numel() // b), b, _p(sg), ctypes.c_uint64(seed), ctypes.c_uint64(offset),
          _p(ap), _stream())
     return out
@@ -158,6 +266,8 @@ def resize_bilinear(img: torch.Tensor, oh: int, ow: int, antialias: bool = False
     x = _f32(img)
     b, c, h, w = x.shape
     out = torch.empty((b, c, oh, ow), device=x.device, dtype=torch.float32)
+    if _dry():
+        return out
     if antialias and (oh < h or ow < w):
         tmp = torch.empty((b, c, h, ow), device=x.device, dtype=torch.float32)
         call("mia_resize_bilinear_aa", _p(x), _p(tmp), _p(out), b, c, h, w, oh, ow, _stream())
@@ -171,21 +281,26 @@ def lowres(img: torch.Tensor, low_hw: Sequence[Sequence[int]], apply=None) -> to
     x = _f32(img)
     b, c, h, w = x.shape
     out = torch.empty_like(x)
-    lw = torch.tensor([[int(a), int(d)] for a, d in low_hw], dtype=torch.int32, device=x.device)
+    lw = dev_array(np.asarray([[int(a), int(d)] for a, d in low_hw], dtype=np.int32), x.device)
     ap = _apply(apply, x.device)
+    if _dry():
+        return out
     call("mia_resize_bilinear", _p(x), _p(out), b, c, h, w, h, w, _p(lw), _p(ap), _stream())
     return out
 
 
 def resize_nearest(x: torch.Tensor, oh: int, ow: int) -> torch.Tensor:
     """interpolate(nearest) on the last two dims; float32 images or int64 label maps."""
-    _need_dev(x)
+    if not _dry():
+        _need_dev(x)
     if x.dtype not in (torch.float32, torch.int64, torch.int32):
         x = x.float() if x.is_floating_point() else x.long()
     x = x.contiguous()
     h, w = x.shape[-2], x.shape[-1]
     planes = x.numel() // (h * w)
     out = torch.empty(list(x.shape[:-2]) + [oh, ow], device=x.device, dtype=x.dtype)
+    if _dry():
+        return out
     call("mia_resize_nearest", _p(x), _p(out), x.element_size(), _c_i64(planes), h, w, oh, ow, _stream())
     return out
 

@@ -48,16 +48,61 @@ class BatchedAugment:
         self.transform = transform
         self.final = JointResize(image_size, antialias=antialias) if image_size is not None else None
         self.normalize = ZScoreNormalize() if do_normalize else None
+        self._arena = None
 
     def __call__(self, images: torch.Tensor, labels: torch.Tensor) -> dict:
+        """Parameters are drawn on the host in the reference's order, then the stages run twice: a dry pass on `meta` tensors
+        that only collects every stage's per-sample parameter arrays, ONE pinned asynchronous upload of all of them, and the
+        real pass (functional_hip.ParamArena) -- no per-stage copies, no host/device synchronisation."""
+        from . import functional_hip as FH
         b = images.shape[0]
         labels = labels.reshape(b, labels.shape[-2], labels.shape[-1])
+        params = None
         if self.transform is not None:
             shape = tuple(images.shape[1:])
             params = [self.transform.draw(shape) for _ in range(b)]  # sample-major, like sequential per-sample calls
+        if self._arena is None or self._arena.device != images.device:
+            self._arena = FH.ParamArena(images.device)
+        arena = self._arena
+        FH.set_arena(arena)
+        try:
+            arena.begin_dry()
+            self._run(torch.empty(images.shape, dtype=images.dtype, device="meta"),
+                      torch.empty(labels.shape, dtype=labels.dtype, device="meta"), params, b)
+            arena.upload()
+            images, labels, nbytes = self._run(images, labels, params, b)
+        finally:
+            arena.dry = False
+            FH.set_arena(None)
+        return {"image": images, "label": labels, "_bytes": nbytes}
+
+    def _run(self, images, labels, params, b):
+        nbytes = 0
+        if self.transform is not None:
+            nbytes += self._stage_bytes(params, images, labels)
             images, labels = self.transform.apply_batch(images, labels, params)
         if self.final is not None:
+            h0, w0 = images.shape[-2:]
             images, labels = self.final.apply_batch(images, labels, [()] * b)
+            nbytes += b * (4 * images.shape[1] + 8) * (h0 * w0 + images.shape[-2] * images.shape[-1])
         if self.normalize is not None:
+            nbytes += 3 * images.numel() * 4
             images, labels = self.normalize.apply_batch(images, labels)
-        return {"image": images, "label": labels}
+        return images, labels, nbytes
+
+    def _stage_bytes(self, params, images, labels) -> int:
+        """Algorithmic bytes of the stages that run on this batch (a stage reads its image (+ label) once and writes
+        it once; a stage selected for at least one sample streams the whole batch, the others are skipped)."""
+        b, c, h, w = images.shape
+        img_b, lab_b = b * c * h * w * 4, b * h * w * 8
+        total = 0
+        stages = getattr(self.transform, "transforms", [])
+        for i, t in enumerate(stages):
+            if all(q is None or q[i] is None for q in params):
+                continue
+            inner = getattr(t, "transform", t)
+            geometric = isinstance(inner, (RandomAffine, RandomElastic, RandomRotation, RandomRotation90, MirrorTransform))
+            total += 2 * img_b + (2 * lab_b if geometric else 0)
+            if isinstance(inner, (RandomContrast, RandomBrightness)):
+                total += img_b  # the mean pass
+        return total

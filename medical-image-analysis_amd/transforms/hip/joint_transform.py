@@ -185,7 +185,7 @@ class RandomElastic(BaseTransform):
 
     def apply_batch(self, images, labels, params):
         zero = torch.zeros(2, self.grid[0], self.grid[1])
-        disp = torch.stack([p[0] if p is not None else zero for p in params]).to(images.device if images is not None else labels.device)
+        disp = torch.stack([p[0] if p is not None else zero for p in params]).numpy()  # host array: rides in the batch's one upload
         return FH.elastic_warp(images, labels, disp, [p is not None for p in params])
 
     def get_params_dict(self):
