@@ -256,6 +256,22 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
   auto ch_local = [&](int ct, int i) __attribute__((always_inline)) -> int {
     return PAIRCT ? 32 * (ct >> 1) + 8 * (i >> 2) + 4 * (ct & 1) + (i & 3) : 16 * ct + i;
   };
+  // fragment-read lane constants: cq = halo column of this lane's pixel (16 wpx + pi16(n)) | k-group << 8; ab0 / ab1 = byte
+  // address of this lane's weight row in the even / odd channel tiles of ring slot 0
+  unsigned cq, ab0, ab1;
+  {
+    const int lane = lane_id(), q = lane >> 4, n16 = lane & 15;
+    cq = (unsigned)((16 * wpx + pi16(n16)) | (q << 8));
+    unsigned abv[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int chl = ch_local(par, n16);
+      const int hrd = (0x1E >> (2 * ((chl >> 2) & 3))) & 3;
+      abv[par] = (unsigned)(G::RING + (wc * NCT * 16 + chl) * 64 + ((q ^ hrd) * 16));
+    }
+    ab0 = abv[0]; ab1 = abv[1];
+    asm volatile("" : "+v"(cq), "+v"(ab0), "+v"(ab1));  // opaque: not rematerialised from the thread id at every use
+  }
   f32x4 acc[MT][NCT];
   // one step: fragment reads + MFMAs of tap column tb; piece(k) (k = 0 .. 5) issues the k-th LDS-DMA piece of the step, placed
   // behind the MFMAs of row k + 1 so that its scalar work and issue slot hide under the matrix pipe
@@ -264,16 +280,12 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
   auto compute = [&](auto tbc, auto finc, unsigned imgoff, auto&& piece, auto&& fin_row) __attribute__((always_inline)) {
     constexpr int tb = decltype(tbc)::value;
     constexpr bool fin = decltype(finc)::value;
-    const int lane = lane_id(), q = lane >> 4, n16 = lane & 15;
-    const int col = 16 * wpx + pi16(n16) + tb;
+    // lane constants kept in three registers (cq, ab0, ab1): recomputing them here costs ~40 instructions (with divergent
+    // branches for the pixel permutation) on the critical path right after every barrier
+    const int c0 = (int)(cq & 0xFF), q = (int)(cq >> 8);
+    const int col = c0 + tb;
     unsigned bb = (unsigned)(((MT * wpy) * IW + col) * 64 + ((q ^ ((col >> 2) & 3)) * 16)) + imgoff;
-    unsigned ab[2];  // weight rows of this lane in the even / odd channel tiles
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      const int chl = ch_local(par, n16);
-      const int hrd = (0x1E >> (2 * ((chl >> 2) & 3))) & 3;
-      ab[par] = (unsigned)(G::RING + tb * SLOT + (wc * NCT * 16 + chl) * 64 + ((q ^ hrd) * 16));
-    }
+    unsigned ab[2] = {ab0 + (unsigned)(tb * SLOT), ab1 + (unsigned)(tb * SLOT)};
     // opaque: the constants below must fold into the ds_read offset fields, not into one hoisted register per fragment
     asm volatile("" : "+v"(ab[0]), "+v"(ab[1]), "+v"(bb));
     const unsigned char* ap0 = smem + ab[0];
