@@ -420,7 +420,10 @@ def main():
             ach = flops / (avg_ms * 1e-3) / 1e12
             traffic = pmc_traffic(args.config, batch, dt)
             persistent = dt == "bf16" and c0 == 64 and mia_hip.get_option("conv64") != 0
+            bigtile = (not persistent and dt == "bf16" and mia_hip.get_option("conv_bt") != 0 and c0 % 32 == 0 and c0 >= 64 and
+                       any(c0 % n == 0 for n in (128, 96, 64)))  # conv_bt_eligible (csrc/conv_bt.hip)
             kname = (f"conv64_persist_kernel {c0}->{c0} 3x3 @{size}x{size} x{batch}" if persistent else
+                     f"conv_bt_kernel<{128 if c0 % 128 == 0 else 96 if c0 % 96 == 0 else 64}-channel blocks> {c0}->{c0} 3x3 @{size}x{size} x{batch}" if bigtile else
                      f"conv_mma_fast_kernel<{dt},G3S1,MT4,NT4> {c0}->{c0} 3x3 @{size}x{size} x{batch}") + " (encoder.levels.0.1 / decoder.levels.3.1)"
             gbs = abytes / (avg_ms * 1e-3) / 1e9
             t_hbm, t_mfma = abytes / (PEAK_HBM_GBS * 1e9), flops / (PEAK_MFMA_TFLOPS[dt] * 1e12)

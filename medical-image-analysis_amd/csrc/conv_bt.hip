@@ -79,12 +79,11 @@ struct BtGeo {
   static constexpr int NCH = WC * NCT * 16;
   static constexpr int SLOT = 3 * NCH * 64;            // weights of the three taps (ta, tb) of one chunk
   static constexpr int WPIECES = 3 * NCH / 16;
-  static constexpr int WPW = (WPIECES + 7) / 8;        // pieces per wave and step (padded with a dummy piece)
-  static constexpr bool WDUMMY = (WPIECES % 8) != 0;
+  static constexpr int WPW = (WPIECES + 7) / 8;        // weight pieces per step of waves 0 .. WPIECES % 8 - 1 (the others: one less when WDUMMY)
+  static constexpr bool WDUMMY = (WPIECES % 8) != 0;  // the pieces do not divide evenly among the 8 waves
   static constexpr int MAXP = WPW + 3;                  // most pieces a wave issues in one step
   static constexpr int RING = 2 * IMG_BYTES;           // byte offset of the weight ring
-  static constexpr int DUMP = RING + 3 * SLOT;         // 1 KB target of dummy pieces
-  static constexpr int BIAS = DUMP + (WDUMMY ? 1024 : 0);  // bias of the current channel block (1 KB piece)
+  static constexpr int BIAS = RING + 3 * SLOT;         // bias of the current channel block (1 KB piece)
   static constexpr int RED = BIAS + 1024;                  // [8 waves][16 NCT channels][2] statistics exchange
   static constexpr int LDS = RED + 8 * NCT * 16 * 8;
   static_assert((8 / WC) * MT * 16 == TW * TH, "tile = 512 pixels");
@@ -220,10 +219,8 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
     }
   };
   auto issue_w1 = [&](unsigned wlane, int chunk, int tb, int jj) __attribute__((always_inline)) {
-    if (!G::WDUMMY || w_ok[jj])
+    if (!G::WDUMMY || w_ok[jj])  // a wave without a piece in the last round issues nothing: its waits count one piece less (wait_w)
       dma16(rsw, wlane, wsoff[tb][jj] + (unsigned)(chunk * 64), __builtin_amdgcn_readfirstlane(lds0 + G::RING + tb * SLOT + (wave + 8 * jj) * 1024));
-    else
-      dma16(rsw, BT_SENT, 0, __builtin_amdgcn_readfirstlane(lds0 + G::DUMP));
   };
   auto issue_w = [&](int chunk, int tb) __attribute__((always_inline)) {
     const unsigned wlane = make_wlane();
@@ -456,6 +453,10 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
     }
   };
 
+  // counted waits: N = operations that may stay outstanding, written for a wave that owns WPW weight pieces per step; a wave
+  // that owns one less (WDUMMY: the piece count is not a multiple of 8) waits for one less.  NW = weight-piece rounds in N.
+  const bool bigw = !G::WDUMMY || wave < (G::WPIECES % 8);  // uniform
+#define WAIT_W(N) do { if (bigw) wait_vm<(N)>(); else wait_vm<((N) - 1)>(); } while (0)
   // ---- prologue of the workgroup: image of chunk 0, bias and the weights of steps 0 and 1 of its first item
   int w = blockIdx.x;
   BtWork cur = decode(w);
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
   if (has_bias) issue_bias(cur.n0);
   issue_w(0, 0);
   issue_w(0, 1);
-  wait_vm<WPW>();
+  WAIT_W(WPW);
   __builtin_amdgcn_s_barrier();
 
 #ifdef CONV64_STAMPS
@@ -502,8 +503,8 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
       }, no_row);
       BSTAMP(z3); BACC(d_cmp, z3, z1);
       // the tile stores of the previous item (issued after everything this step reads) may stay in flight
-      if (c == 0 && !first) { if (pre) wait_vm<WPW + 3 + NSTORE>(); else wait_vm<WPW + NSTORE>(); }
-      else { if (pre) wait_vm<WPW + 3>(); else wait_vm<WPW>(); }
+      if (c == 0 && !first) { if (pre) WAIT_W(WPW + 3 + NSTORE); else WAIT_W(WPW + NSTORE); }
+      else { if (pre) WAIT_W(WPW + 3); else WAIT_W(WPW); }
       BSTAMP(z4); BACC(d_wait, z4, z3);
       __builtin_amdgcn_s_barrier();
       BSTAMP(z1); BACC(d_bar, z1, z4);
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
         else if (wbias) issue_bias(nxt.n0);
       }, no_row);
       BSTAMP(z3); BACC(d_cmp, z3, z1);
-      if (!pre) wait_vm<0>(); else if (wbias) wait_vm<WPW + 3>(); else wait_vm<WPW + 2>();
+      if (!pre) wait_vm<0>(); else if (wbias) WAIT_W(WPW + 3); else WAIT_W(WPW + 2);
       BSTAMP(z4); BACC(d_wait, z4, z3);
       __builtin_amdgcn_s_barrier();
       BSTAMP(z1); BACC(d_bar, z1, z4);
@@ -531,8 +532,8 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
       if (last) d_fin += z3 - z1; else d_cmp += z3 - z1;
 #endif
       // (last chunk) the tile stores are younger than every piece
-      if (last) { if (pre) wait_vm<WPW + NSTORE>(); else wait_vm<NSTORE>(); }
-      else wait_vm<WPW>();
+      if (last) { if (pre) WAIT_W(WPW + NSTORE); else wait_vm<NSTORE>(); }
+      else WAIT_W(WPW);
       BSTAMP(z4); BACC(d_wait, z4, z3);
       __builtin_amdgcn_s_barrier();
       BSTAMP(z1); BACC(d_bar, z1, z4);
@@ -559,6 +560,8 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
     cur = nxt; w = wnext; first = false;
   }
 }
+
+#undef WAIT_W
 
 static int bt_nch(const ConvArgs& a) {
   const int nout = a.o1 + a.o2;
