@@ -829,6 +829,234 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) 
       }
 }
 
+// ---------------------------------------------------------------- bf16, 512-thread big block (stride-1 3x3, cdy % 128 == 0)
+// Round 3.  wgrad_bf16_dma_kernel moves 92 bytes L2 -> LDS per MFMA (an 18 KB x tile + an 8 KB dy tile per 288 MFMAs) and runs two
+// 256-thread workgroups per CU.  Here ONE 512-thread workgroup per CU owns a 128 n x 64 k x 9 taps block: waves 0-3 take output
+// channels n0 .. n0 + 63, waves 4-7 the next 64, both halves share the x tile (59 bytes per MFMA), wave (nh, kq) keeps the same
+// 9 x 4 accumulator tiles as before.  Same swizzled LDS images, transposing reads and three-stage LDS-DMA ring; what changes with
+// one workgroup per CU is that nothing hides a wave's non-matrix work any more, so (lesson of conv_bt.hip) the DMA pieces of tile
+// t + 2 are issued BETWEEN the MFMA steps of tile t instead of in a block in front of them, and everything a piece needs is a lane
+// constant or a scalar prepared once per tile.
+__global__ __launch_bounds__(512, 2) void wgrad_bf16_bt_kernel(const WgArgs a) {
+  constexpr int KS = 3, TAPS = 9, TH = 4;
+  constexpr int XH = TH + 2, XROW = 3072;  // 24 pixels x 128 B per image row of the x tile
+  constexpr int X_BYTES = XH * XROW, DH_BYTES = TH * 16 * 128, D_BYTES = 2 * DH_BYTES, STAGE = X_BYTES + D_BYTES, NSTAGE = 3;
+  constexpr int XPIECES = XH * 3, DPIECES = TH * 2, PIECES = XPIECES + 2 * DPIECES;  // 18 + 8 + 8: piece pc lives at byte 1024 pc
+  constexpr int MAXOWN = (PIECES + 7) / 8;                                            // 5 (waves 0, 1) or 4 pieces per wave and tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nh = wave >> 2, kq = wave & 3;  // 64-channel half of dy and 16-input-channel tile of this wave
+  const int grp = lane >> 4, i16 = lane & 15, qp = i16 >> 2, pp = i16 & 3;
+  const int kb1 = (a.c1 + 63) / 64, nkb = kb1 + (a.c2 + 63) / 64;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (a.opt & 16) {  // XCD-aware order (1-D grid): the column blocks of one split index share their tiles -> one XCD, one L2
+    const int ncol = nkb * (a.npad / 128), slot = bx >> 3;
+    by = (slot / ncol) * 8 + (bx & 7);
+    bx = slot % ncol;
+    if (by >= a.ksplit) return;
+  }
+  const int kblk = bx % nkb, nblk = bx / nkb;
+  const bool second = kblk >= kb1;
+  const int cs = second ? a.c2 : a.c1, kloc = (second ? kblk - kb1 : kblk) * 64;
+  const int n0 = nblk * 128, k0 = (second ? a.c1 : 0) + kloc;
+  const bf16_t* xsrc = static_cast<const bf16_t*>(second ? a.x2 : a.x1);
+  const bf16_t* dy = static_cast<const bf16_t*>(a.dy);
+  const size_t xpix = (size_t)a.Hx * a.Wx, ypix = (size_t)a.Hy * a.Wy;
+
+  // DMA lane constants (as in wgrad_bf16_dma_kernel): lane L of a piece is 16-byte chunk (L&3) of half (L>>5) of pixel row
+  // r = (L>>2)&7 of the 8-row block; the source chunk is un-swizzled by the block's parity
+  const int dr = (lane >> 2) & 7;
+  const int ch8_0 = 4 * (lane >> 5) + ((lane & 3) ^ ((dr >> 2) & 3)), ch8_1 = 4 * (lane >> 5) + ((lane & 3) ^ ((2 + (dr >> 2)) & 3));
+  const unsigned xlane0 = (unsigned)((dr * cs + kloc + ch8_0 * 8) * 2), xlane1 = (unsigned)((dr * cs + kloc + ch8_1 * 8) * 2);
+  const unsigned dlane0 = (unsigned)((dr * a.cdy + n0 + ch8_0 * 8) * 2), dlane1 = (unsigned)((dr * a.cdy + n0 + ch8_1 * 8) * 2);
+  const bool xok0 = kloc + ch8_0 * 8 < cs, xok1 = kloc + ch8_1 * 8 < cs;
+  const unsigned lds0 = (unsigned)(size_t)(lds_u8*)smem;
+
+  // per-piece lane offsets of a tile whose 18 columns lie inside the image (descriptor based at the tile origin); padding /
+  // channel-tail lanes already point out of range.  dy piece q = (half h = q >> 3, 8-pixel block q & 7) reads channels n0 + 64 h ..
+  unsigned voffc[MAXOWN];
+#pragma unroll
+  for (int j = 0; j < MAXOWN; ++j) {
+    const int pc = wave + 8 * j;
+    if (pc < XPIECES) {
+      const int iy = pc / 3, xb = pc - 3 * iy, ix = 8 * xb + dr;
+      const bool ok = (ix < 18) & ((xb & 1) ? xok1 : xok0);
+      voffc[j] = ok ? (unsigned)((iy * a.Wx + 8 * xb) * cs * 2) + ((xb & 1) ? xlane1 : xlane0) : WSENT;
+    } else {
+      const int q = pc - XPIECES, h = q >> 3, qq = q & 7;
+      const bool ok = pc < PIECES;
+      voffc[j] = ok ? (unsigned)(((qq >> 1) * a.Wy + 8 * (qq & 1)) * a.cdy * 2) + ((qq & 1) ? dlane1 : dlane0) + (unsigned)(h * 128) : WSENT;
+    }
+  }
+
+  // ---- issue state of the tile being fetched (prepared once per tile, pieces issued between the MFMA steps)
+  wi32x4 rx, rd;
+  bool fastp = false;
+  int i_oy0 = 0, i_ox0 = 0;
+  unsigned i_stage = 0;
+  auto prepare = [&](int img, int ty, int tx, unsigned stage_base) {
+    i_oy0 = ty * TH; i_ox0 = tx * 16; i_stage = stage_base;
+    fastp = tx > 0 && tx * 16 + 17 <= a.Wx && tx * 16 + 16 <= a.Wy;  // uniform
+    if (fastp) {  // descriptor bases at the tile origin (row iy0 may be -1: its pieces are dropped, nothing is read through it)
+      const long long xorg = ((long long)(img * a.Hx + i_oy0 - 1) * a.Wx + i_ox0 - 1) * cs;
+      const long long dorg = ((long long)(img * a.Hy + i_oy0) * a.Wy + i_ox0) * a.cdy;
+      rx = wmake_rsrc_i(xsrc + xorg, (unsigned)(XH * a.Wx * cs * 2));
+      rd = wmake_rsrc_i(dy + dorg, (unsigned)(TH * a.Wy * a.cdy * 2));
+    } else {
+      rx = wmake_rsrc_i(xsrc + (size_t)img * xpix * cs, (unsigned)(xpix * cs * 2));
+      rd = wmake_rsrc_i(dy + (size_t)img * ypix * a.cdy, (unsigned)(ypix * a.cdy * 2));
+    }
+  };
+  auto issue_piece = [&](auto jc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    const int pc = wave + 8 * j;  // wave-uniform piece index
+    if (pc >= PIECES) return;
+    const unsigned dst = i_stage + pc * 1024;
+    const int iy0 = i_oy0 - 1, ix0 = i_ox0 - 1;
+    if (fastp) {
+      if (pc < XPIECES) {
+        const bool rowok = (unsigned)(iy0 + pc / 3) < (unsigned)a.Hx;
+        lds_dma16(rx, rowok ? voffc[j] : WSENT, __builtin_amdgcn_readfirstlane(dst));
+      } else {
+        const bool rowok = i_oy0 + (((pc - XPIECES) & 7) >> 1) < a.Hy;
+        lds_dma16(rd, rowok ? voffc[j] : WSENT, __builtin_amdgcn_readfirstlane(dst));
+      }
+    } else if (pc < XPIECES) {
+      const int iy = pc / 3, xb = pc - 3 * iy;
+      const int gy = iy0 + iy, gx = ix0 + 8 * xb + dr;
+      const bool ok = ((unsigned)gy < (unsigned)a.Hx) & ((unsigned)gx < (unsigned)a.Wx) & (8 * xb + dr < 18) & ((xb & 1) ? xok1 : xok0);
+      const unsigned off = (unsigned)((gy * a.Wx + ix0 + 8 * xb) * cs * 2) + ((xb & 1) ? xlane1 : xlane0);
+      lds_dma16(rx, ok ? off : WSENT, __builtin_amdgcn_readfirstlane(dst));
+    } else {
+      const int q = pc - XPIECES, h = q >> 3, qq = q & 7;  // 8-pixel block of the dy tile: output row qq >> 1, pixels 8 (qq & 1) ..
+      const int gy = i_oy0 + (qq >> 1), gx = i_ox0 + 8 * (qq & 1) + dr;
+      const bool ok = (gy < a.Hy) & (gx < a.Wy);
+      const unsigned off = (unsigned)((gy * a.Wy + i_ox0 + 8 * (qq & 1)) * a.cdy * 2) + ((qq & 1) ? dlane1 : dlane0) + (unsigned)(h * 128);
+      lds_dma16(rd, ok ? off : WSENT, __builtin_amdgcn_readfirstlane(dst));
+    }
+  };
+  auto issue_all = [&]() {
+    issue_piece(std::integral_constant<int, 0>{}); issue_piece(std::integral_constant<int, 1>{}); issue_piece(std::integral_constant<int, 2>{});
+    issue_piece(std::integral_constant<int, 3>{}); issue_piece(std::integral_constant<int, 4>{});
+  };
+  // this wave's pieces per tile: waves with wave < PIECES % 8 own one more
+  auto wait_own_in_flight = [&]() {  // all but the newest tile's own pieces have landed
+    if (wave < (PIECES & 7)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXOWN) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXOWN - 1) : "memory");
+  };
+
+  f32x4 acc[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // lane-constant fragment bases (absolute LDS bytes of the CURRENT stage; stepped by one stage per tile)
+  const int g1 = grp >> 1, xb0 = 8 * (grp & 1) + qp, sub = 8 * (pp & 1);
+  unsigned dbase[2][2], xbase[KS][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {  // channel tiles c and c + 2 differ by +512 bytes
+    dbase[c][0] = lds0 + X_BYTES + nh * DH_BYTES + swz_off(g1 * 16 + xb0, 2 * c + (pp >> 1)) + sub;
+    dbase[c][1] = lds0 + X_BYTES + nh * DH_BYTES + swz_off(g1 * 16 + xb0 + 4, 2 * c + (pp >> 1)) + sub;
+  }
+#pragma unroll
+  for (int kw = 0; kw < KS; ++kw) {
+    xbase[kw][0] = lds0 + g1 * XROW + swz_off(xb0 + kw, 2 * kq + (pp >> 1)) + sub;
+    xbase[kw][1] = lds0 + g1 * XROW + swz_off(xb0 + kw + 4, 2 * kq + (pp >> 1)) + sub;
+  }
+
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  int tile = by;
+  int t_tx, t_ty, t_img;  // digits of the NEXT tile to issue
+  { int tt = tile; t_tx = tt % a.tiles_x; tt /= a.tiles_x; t_ty = tt % a.tiles_y; t_img = tt / a.tiles_y; }
+  int d_tx, d_ty, d_img;
+  { int tt = a.ksplit; d_tx = tt % a.tiles_x; tt /= a.tiles_x; d_ty = tt % a.tiles_y; d_img = tt / a.tiles_y; }
+  auto advance = [&]() {
+    t_tx += d_tx; if (t_tx >= a.tiles_x) { t_tx -= a.tiles_x; t_ty += 1; }
+    t_ty += d_ty; if (t_ty >= a.tiles_y) { t_ty -= a.tiles_y; t_img += 1; }
+    t_img += d_img;
+  };
+  int issue_tile = tile;       // index of the next tile to issue
+  unsigned issue_stage = 0;    // ring slot it goes to
+  // prologue: two tiles in flight
+#pragma unroll 1
+  for (int s = 0; s < 2; ++s) {
+    if (issue_tile < ntiles) { prepare(t_img, t_ty, t_tx, lds0 + issue_stage * STAGE); issue_all(); advance(); }
+    issue_tile += a.ksplit;
+    issue_stage = issue_stage == NSTAGE - 1 ? 0 : issue_stage + 1;
+  }
+  if (tile + a.ksplit < ntiles) wait_own_in_flight(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int stage = 0;
+  for (; tile < ntiles; tile += a.ksplit) {
+    const bool more = issue_tile < ntiles;  // uniform
+    if (more) { prepare(t_img, t_ty, t_tx, lds0 + issue_stage * STAGE); advance(); }
+    issue_tile += a.ksplit;
+    issue_stage = issue_stage == NSTAGE - 1 ? 0 : issue_stage + 1;
+
+    u32x4 af[2][4], bf[3];
+    auto load_a = [&](int kb, int c) -> u32x4 {
+      const s16x4 lo = tr_read_at(dbase[c & 1][0] + 512 * (c >> 1) + 4096 * kb);
+      const s16x4 hi = tr_read_at(dbase[c & 1][1] + 512 * (c >> 1) + 4096 * kb);
+      return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto load_b = [&](int step) -> u32x4 {  // step = kb * 9 + tap
+      const int kb = step / TAPS, t = step % TAPS, kh = t / KS, kw = t % KS;
+      const s16x4 lo = tr_read_at(xbase[kw][0] + XROW * (2 * kb + kh));
+      const s16x4 hi = tr_read_at(xbase[kw][1] + XROW * (2 * kb + kh));
+      return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) af[0][c] = load_a(0, c);
+    bf[0] = load_b(0);
+    bf[1] = load_b(1);
+#pragma unroll
+    for (int step = 0; step < 2 * TAPS; ++step) {
+      const int kb = step / TAPS, t = step % TAPS;
+      if (step + 2 < 2 * TAPS) bf[(step + 2) % 3] = load_b(step + 2);
+      if (kb == 0 && t >= 5 && t <= 8) af[1][t - 5] = load_a(1, t - 5);  // second row block's dy fragments behind the first's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kb][c]), __builtin_bit_cast(bf16x8, bf[step % 3]),
+                                                            acc[t][c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // the pieces of tile t + 2 behind the MFMAs of steps 1, 4, 7, 10, 13
+      if (more) {
+        if (step == 1) issue_piece(std::integral_constant<int, 0>{});
+        if (step == 4) issue_piece(std::integral_constant<int, 1>{});
+        if (step == 7) issue_piece(std::integral_constant<int, 2>{});
+        if (step == 10) issue_piece(std::integral_constant<int, 3>{});
+        if (step == 13) issue_piece(std::integral_constant<int, 4>{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // next stage's fragment bases
+    const int delta = stage == NSTAGE - 1 ? -(NSTAGE - 1) * STAGE : STAGE;
+    stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { dbase[c][0] += delta; dbase[c][1] += delta; }
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw) { xbase[kw][0] += delta; xbase[kw][1] += delta; }
+    if (more) wait_own_in_flight(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  float* slab = a.slabs + (size_t)by * TAPS * a.npad * a.kpad;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 64 * nh + c * 16 + 4 * grp + r, k = k0 + kq * 16 + i16;
+        if (kloc + kq * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+      }
+}
+
 // ---------------------------------------------------------------- fp32
 template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgArgs a) {
@@ -1168,7 +1396,11 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   const int th = wgrad_tile_h(o, mode, dtype, hy, fast);
   a.tiles_y = ceil_div(hy, th);
   a.tiles_x = ceil_div(wy, 16);
-  if (fast && th == 4 && mode == MODE_W3S1) {
+  if (fast && th == 4 && mode == MODE_W3S1 && o.wgrad_bt && cdy % 128 == 0 && npad % 128 == 0) {
+    // 512-thread workgroups on 128 n x 64 k blocks: half as many column blocks
+    dim3 bgrid(fgrid.x / 2, fgrid.y);
+    hipLaunchKernelGGL(wgrad_bf16_bt_kernel, bgrid, dim3(512), 0, st, a);
+  } else if (fast && th == 4 && mode == MODE_W3S1) {
     hipLaunchKernelGGL(wgrad_bf16_dma_kernel, fgrid, dim3(256), 0, st, a);
   } else if (fast && wgrad_two_wg(o, mode, dtype)) {  // stride-2 / transposed shapes stay on the one-workgroup-per-CU kernel
     hipLaunchKernelGGL(wgrad_bf16_2wg_kernel<8>, fgrid, dim3(256), 0, st, a);

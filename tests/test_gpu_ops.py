@@ -675,6 +675,18 @@ def test_conv_bt_matches_tile_kernel_and_reference(case):
     assert (on[0] - off[0]).abs().max().item() <= 2 ** -7 * off[0].abs().max().item()
     assert (on[2] - off[2]).abs().max().item() <= 2 ** -7 * off[2].abs().max().item()
     assert torch.allclose(on[1], off[1], rtol=1e-4, atol=1e-3 * off[1].abs().max().item())
+    # weight gradient: the 512-thread 128 x 64 block kernel (option wgrad_bt; >= 128 output channels) against the ring kernel
+    # it replaces and against the fp32 reference (fp32 slabs of exact bf16 products: summation order only)
+    from mia_hip import WGRAD_3S1
+    try:
+        mia_hip.set_option("wgrad_bt", 1)
+        dw_on = ops.conv_wgrad(WGRAD_3S1, x1, x2, dyd, wt.shape, cout, cin)
+        mia_hip.set_option("wgrad_bt", 0)
+        dw_off = ops.conv_wgrad(WGRAD_3S1, x1, x2, dyd, wt.shape, cout, cin)
+    finally:
+        mia_hip.set_option("wgrad_bt", 1)
+    assert relerr(dw_on, wr.grad) < 1e-4 and relerr(dw_off, wr.grad) < 1e-4
+    assert torch.allclose(dw_on, dw_off, rtol=1e-4, atol=1e-4 * dw_off.abs().max().item())
 
 
 @pytest.mark.gpu
