@@ -1057,6 +1057,187 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_bt_kernel(const WgArgs a) {
       }
 }
 
+// ---------------------------------------------------------------- bf16, 512-thread big block, 3x3 STRIDE 2 (cdy % 128 == 0)
+// The stride-2 weight gradient (first conv of every encoder level, unet.py:57) ran on wgrad_bf16_fast_kernel<MODE_W3S2>: 436
+// registers = one wave per SIMD, register staging, two barriers per tile, 0.5 PFLOP/s.  Same block and wave roles as
+// wgrad_bf16_bt_kernel (128 n x 64 k x 9 taps, waves = 2 n halves x 4 k tiles); differences:
+//   * x tile of 4 output rows x 16 pixels = 9 input rows x 33 pixels, kept as [9 rows][40-pixel pitch][64 ch] (45 pieces of 8
+//     pixels x 128 B, swizzled within a row like the stride-1 image): the pitch is a multiple of 8 pixels, so a tap row (kh) and a
+//     row block (kb) are IMMEDIATE offsets of the transposing reads (5 KB, 20 KB): six lane-constant bases (kw x the two 4-pixel
+//     halves of a fragment) serve all 36 x reads of a tile.
+//     A transposing read takes its four K rows from four lane-supplied addresses, so the stride-2 pixel gather costs nothing;
+//   * 61 KB per stage -> a ring of TWO stages (122 KB): tile t + 1 is issued during the first MFMA steps of tile t and waited
+//     for (vmcnt(0)) at its end.
+__global__ __launch_bounds__(512, 2) void wgrad_bf16_bt_s2_kernel(const WgArgs a) {
+  constexpr int KS = 3, TAPS = 9, TH = 4;
+  constexpr int XH = 2 * TH + 1, XBLK = 5, XROW = XBLK * 1024, XW = 33;  // 9 rows x 5 blocks of 8 pixels (33 used) x 128 B
+  constexpr int X_BYTES = XH * XROW, DH_BYTES = TH * 16 * 128, D_BYTES = 2 * DH_BYTES, STAGE = X_BYTES + D_BYTES, NSTAGE = 2;
+  constexpr int XPIECES = XH * XBLK, DPIECES = TH * 2, PIECES = XPIECES + 2 * DPIECES;  // 45 + 8 + 8: piece pc lives at byte 1024 pc
+  constexpr int MAXOWN = (PIECES + 7) / 8;                                              // 8 (waves 0-4) or 7 pieces per wave and tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nh = wave >> 2, kq = wave & 3;
+  const int grp = lane >> 4, i16 = lane & 15, qp = i16 >> 2, pp = i16 & 3;
+  const int kb1 = (a.c1 + 63) / 64, nkb = kb1 + (a.c2 + 63) / 64;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (a.opt & 16) {
+    const int ncol = nkb * (a.npad / 128), slot = bx >> 3;
+    by = (slot / ncol) * 8 + (bx & 7);
+    bx = slot % ncol;
+    if (by >= a.ksplit) return;
+  }
+  const int kblk = bx % nkb, nblk = bx / nkb;
+  const bool second = kblk >= kb1;
+  const int cs = second ? a.c2 : a.c1, kloc = (second ? kblk - kb1 : kblk) * 64;
+  const int n0 = nblk * 128, k0 = (second ? a.c1 : 0) + kloc;
+  const bf16_t* xsrc = static_cast<const bf16_t*>(second ? a.x2 : a.x1);
+  const bf16_t* dy = static_cast<const bf16_t*>(a.dy);
+  const size_t xpix = (size_t)a.Hx * a.Wx, ypix = (size_t)a.Hy * a.Wy;
+
+  // DMA lane constants: lane L of a piece = 16-byte chunk (L&3) of half (L>>5) of pixel row (L>>2)&7 of the 8-pixel block; the
+  // source chunk is un-swizzled by the block's parity within its image row
+  const int dr = (lane >> 2) & 7;
+  const int ch8_0 = 4 * (lane >> 5) + ((lane & 3) ^ ((dr >> 2) & 3)), ch8_1 = 4 * (lane >> 5) + ((lane & 3) ^ ((2 + (dr >> 2)) & 3));
+  const unsigned xlane0 = (unsigned)((dr * cs + kloc + ch8_0 * 8) * 2), xlane1 = (unsigned)((dr * cs + kloc + ch8_1 * 8) * 2);
+  const unsigned dlane0 = (unsigned)((dr * a.cdy + n0 + ch8_0 * 8) * 2), dlane1 = (unsigned)((dr * a.cdy + n0 + ch8_1 * 8) * 2);
+  const bool xok0 = kloc + ch8_0 * 8 < cs, xok1 = kloc + ch8_1 * 8 < cs;
+  const unsigned lds0 = (unsigned)(size_t)(lds_u8*)smem;
+
+  // ---- issue state of the tile being fetched
+  wi32x4 rx, rd;
+  int i_oy0 = 0, i_ox0 = 0;
+  unsigned i_stage = 0;
+  auto prepare = [&](int img, int ty, int tx, unsigned stage_base) {
+    i_oy0 = ty * TH; i_ox0 = tx * 16; i_stage = stage_base;
+    rx = wmake_rsrc_i(xsrc + (size_t)img * xpix * cs, (unsigned)(xpix * cs * 2));
+    rd = wmake_rsrc_i(dy + (size_t)img * ypix * a.cdy, (unsigned)(ypix * a.cdy * 2));
+  };
+  auto issue_piece = [&](auto jc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    const int pc = wave + 8 * j;  // wave-uniform piece index
+    if (pc >= PIECES) return;
+    const unsigned dst = i_stage + pc * 1024;
+    if (pc < XPIECES) {
+      const int iy = pc / XBLK, xb = pc - XBLK * iy;
+      const int iy0 = 2 * i_oy0 - 1, ix0 = 2 * i_ox0 - 1;
+      const int gy = iy0 + iy, gx = ix0 + 8 * xb + dr;
+      const bool ok = ((unsigned)gy < (unsigned)a.Hx) & ((unsigned)gx < (unsigned)a.Wx) & (8 * xb + dr < XW) & ((xb & 1) ? xok1 : xok0);
+      const unsigned off = (unsigned)((gy * a.Wx + ix0 + 8 * xb) * cs * 2) + ((xb & 1) ? xlane1 : xlane0);
+      lds_dma16(rx, ok ? off : WSENT, __builtin_amdgcn_readfirstlane(dst));
+    } else {
+      const int q = pc - XPIECES, h = q >> 3, qq = q & 7;  // 8-pixel block of the dy tile: output row qq >> 1, pixels 8 (qq & 1) ..
+      const int gy = i_oy0 + (qq >> 1), gx = i_ox0 + 8 * (qq & 1) + dr;
+      const bool ok = (gy < a.Hy) & (gx < a.Wy);
+      const unsigned off = (unsigned)((gy * a.Wy + i_ox0 + 8 * (qq & 1)) * a.cdy * 2) + ((qq & 1) ? dlane1 : dlane0) + (unsigned)(h * 128);
+      lds_dma16(rd, ok ? off : WSENT, __builtin_amdgcn_readfirstlane(dst));
+    }
+  };
+#define WG_PIECE(J) issue_piece(std::integral_constant<int, J>{})
+
+  f32x4 acc[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // lane-constant fragment bases (absolute LDS bytes of stage 0; the stage offset is added per tile)
+  const int g1 = grp >> 1, xb0 = 8 * (grp & 1) + qp, sub = 8 * (pp & 1);
+  unsigned dbase[2][2], xbase[KS][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {  // channel tiles c and c + 2 differ by +512 bytes
+    dbase[c][0] = lds0 + X_BYTES + nh * DH_BYTES + swz_off(g1 * 16 + xb0, 2 * c + (pp >> 1)) + sub;
+    dbase[c][1] = lds0 + X_BYTES + nh * DH_BYTES + swz_off(g1 * 16 + xb0 + 4, 2 * c + (pp >> 1)) + sub;
+  }
+#pragma unroll
+  for (int kw = 0; kw < KS; ++kw) {  // input row 4 kb + 2 g1 + kh, input column 2 (output pixel) + kw; +4 output pixels = +8 columns
+    xbase[kw][0] = lds0 + 2 * g1 * XROW + swz_off(2 * xb0 + kw, 2 * kq + (pp >> 1)) + sub;
+    xbase[kw][1] = lds0 + 2 * g1 * XROW + swz_off(2 * xb0 + kw + 8, 2 * kq + (pp >> 1)) + sub;  // (+8 flips the swizzle's bit 1)
+  }
+
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  int tile = by;
+  int t_tx, t_ty, t_img;  // digits of the NEXT tile to issue
+  { int tt = tile; t_tx = tt % a.tiles_x; tt /= a.tiles_x; t_ty = tt % a.tiles_y; t_img = tt / a.tiles_y; }
+  int d_tx, d_ty, d_img;
+  { int tt = a.ksplit; d_tx = tt % a.tiles_x; tt /= a.tiles_x; d_ty = tt % a.tiles_y; d_img = tt / a.tiles_y; }
+  auto advance = [&]() {
+    t_tx += d_tx; if (t_tx >= a.tiles_x) { t_tx -= a.tiles_x; t_ty += 1; }
+    t_ty += d_ty; if (t_ty >= a.tiles_y) { t_ty -= a.tiles_y; t_img += 1; }
+    t_img += d_img;
+  };
+  int issue_tile = tile;
+  unsigned stage = 0;  // stage the CURRENT tile is read from
+  if (issue_tile < ntiles) {
+    prepare(t_img, t_ty, t_tx, lds0);
+    WG_PIECE(0); WG_PIECE(1); WG_PIECE(2); WG_PIECE(3); WG_PIECE(4); WG_PIECE(5); WG_PIECE(6); WG_PIECE(7);
+    advance();
+  }
+  issue_tile += a.ksplit;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (; tile < ntiles; tile += a.ksplit) {
+    const bool more = issue_tile < ntiles;  // uniform
+    if (more) { prepare(t_img, t_ty, t_tx, lds0 + (stage ^ 1) * STAGE); advance(); }
+    issue_tile += a.ksplit;
+    const unsigned so = stage * STAGE;
+
+    u32x4 af[2][4], bf[3];
+    auto load_a = [&](int kb, int c) -> u32x4 {
+      const s16x4 lo = tr_read_at(dbase[c & 1][0] + so + 512 * (c >> 1) + 4096 * kb);
+      const s16x4 hi = tr_read_at(dbase[c & 1][1] + so + 512 * (c >> 1) + 4096 * kb);
+      return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto load_b = [&](int step) -> u32x4 {  // step = kb * 9 + tap
+      const int kb = step / TAPS, t = step % TAPS, kh = t / KS, kw = t % KS;
+      const s16x4 lo = tr_read_at(xbase[kw][0] + so + XROW * (4 * kb + kh));
+      const s16x4 hi = tr_read_at(xbase[kw][1] + so + XROW * (4 * kb + kh));
+      return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) af[0][c] = load_a(0, c);
+    bf[0] = load_b(0);
+    bf[1] = load_b(1);
+#pragma unroll
+    for (int step = 0; step < 2 * TAPS; ++step) {
+      const int kb = step / TAPS, t = step % TAPS;
+      if (step + 2 < 2 * TAPS) bf[(step + 2) % 3] = load_b(step + 2);
+      if (kb == 0 && t >= 5 && t <= 8) af[1][t - 5] = load_a(1, t - 5);  // second row block's dy fragments behind the first's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kb][c]), __builtin_bit_cast(bf16x8, bf[step % 3]),
+                                                            acc[t][c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // tile t + 1: two pieces behind each of the first four steps, so that they have the rest of the tile to land
+      if (more) {
+        if (step == 0) { WG_PIECE(0); WG_PIECE(1); }
+        if (step == 1) { WG_PIECE(2); WG_PIECE(3); }
+        if (step == 2) { WG_PIECE(4); WG_PIECE(5); }
+        if (step == 3) { WG_PIECE(6); WG_PIECE(7); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    stage ^= 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#undef WG_PIECE
+  float* slab = a.slabs + (size_t)by * TAPS * a.npad * a.kpad;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 64 * nh + c * 16 + 4 * grp + r, k = k0 + kq * 16 + i16;
+        if (kloc + kq * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+      }
+}
+
 // ---------------------------------------------------------------- fp32
 template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgArgs a) {
@@ -1349,6 +1530,7 @@ static bool wgrad_two_wg(const MiaOptions& o, int mode, int dtype) {  // option 
 extern "C" int mia_wgrad_target_blocks(int mode, int dtype) {
   const MiaOptions o = mia_options();
   if (wgrad_two_wg(o, mode, dtype)) return 512;
+  if (mode == MODE_W3S2 && dtype == MIA_BF16 && o.wgrad_bt && o.wgrad_dma) return 512;  // 128 n x 64 k blocks: half as many column blocks
   if (mode == MODE_W2S2 && dtype == MIA_BF16 && o.wgrad_w8 != 0) return 512;  // 4 taps: 172 registers, 40 KB LDS -> two workgroups fit a CU
   return 256;
 }
@@ -1400,6 +1582,9 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
     // 512-thread workgroups on 128 n x 64 k blocks: half as many column blocks
     dim3 bgrid(fgrid.x / 2, fgrid.y);
     hipLaunchKernelGGL(wgrad_bf16_bt_kernel, bgrid, dim3(512), 0, st, a);
+  } else if (fast && th == 4 && mode == MODE_W3S2 && o.wgrad_bt && cdy % 128 == 0 && npad % 128 == 0) {
+    dim3 bgrid(fgrid.x / 2, fgrid.y);
+    hipLaunchKernelGGL(wgrad_bf16_bt_s2_kernel, bgrid, dim3(512), 0, st, a);
   } else if (fast && th == 4 && mode == MODE_W3S1) {
     hipLaunchKernelGGL(wgrad_bf16_dma_kernel, fgrid, dim3(256), 0, st, a);
   } else if (fast && wgrad_two_wg(o, mode, dtype)) {  // stride-2 / transposed shapes stay on the one-workgroup-per-CU kernel

@@ -755,3 +755,32 @@ def test_norm_streams_wide_bf16_vs_fp32_cpu(c, hw, norm, pieces):
     if norm == "batch":
         np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * y.mean((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * y.var((0, 2, 3), unbiased=True)).numpy(), rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 128, 40, 72), (1, 128, 256, 17, 33), (1, 256, 512, 64, 64), (3, 96, 384, 23, 41),
+                                  (1, 512, 1024, 9, 16), (1, 64, 128, 130, 260)])
+def test_wgrad_bt_stride2_matches_fast_kernel_and_reference(case):
+    """Weight gradient of the stride-2 3x3 conv (first block of an encoder level, unet.py:57) on the 512-thread LDS-DMA kernel
+    (wgrad_bf16_bt_s2_kernel; option wgrad_bt) against the register-staged kernel it replaces and fp32-CPU autograd on shared bf16
+    operands: ragged tiles, odd sizes, several split-K rounds, more tiles than workgroups."""
+    import mia_hip
+    from mia_hip import WGRAD_3S2, ops
+    dev = _dev()
+    n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(cin + h)
+    x = q(torch.randn(n, cin, h, w, generator=g), torch.bfloat16)
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    dy = q(torch.randn(n, cout, ho, wo, generator=g), torch.bfloat16)
+    wr = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(x, wr, None, stride=2, padding=1).backward(dy)
+    xd, dyd = nhwc(x, torch.bfloat16, dev), nhwc(dy, torch.bfloat16, dev)
+    try:
+        mia_hip.set_option("wgrad_bt", 1)
+        on = ops.conv_wgrad(WGRAD_3S2, xd, None, dyd, wr.shape, cout, cin)
+        mia_hip.set_option("wgrad_bt", 0)
+        off = ops.conv_wgrad(WGRAD_3S2, xd, None, dyd, wr.shape, cout, cin)
+    finally:
+        mia_hip.set_option("wgrad_bt", 1)
+    assert relerr(on, wr.grad) < 1e-4 and relerr(off, wr.grad) < 1e-4
+    assert torch.allclose(on, off, rtol=1e-4, atol=1e-4 * off.abs().max().item())
