@@ -390,13 +390,31 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
     }
   };
   // statistics partials of the tile (after its last step): per-channel sum and sum of squares over the valid pixels
-  auto tile_stats = [&](const BtWork& t, const OutState& o) __attribute__((always_inline)) {
+  // EARLY: variants with registers to spare (odd NCT, MT = 4) accumulate the per-lane sums row by row inside the final step
+  // (stats_row, behind that step's MFMAs) -- the 96-channel launches of cfg5 have 9 steps per tile, where the ~2k cycles of
+  // packed adds after the K loop weigh 6 %; at NCT = 4 / MT = 8 the 32 extra live registers would spill.
+  constexpr bool EARLY = (NCT % 2 == 1) || MT == 4;
+  struct LaneStats { float s1[NCT][4], s2[NCT][4]; };
+  auto stats_row = [&](LaneStats& ls, const OutState& o, int m) __attribute__((always_inline)) {
+    const float wgt = (o.full || (o.colok && o.wy0 + m < a.Hout)) ? 1.f : 0.f;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[m][ct][r], vm = o.full ? v : v * wgt;
+        ls.s1[ct][r] += vm; ls.s2[ct][r] += vm * v;
+      }
+  };
+  auto tile_stats = [&](const BtWork& t, const OutState& o, const LaneStats& ls) __attribute__((always_inline)) {
     float* red = reinterpret_cast<float*>(smem + G::RED);  // [wave][16 NCT channels][2]
     const int lane = lane_id(), q = lane >> 4, n16 = lane & 15;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-      if (o.full) {
+      if (EARLY) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[r] = ls.s1[ct][r]; s2[r] = ls.s2[ct][r]; }
+      } else if (o.full) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -477,6 +495,7 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
   auto no_row = [&](int) __attribute__((always_inline)) {};
   using F = std::false_type;
   using T = std::true_type;
+  const bool want_stats = a.stats != nullptr;  // uniform
   bool first = true;
   while (true) {
     const int wnext = w + (int)gridDim.x;
@@ -523,10 +542,22 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
       BSTAMP(z1); BACC(d_bar, z1, z4);
       // step (c, 2): weights of (following chunk, 1); in the last chunk the tile is stored row by row as its rows complete
       OutState os;
-      if (last) os = out_state(cur);
+      LaneStats ls;
+      if (last) {
+        os = out_state(cur);
+        if (EARLY) {
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ls.s1[ct][r] = 0.f; ls.s2[ct][r] = 0.f; }
+        }
+      }
       compute(TB2{}, lastc, imgoff, [&](int k) __attribute__((always_inline)) {
         if (k < WPW && pre) issue_w1(wlane, cn, 1, k);
-      }, [&](int m) __attribute__((always_inline)) { store_row(os, m); });
+      }, [&](int m) __attribute__((always_inline)) {
+        store_row(os, m);
+        if (EARLY && want_stats) stats_row(ls, os, m);
+      });
       BSTAMP(z3);
 #ifdef CONV64_STAMPS
       if (last) d_fin += z3 - z1; else d_cmp += z3 - z1;
@@ -543,7 +574,7 @@ __global__ __launch_bounds__(512, 2) void conv_bt_kernel(const ConvArgs a, int p
       ++gchunk;
       if (last) {
         BSTAMP(z0);
-        if (a.stats != nullptr) tile_stats(cur, os);
+        if (want_stats) tile_stats(cur, os, ls);
         BSTAMP(z1); BACC(d_epi, z1, z0);
       }
     };
