@@ -71,6 +71,9 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
  *   conv_bt (MIA_CONV_BT, 1)       wide stride-1 3x3 bf16 convs on the 512-thread big-tile LDS-DMA kernel (0: tile kernel)
  *   conv_bt_order (MIA_CONV_BT_ORDER, 1)   its work-item order: 1 = the channel blocks of a pixel tile run together on one XCD
  *   conv64 (MIA_CONV64, 1)         64 -> 64 channel bf16 3x3 stride-1 launches on the persistent register-weight kernel
+ *   conv64_dma (MIA_CONV64_DMA, 1) the 512-thread LDS-DMA 64-channel kernel: 1 = the 64 -> (64 | 64) two-destination input
+ *                                  gradient in one pass (measured 7 % faster than two conv64 passes), 2 = also plain
+ *                                  64 -> 64 launches (measured 6-11 % slower than conv64_persist_kernel), 0 = never
  *   conv64_blocks (MIA_CONV64_BLOCKS, 0 = 512)   its workgroup count (diagnostics)
  *   conv_xcd / wgrad_xcd (MIA_CONV_XCD / MIA_WGRAD_XCD, 1)   blocks sharing an input tile run on one XCD (0: plain grid order)
  *   conv_mt8 (MIA_CONV_MT8, 0)     32-row tiles of the tile kernel (experiment)

@@ -65,3 +65,8 @@ int conv64_launch(const ConvArgs& a, int blocks_override, hipStream_t st);
 // of the network, the decoder's two-source convs, cfg5's 96-multiples); false = shape outside its contract.
 bool conv_bt_eligible(int mode, int dtype, const ConvArgs& a);
 int conv_bt_launch(const ConvArgs& a, int order /* option conv_bt_order: 1 = tile-major item order */, hipStream_t st);
+
+// conv64_dma.hip: second generation of the 64 -> 64 (| 64) kernel: 512 threads per CU, LDS-DMA ring of three input tiles, one
+// barrier per tile; both destinations of a two-destination input gradient in one pass.
+bool conv64_dma_eligible(int mode, int dtype, const ConvArgs& a);
+int conv64_dma_launch(const ConvArgs& a, hipStream_t st);

@@ -9,6 +9,7 @@
 struct MiaOptions {
   int conv_xcd;       // XCD-aware block order of conv_mma_fast_kernel                         env MIA_CONV_XCD      default 1
   int conv64;         // persistent register-weight kernel for 64 -> 64 3x3 bf16               env MIA_CONV64        default 1
+  int conv64_dma;     // 512-thread LDS-DMA 64-channel kernel: 1 two-destination 64 -> (64|64) launches only, 2 every 64 -> 64 launch, 0 never   env MIA_CONV64_DMA   default 1
   int conv_bt;        // big-tile LDS-DMA kernel for the wide stride-1 3x3 bf16 convs          env MIA_CONV_BT       default 1
   int conv_bt_order;  // item order of conv_bt_kernel: 1 = a tile's channel blocks together on one XCD, 0 = channel block slow   env MIA_CONV_BT_ORDER default 1
   int conv_mt8;       // 32-row tiles of the tile kernel (experiment)                          env MIA_CONV_MT8      default 0

@@ -23,6 +23,7 @@ Entry g_table[] = {
     {"stem_mfma", "MIA_STEM_MFMA", 1, 0, 1, {1}},
     {"conv_bt_order", "MIA_CONV_BT_ORDER", 1, 0, 1, {1}},
     {"wgrad_bt", "MIA_WGRAD_BT", 1, 0, 1, {1}},
+    {"conv64_dma", "MIA_CONV64_DMA", 1, 0, 2, {1}},
 };
 constexpr int N_OPT = (int)(sizeof(g_table) / sizeof(g_table[0]));
 std::once_flag g_env_once;
@@ -52,7 +53,7 @@ MiaOptions mia_options() {
   MiaOptions o;
   o.conv_xcd = get(0); o.conv64 = get(1); o.conv_bt = get(2); o.conv_mt8 = get(3); o.conv64_blocks = get(4);
   o.wgrad_xcd = get(5); o.wgrad_dma = get(6); o.wgrad_tab = get(7); o.wgrad_w8 = get(8); o.stream_blocks = get(9);
-  o.stem_mfma = get(10); o.conv_bt_order = get(11); o.wgrad_bt = get(12);
+  o.stem_mfma = get(10); o.conv_bt_order = get(11); o.wgrad_bt = get(12); o.conv64_dma = get(13);
   return o;
 }
 

@@ -61,6 +61,7 @@ CONV_CASES = [
     (1, 64, 0, 64, 9, 200),
     (3, 64, 0, 64, 200, 216),
     (2, 32, 32, 64, 40, 56),  # input gradient = 64 -> (32 | 32): stays on the generic kernel
+    (2, 64, 64, 64, 37, 53),  # input gradient = 64 -> (64 | 64): one pass of conv64_dma_kernel<128>, ragged tiles
 ]
 
 
@@ -578,7 +579,7 @@ def test_plain_block_two_output_gradients_are_summed_on_load(norm, dtype, c):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knob", ["conv_xcd", "conv64", "wgrad_xcd", "wgrad_dma"])
+@pytest.mark.parametrize("knob", ["conv_xcd", "conv64", "conv64_dma", "wgrad_xcd", "wgrad_dma"])
 def test_kernel_selection_knobs_do_not_change_results(knob):
     """mia_set_option knobs pick kernels / block orders only: the forward and input-gradient results are bit-identical either
     way (same per-element operation order), the weight gradient agrees to fp32 summation order."""
@@ -603,14 +604,15 @@ def test_kernel_selection_knobs_do_not_change_results(knob):
         dw = ops.conv_wgrad(WGRAD_3S1, x, None, dy, w.shape, 64, 64)
         return y.float().clone(), st.sum(1).clone(), up.float().clone(), dw.clone()
 
+    default = mia_hip.get_option(knob)
     try:
-        lib.mia_set_option(knob.encode(), 1)
+        lib.mia_set_option(knob.encode(), 2 if knob == "conv64_dma" else 1)  # conv64_dma = 2: also the plain 64 -> 64 launches
         on = run()
         lib.mia_set_option(knob.encode(), 0)
         off = run()
     finally:
-        lib.mia_set_option(knob.encode(), 1)
-    if knob != "conv64":  # the persistent 64-channel kernel accumulates taps in another order than the tile kernel
+        lib.mia_set_option(knob.encode(), default)
+    if knob not in ("conv64", "conv64_dma"):  # the 64-channel kernels accumulate taps in another order than the tile kernel / each other
         assert torch.equal(on[0], off[0])
     else:
         assert (on[0] - off[0]).abs().max().item() <= 2e-2 * off[0].abs().max().item()

@@ -25,12 +25,14 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--inner", type=int, default=4)
+    ap.add_argument("--on", type=int, default=1, help="value of the '1' arm (e.g. conv64_dma 2)")
     a = ap.parse_args()
     import mia_hip
     from mia_hip import BF16, CONV_G3S1, ops
     dev = torch.device("cuda:0")
     lib = mia_hip.lib()
     opt = a.option.encode()
+    default = mia_hip.get_option(a.option)
     tot = {0: 0.0, 1: 0.0}
     flops = 0.0
     for lvl in range(a.levels):
@@ -57,7 +59,7 @@ def main():
             times = {0: [], 1: []}
             for r in range(a.rounds):
                 for flag in ((0, 1) if r % 2 else (1, 0)):
-                    lib.mia_set_option(opt, flag)
+                    lib.mia_set_option(opt, a.on if flag else 0)
                     fn()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -73,7 +75,7 @@ def main():
             flops += fl
             print(f"level {lvl} {name:11s} C={c:4d} {s:3d}x{s:3d}: {a.option}=0 {m0:.3f} ms {fl / m0 / 1e9:7.1f} TF | =1 {m1:.3f} ms {fl / m1 / 1e9:7.1f} TF | ratio {m1 / m0:.3f}",
                   flush=True)
-    lib.mia_set_option(opt, 1)
+    lib.mia_set_option(opt, default)
     print(f"sum: {a.option}=0 {tot[0]:.3f} ms ({flops / tot[0] / 1e9:.0f} TF) | =1 {tot[1]:.3f} ms ({flops / tot[1] / 1e9:.0f} TF) | ratio {tot[1] / tot[0]:.3f}")
 
 

@@ -94,7 +94,40 @@ def bt():
             print(f"{nm:26s} {(d[..., i][live] / tiles[live]).mean():9.0f} cycles / tile / wave")
 
 
+def c64dma():
+    """Phases of conv64_dma_kernel: python tools/conv64_stamps.py c64dma [dgrad]"""
+    os.environ["MIA_HIP_LIB"] = os.path.join(OUT, "libmia_hip_stamps.so")
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import numpy as np
+    import torch
+    import mia_hip
+    from mia_hip import CONV_G3S1, ops
+    dev = torch.device("cuda:0")
+    x = torch.randn(32, 512, 512, 64, device=dev).to(torch.bfloat16)
+    w = (torch.randn(64, 64, 3, 3, device=dev) / 24)
+    b = torch.randn(64, device=dev)
+    dg = "dgrad" in sys.argv
+    mia_hip.set_option("conv64_dma", 2)
+    wp, npad, kpad = ops.PackCache().get(w, mia_hip.BF16, not dg)
+    for _ in range(3):
+        ops.conv_mma(CONV_G3S1, x, None, wp, npad, kpad, dg, None if dg else b, 64, (512, 512), want_stats=not dg)
+    torch.cuda.synchronize()
+    l = ctypes.CDLL(os.environ["MIA_HIP_LIB"])
+    buf = np.zeros(256 * 8 * 8, dtype=np.uint64)
+    assert l.mia_conv64_dma_debug_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    d = buf.reshape(256, 8, 8).astype(np.float64)
+    n = d[..., 5]
+    live = n > 0
+    print(f"--- conv64_dma {'dgrad' if dg else 'fwd+stats'}: tiles/wg {n[live].mean():.0f} (MFMA floor per tile and wave: 144 x 16 = 2304 cycles)")
+    for i, nm in enumerate(["head (combine, decode)", "reads + MFMAs (+ slices)", "tail (copy / epilogue)", "vmcnt + lgkm wait", "barrier"]):
+        print(f"{nm:26s} {(d[..., i][live] / n[live]).mean():9.0f} cycles / tile / wave   (waves 0-3 {(d[:, :4, i][live[:, :4]] / n[:, :4][live[:, :4]]).mean():.0f}, 4-7 {(d[:, 4:, i][live[:, 4:]] / n[:, 4:][live[:, 4:]]).mean():.0f})")
+
+
 def main():
+    if "c64dma" in sys.argv:
+        return c64dma()
     if "bt" in sys.argv:
         return bt()
     if "build" in sys.argv:
