@@ -12,6 +12,7 @@ struct ConvArgs {
   int N, Hin, Win, Hout, Wout;
   int npad, kpad, flip;
   int tiles_x, tiles_y, nblk_n;
+  int st_tiles_y;  // rows of the statistics tile grid (8-row tiles under the 512-thread stride-2 kernel's 16-row tiles; else = tiles_y)
   int vec_in, vec_out;
   int xcd;  // fast kernel: XCD-aware block order (the blocks that share an input tile run on one XCD, back to back)
 };
@@ -70,3 +71,8 @@ int conv_bt_launch(const ConvArgs& a, int order /* option conv_bt_order: 1 = til
 // barrier per tile; both destinations of a two-destination input gradient in one pass.
 bool conv64_dma_eligible(int mode, int dtype, const ConvArgs& a);
 int conv64_dma_launch(const ConvArgs& a, hipStream_t st);
+
+// conv_pw.hip: ConvTranspose2d 2x2 / stride 2 forward (MODE_T2S2) and input gradient (MODE_G2S2), bf16, as one pointwise GEMM
+// per launch (512 threads per CU, LDS-DMA ring of three 64-wide K stages); false = shape outside its contract.
+bool conv_pw_eligible(int mode, int dtype, const ConvArgs& a);
+int conv_pw_launch(int mode, const ConvArgs& a, hipStream_t st);

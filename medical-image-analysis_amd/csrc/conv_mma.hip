@@ -330,10 +330,11 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
   a.npad = npad; a.kpad = kpad; a.flip = flip_taps;
   int th;
   mia_conv_mma_tiles(mode, hout, wout, &a.tiles_y, &a.tiles_x, &th);
-  const int mt = th / 4;
+  int mt = th / 4;
   const int nout = o1 + o2;
   const int nt = nout > 32 ? 4 : (nout > 16 ? 2 : 1);
   a.nblk_n = ceil_div(nout, 16 * nt);
+  a.st_tiles_y = a.tiles_y;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vec_in = (c1 % epu == 0) && (c2 % epu == 0) && al16(in1) && (in2 == nullptr || al16(in2));
   a.vec_out = (o1 % epu == 0) && (o2 % epu == 0) && al16(out1) && (out2 == nullptr || al16(out2));
@@ -343,6 +344,15 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;
   const bool fast = conv_mma_fast_eligible(dtype, a, nt);
+  // stride-2 3x3 forward, bf16, 128-multiples of output channels: 512-thread workgroups on 16-row tiles (two statistics tiles each)
+  // (measured per level, tools/s2_levels.py: 14-20 % faster from 128 input channels on; at 64 the two-chunk K loop leaves
+  // the lone workgroup's prologue / epilogue exposed: 0.63 vs 0.62 ms, so the two-workgroups-per-CU shape keeps that launch)
+  if (opt.conv_s2_wide && fast && mode == MODE_G3S2 && dtype == MIA_BF16 && nout % 128 == 0 && o1 % 128 == 0 && hout > 8 &&
+      (c1 + c2 >= 128 || opt.conv_s2_wide >= 2)) {
+    mt = 4;
+    a.tiles_y = ceil_div(hout, 16);
+    a.nblk_n = nout / 128;
+  }
   if (mt == 8 && !(fast && dtype == MIA_BF16 && nt == 4 && mode == MODE_G3S1)) {
     mia_set_error("mia_conv_mma: MIA_CONV_MT8 tiles need the bf16 fast path with >= 64 output channels");
     return MIA_EUNSUPPORTED;
@@ -351,6 +361,7 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
   if (opt.conv64 && opt.conv64_dma && (opt.conv64_dma >= 2 || a.o2 != 0) && mt == 4 && conv64_dma_eligible(mode, dtype, a)) rc = conv64_dma_launch(a, st);
   else if (opt.conv64 && mt == 4 && conv64_eligible(mode, dtype, a)) rc = conv64_launch(a, opt.conv64_blocks, st);
   else if (opt.conv_bt && mt == 4 && conv_bt_eligible(mode, dtype, a)) rc = conv_bt_launch(a, opt.conv_bt_order, st);
+  else if (opt.conv_pw && conv_pw_eligible(mode, dtype, a)) rc = conv_pw_launch(mode, a, st);
   else if (fast) rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
   else rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);
   if (rc != MIA_OK) return rc;

@@ -17,29 +17,35 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
-template <typename T, int MODE, int MT, int NT>
-__global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(const ConvArgs a) {
+// WC = 2 (stride-2 3x3 forward, bf16): 512 threads, the eight waves are 4 row groups x 2 halves of a 128-channel block on a
+// 16-row tile -- each wave owns 4 x 4 accumulators (8 fragment reads per 16 MFMAs instead of 6 per 8: the 256-thread
+// 8-row shape saturates the LDS pipe), one workgroup per CU.  The statistics stay in the host's 8-row tile layout.
+template <typename T, int MODE, int MT, int NT, int WC = 1>
+__global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_mma_fast_kernel(const ConvArgs a) {
   using G = Geo<MODE, MT>;
-  constexpr int TH = G::TH, BN = 16 * NT, EPU = Elem<T>::EPU, KB = 4 * EPU, ES = (int)sizeof(T);
+  constexpr int NTHR = 256 * WC, PL = 64 * WC;  // threads; pixel lanes (x 4 channel groups) of a staging iteration
+  constexpr int TH = G::TH, BN = 16 * NT * WC, EPU = Elem<T>::EPU, KB = 4 * EPU, ES = (int)sizeof(T);
   constexpr int PITCH = G::PITCH, S = G::S, IW = G::IW, IH = G::IH;
-  constexpr int A_IT = (IH * IW + 63) / 64;  // 64 pixels (x 4 channel groups) per staging iteration
-  constexpr int NPIX_ALLOC = (S == 1) ? (A_IT * 64 > G::NPIX ? A_IT * 64 : G::NPIX) : G::NPIX + 1;  // S==2: +1 dummy slot
+  constexpr int A_IT = (IH * IW + PL - 1) / PL;  // PL pixels (x 4 channel groups) per staging iteration
+  constexpr int NPIX_ALLOC = (S == 1) ? (A_IT * PL > G::NPIX ? A_IT * PL : G::NPIX) : G::NPIX + 1;  // S==2: +1 dummy slot
   constexpr int NPA = ((NPIX_ALLOC + 13) / 16) * 16 + 2;
   constexpr int NPB = BN + 2;
-  constexpr int TPI = 64 / BN;  // taps staged per iteration
+  constexpr int TPI = PL / BN;  // taps staged per iteration
   constexpr int B_IT = (G::MAXTAPS + TPI - 1) / TPI;
   constexpr int OSTR = BN + EPU;
   constexpr int A_UNITS = 4 * NPA, B_UNITS = B_IT * TPI * 4 * NPB;
   constexpr int STAGE_BYTES = (A_UNITS + B_UNITS) * 16;
   constexpr int OUT_BYTES = TH * 16 * OSTR * ES;
   constexpr int LDS_BYTES = STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES;
+  static_assert(PL % BN == 0 && TPI >= 1, "weight staging deals whole taps");
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + 2 * 4 * BN * 4];
   u32x4* ldsA = reinterpret_cast<u32x4*>(smem);
   u32x4* ldsB = ldsA + A_UNITS;
   T* ldsO = reinterpret_cast<T*>(smem);
   float* ldsR = reinterpret_cast<float*>(smem + LDS_BYTES);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (tid >> 6) & 3, wc = tid >> 8;  // row group; channel half (WC == 2)
   const int q = lane >> 4, r16 = lane & 15;
   const int pr = pi16(r16);
   const int g = tid & 3, p4 = tid >> 2;
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
   int a_lds[S == 2 ? A_IT : 1];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const int pix = p4 + 64 * i;
+    const int pix = p4 + PL * i;
     const int iy = pix / IW, ix = pix - iy * IW;
     const int gy = iy0 + iy, gx = ix0 + ix;
     const bool ok = pix < IH * IW && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
   const int bn_ = p4 % BN, tsub = p4 / BN;
   // weight staging offsets.  3x3 / stride 1 with a 64-channel output block stages exactly one tap per iteration: the tap
   // stride is uniform and rides in the load's scalar offset, so one thread-dependent offset serves all nine loads
-  constexpr bool LINB = (MODE == MODE_G3S1 && TPI == 1);
+  constexpr bool LINB = ((MODE == MODE_G3S1 || MODE == MODE_G3S2) && TPI == 1);
   const int wtap_bytes = a.npad * a.kpad * ES;
   unsigned b_voff[LINB ? 1 : B_IT];
   if constexpr (LINB) {
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
   float bv[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    int bi = n0 + n * 16 + pr;
+    int bi = n0 + (wc * NT + n) * 16 + pr;
     bi = bi < nout ? bi : nout - 1;
     bv[n] = a.bias ? a.bias[bi] : 0.f;
   }
@@ -155,14 +161,14 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       if constexpr (LINB)
-        pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)b_voff[0], c0 * ES + (a.flip ? 8 - i : i) * wtap_bytes, 0);
+        pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)b_voff[0], c0 * ES + ((MODE == MODE_G3S1 && a.flip) ? 8 - i : i) * wtap_bytes, 0);
       else
         pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)b_voff[i], c0 * ES, 0);
     }
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) ldsA[g * NPA + (S == 2 ? a_lds[i] : p4 + 64 * i)] = pa[i];
+    for (int i = 0; i < A_IT; ++i) ldsA[g * NPA + (S == 2 ? a_lds[i] : p4 + PL * i)] = pa[i];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) ldsB[((i * TPI + tsub) * 4 + g) * NPB + bn_] = pb[i];
   };
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
           const int toff = tap_off(ta, tb);
           u32x4 bf[NT], af[MT];
 #pragma unroll
-          for (int n = 0; n < NT; ++n) bf[n] = ldsB[(tl * 4 + q) * NPB + n * 16 + pr];
+          for (int n = 0; n < NT; ++n) bf[n] = ldsB[(tl * 4 + q) * NPB + (wc * NT + n) * 16 + pr];
 #pragma unroll
           for (int m = 0; m < MT; ++m) af[m] = ldsA[q * NPA + S * (wave * MT + m) * PITCH + toff + pr];
 #pragma unroll
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
       auto load_row = [&](int j, int tb, u32x4* f) { f[j] = ldsA[q * NPA + (wave * MT + j) * PITCH + tb + pr]; };
       auto load_b = [&](int tl, u32x4* b) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) b[n] = ldsB[(tl * 4 + q) * NPB + n * 16 + pr];
+        for (int n = 0; n < NT; ++n) b[n] = ldsB[(tl * 4 + q) * NPB + (wc * NT + n) * 16 + pr];
       };
 #pragma unroll
       for (int j = 0; j < ROWS; ++j) load_row(j, 0, fr[0]);
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
       auto load_tap = [&](int tl, u32x4* bfr, u32x4* afr) {
         const int toff = tap_off(tl / KSW, tl % KSW);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bfr[n] = ldsB[(tl * 4 + q) * NPB + n * 16 + pr];
+        for (int n = 0; n < NT; ++n) bfr[n] = ldsB[(tl * 4 + q) * NPB + (wc * NT + n) * 16 + pr];
 #pragma unroll
         for (int m = 0; m < MT; ++m) afr[m] = ldsA[q * NPA + S * (wave * MT + m) * PITCH + toff + pr];
       };
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
           const float vm = full ? v : v * (rm * cmask[r]);
           s1[n] += vm; s2[n] += vm * v;
         }
-        ldsO[rowoff[r] + m * 16 * OSTR + n * 16] = Elem<T>::cvt(v);
+        ldsO[rowoff[r] + m * 16 * OSTR + (wc * NT + n) * 16] = Elem<T>::cvt(v);
       }
     }
   }
@@ -284,22 +290,35 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
       float t1 = s1[n], t2 = s2[n];
       t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
       t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
-      if (q == 0) { ldsR[(0 * 4 + wave) * BN + n * 16 + pr] = t1; ldsR[(1 * 4 + wave) * BN + n * 16 + pr] = t2; }
+      if (q == 0) { ldsR[(0 * 4 + wave) * BN + (wc * NT + n) * 16 + pr] = t1; ldsR[(1 * 4 + wave) * BN + (wc * NT + n) * 16 + pr] = t2; }
     }
   }
   __syncthreads();
-  if (a.stats != nullptr && tid < BN && n0 + tid < nout) {
-    const float t1 = ldsR[0 * BN + tid] + ldsR[1 * BN + tid] + ldsR[2 * BN + tid] + ldsR[3 * BN + tid];
-    const float t2 = ldsR[4 * BN + tid] + ldsR[5 * BN + tid] + ldsR[6 * BN + tid] + ldsR[7 * BN + tid];
-    const size_t tile = (size_t)img * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx;
-    // global (not flat) store: a flat access makes the compiler drain every outstanding memory operation around it
-    typedef __attribute__((address_space(1))) float gfloat;
-    gfloat* dst = (gfloat*)(a.stats + (tile * nout + n0 + tid) * 2);
-    dst[0] = t1; dst[1] = t2;
+  typedef __attribute__((address_space(1))) float gfloat;  // global (not flat) stores: a flat access makes the compiler drain every outstanding memory operation around it
+  if constexpr (WC == 1) {
+    if (a.stats != nullptr && tid < BN && n0 + tid < nout) {
+      const float t1 = ldsR[0 * BN + tid] + ldsR[1 * BN + tid] + ldsR[2 * BN + tid] + ldsR[3 * BN + tid];
+      const float t2 = ldsR[4 * BN + tid] + ldsR[5 * BN + tid] + ldsR[6 * BN + tid] + ldsR[7 * BN + tid];
+      const size_t tile = (size_t)img * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx;
+      gfloat* dst = (gfloat*)(a.stats + (tile * nout + n0 + tid) * 2);
+      dst[0] = t1; dst[1] = t2;
+    }
+  } else {
+    // the statistics keep the host's 8-row tile layout (mia_conv_mma_tiles): row groups {0, 1} and {2, 3} of the 16-row
+    // tile are two statistics tiles
+    static_assert(WC == 1 || (TH == 16 && 2 * BN <= NTHR), "two 8-row statistics tiles per 16-row tile");
+    const int half = tid / BN, ch = tid - half * BN;
+    if (a.stats != nullptr && tid < 2 * BN && n0 + ch < nout && 2 * ty + half < a.st_tiles_y) {
+      const float t1 = ldsR[(0 + 2 * half) * BN + ch] + ldsR[(1 + 2 * half) * BN + ch];
+      const float t2 = ldsR[(4 + 2 * half) * BN + ch] + ldsR[(5 + 2 * half) * BN + ch];
+      const size_t tile = (size_t)img * (a.tiles_x * a.st_tiles_y) + (2 * ty + half) * a.tiles_x + tx;
+      gfloat* dst = (gfloat*)(a.stats + (tile * nout + n0 + ch) * 2);
+      dst[0] = t1; dst[1] = t2;
+    }
   }
   // coalesced 16-byte stores.  A block's channel range normally lies in one destination; when the split point o1 is not
   // a multiple of BN the straddling block issues every store twice, once per destination, each masked to its own lanes.
-  constexpr int UPP = BN / EPU, PPI = 256 / UPP, O_IT = TH * 16 / PPI;
+  constexpr int UPP = BN / EPU, PPI = NTHR / UPP, O_IT = TH * 16 / PPI;
   const size_t opix = (size_t)a.Hout * a.Wout;
   const int cu = tid % UPP, pl0 = tid / UPP;
   const int y0 = pl0 >> 4, px = pl0 & 15;
@@ -326,14 +345,14 @@ __global__ __launch_bounds__(256, (MT >= 8 ? 1 : 2)) void conv_mma_fast_kernel(c
   if (second_part) store_to(true);
 }
 
-template <typename T, int MODE, int MT, int NT>
+template <typename T, int MODE, int MT, int NT, int WC = 1>
 static void flaunch(const ConvArgs& a, int grid_y, hipStream_t st) {
   int grid_x = a.N * a.tiles_x * a.tiles_y * a.nblk_n;
   if (a.xcd) {  // groups of (channel blocks x parity classes) per tile, tiles rounded up to a multiple of 8
     grid_x = ((a.N * a.tiles_x * a.tiles_y + 7) / 8) * 8 * a.nblk_n * grid_y;
     grid_y = 1;
   }
-  hipLaunchKernelGGL((conv_mma_fast_kernel<T, MODE, MT, NT>), dim3(grid_x, grid_y), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_mma_fast_kernel<T, MODE, MT, NT, WC>), dim3(grid_x, grid_y), dim3(256 * WC), 0, st, a);
 }
 template <typename T, int MODE, int MT>
 static void flaunch_nt(const ConvArgs& a, int nt, int grid_y, hipStream_t st) {
@@ -344,6 +363,9 @@ static void flaunch_nt(const ConvArgs& a, int nt, int grid_y, hipStream_t st) {
 template <typename T, int MODE>
 static void flaunch_mt(const ConvArgs& a, int mt, int nt, int grid_y, hipStream_t st) {
   if constexpr (MODE == MODE_G3S2 || MODE == MODE_G2S2) {
+    if constexpr (MODE == MODE_G3S2 && sizeof(T) == 2) {
+      if (mt == 4) { flaunch<T, MODE, 4, 4, 2>(a, grid_y, st); return; }  // 512-thread 16-row tile, 128-channel blocks
+    }
     flaunch_nt<T, MODE, 2>(a, nt, grid_y, st);
   } else {
     if constexpr (MODE == MODE_G3S1 && sizeof(T) == 2) {

@@ -1,0 +1,273 @@
+// ConvTranspose2d(kernel 2, stride 2) forward and input gradient for bf16, as ONE pointwise GEMM per launch on the LDS-DMA
+// pattern of conv_bt.hip.  Reference layer: the decoder's upsampling `nn.ConvTranspose2d(c_below, c, 2, 2)`
+// (src/models/unet/unet.py:142, applied at :212); its input gradient is what autograd runs for that module.
+//
+// A 2x2 / stride-2 transposed conv has no overlapping taps: every fine pixel (2i + ph, 2j + pw) is one tap (ph, pw) of the
+// coarse pixel (i, j).  So
+//   forward  (MODE_T2S2): out[p, tap * Cout + co] = bias[co] + sum_ci x[p, ci] W[tap][co][ci]        M = coarse pixels p = (n, i, j),
+//                         K = Cin, N = 4 Cout; the store scatters column block `tap` to fine pixel (2i + ph, 2j + pw);
+//   gradient (MODE_G2S2): dx[p, ci] = sum_tap sum_co dout[(n, 2i + ph, 2j + pw), co] W[tap][ci][co]  K = 4 Cout (the gather of the
+//                         four fine pixels is a per-tap scalar offset of the row address), N = Cin.
+// The 256-thread tile kernel ran these as one-tap 32-channel chunks: 16 (forward) / 32 (gradient) MFMAs per wave between two
+// barriers, the four parity classes as separate workgroups re-staging the same input tile.  Here ONE 512-thread workgroup per
+// CU owns a 256-pixel x 128-column block and walks K in 64-wide stages through a ring of three LDS stages (A 32 KB + B 16 KB),
+// every byte by LDS-DMA (`buffer_load_dwordx4 ... offen lds`, issued and counted in inline asm), one barrier per stage, the
+// ring running across work items (the next item's first stages are in flight during the epilogue).  MFMA operands swapped
+// (A = weights, B = pixels): a lane's accumulators are 8 consecutive channels of one pixel -> 16-byte stores straight from
+// registers.  Per stage and wave: 6 DMA pieces, 16 ds_read_b128, 32 MFMAs.
+//
+// LDS images, 128 bytes per row (64 k), eight 16-byte units per row, unit u of row r stored at (u ^ f(r)); both are
+// conflict-free for the 16-lane groups of ds_read_b128:
+//   pixels : rows r .. r + 15 of one fragment: f(r) = (r >> 1) & 7
+//   weights: fragment row i of channel fragment ct is local channel 32 (ct >> 1) + 8 (i >> 2) + 4 (ct & 1) + (i & 3) (so that the
+//            accumulators of fragments (ct, ct + 1) are 8 consecutive channels): f(r) = ((r >> 1) & 1) | (((r >> 3) & 3) << 1)
+// The DMA destination is lane-linear (one piece = 8 rows x 128 B), so the swizzle is applied on each lane's SOURCE address.
+//
+// Contract (conv_pw_eligible, otherwise the tile kernel runs): bf16, one source, one destination, no statistics; channels per
+// tap of the input % 64 == 0, K >= 128, N % 128 == 0, npad / kpad unpadded, tensors < 4 GiB, 16-byte aligned pointers.
+#include "conv_common.h"
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+#define PW_SENT 0xFFFFFFF0u /* always beyond num_records: loads return zero, stores are dropped */
+
+__device__ __forceinline__ i32x4 pw_rsrc_words(const void* p, unsigned bytes) {
+  const unsigned long long addr = (unsigned long long)p;
+  i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)addr);
+  r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(addr >> 32));
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+// One LDS-DMA piece: 64 lanes x 16 bytes, lane L lands at lds_dst + 16 L (see conv_bt.hip::dma16 for the M0 / s_nop notes).
+__device__ __forceinline__ void pw_dma16(i32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+  soff = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);        // wave-uniform by construction; tells hipcc so
+  lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void pw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+typedef float pw_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pw_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pw_pack(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(pw_f32x2{a, b}, pw_bf16x2));
+}
+
+constexpr int PW_TM = 256, PW_TN = 128;
+constexpr int PW_A = PW_TM * 128, PW_B = PW_TN * 128, PW_STAGE = PW_A + PW_B, PW_NSTAGE = 3;
+constexpr int PW_BIAS = PW_NSTAGE * PW_STAGE;  // two 1 KB slots: the bias of the item being computed / being fetched
+constexpr int PW_LDS = PW_BIAS + 2 * 1024;
+constexpr int PW_NSTORE = 8;                   // store instructions per wave and item
+
+}  // namespace
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int mtot, int wco, int nk, int mtiles, int nwork, int tile_major) {
+  constexpr bool TR = (MODE == MODE_T2S2);
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[PW_LDS];
+  const unsigned lds0 = (unsigned)(size_t)(lds_u8*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;  // 64-pixel quarter, 64-column half of the block
+  const int q = lane >> 4, r = lane & 15;
+  const int cin = a.c1;                     // channels per tap of the A tensor
+  const unsigned kpitch = (unsigned)a.kpad * 2u;
+  const int cpt = cin >> 6;                 // 64-wide stages per tap (MODE_G2S2)
+
+  const size_t in_bytes = (size_t)a.N * a.Hin * a.Win * a.c1 * 2, out_bytes = (size_t)a.N * a.Hout * a.Wout * a.o1 * 2;
+  const i32x4 rsA = pw_rsrc_words(a.in1, (unsigned)in_bytes);
+  const i32x4 rsW = pw_rsrc_words(a.wp, (unsigned)((size_t)4 * a.npad * a.kpad * 2));
+  const i32x4 rsB = pw_rsrc_words(TR ? (const void*)a.bias : a.wp, TR ? (unsigned)(a.o1 * 4) : 0u);
+  const rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.out1, 0, (int)(unsigned)out_bytes, 0x00020000);
+
+  struct Item { int m0, n0; };
+  auto decode = [&](int w) __attribute__((always_inline)) -> Item {
+    int cb, tile;
+    if (tile_major > 0) {  // the column blocks of a pixel tile take consecutive slots of one XCD (its A rows stay in that L2)
+      const int slot = w >> 3, grp = slot / tile_major;
+      cb = slot - grp * tile_major;
+      tile = grp * 8 + (w & 7);
+    } else {
+      cb = w / mtiles;
+      tile = w - cb * mtiles;
+    }
+    return Item{tile * PW_TM, cb * PW_TN};
+  };
+
+  // ---- issue side: the DMA lane offsets of the item being fetched
+  const int lr = lane >> 3;
+  const unsigned uA = (unsigned)((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7));
+  const unsigned uB = (unsigned)((lane & 7) ^ (((lane >> 4) & 1) | ((wave & 3) << 1)));
+  unsigned va[4], vb[2], vbias = PW_SENT;
+  auto setup_issue = [&](int w) __attribute__((always_inline)) {
+    const Item it = decode(w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = it.m0 + 8 * wave + 64 * k + lr;
+      unsigned base;
+      if (TR) base = (unsigned)p * (unsigned)(cin * 2);
+      else { const int j = p % wco; base = (unsigned)(4 * p - 2 * j) * (unsigned)(cin * 2); }  // fine pixel (n, 2i, 2j)
+      va[k] = p < mtot ? base + uA * 16u : PW_SENT;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) vb[k] = (unsigned)(it.n0 + 8 * wave + 64 * k + lr) * kpitch + uB * 16u;
+    if (TR) vbias = lane < 32 ? (unsigned)((it.n0 + 4 * lane) % a.o1) * 4u : PW_SENT;
+  };
+  int wi = blockIdx.x, ki = 0, itap = 0, icc = 0, islot = 0, ibias = 0;
+  bool ihave = wi < nwork;
+  if (ihave) setup_issue(wi);
+  auto issue_next = [&]() __attribute__((always_inline)) -> int {
+    if (!ihave) return 0;
+    unsigned soffA, soffB;
+    if (TR) { soffA = (unsigned)ki * 128u; soffB = soffA; }
+    else {
+      soffA = (unsigned)((itap >> 1) * a.Win + (itap & 1)) * (unsigned)(cin * 2) + (unsigned)icc * 128u;
+      soffB = (unsigned)itap * (unsigned)a.npad * kpitch + (unsigned)icc * 128u;
+    }
+    const unsigned dst = lds0 + (unsigned)islot * PW_STAGE + (unsigned)wave * 1024u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pw_dma16(rsA, va[k], soffA, dst + (unsigned)k * 8192u);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) pw_dma16(rsW, vb[k], soffB, dst + PW_A + (unsigned)k * 8192u);
+    int cnt = 6;
+    if (TR && ki == 0) { pw_dma16(rsB, vbias, 0u, lds0 + PW_BIAS + (unsigned)ibias * 1024u); ibias ^= 1; cnt = 7; }
+    islot = islot == PW_NSTAGE - 1 ? 0 : islot + 1;
+    ++ki;
+    if (!TR) { if (++icc == cpt) { icc = 0; ++itap; } }
+    if (ki == nk) {
+      ki = 0; itap = 0; icc = 0;
+      wi += gridDim.x;
+      ihave = wi < nwork;
+      if (ihave) setup_issue(wi);
+    }
+    return cnt;
+  };
+
+  // ---- compute side: fragment addresses (stage-relative); k-step 1 of a stage is the same address ^ 64
+  const unsigned pfrag = (unsigned)((wm * 64 + r) * 128 + ((q ^ ((r >> 1) & 7)) * 16));
+  const unsigned wfrag = (unsigned)(PW_A + (wn * 64 + 8 * (r >> 2) + (r & 3)) * 128 + ((q ^ (((r & 3) >> 1) | ((r >> 2) << 1))) * 16));
+
+  issue_next();
+  issue_next();  // nk >= 2: the first item's second stage, 6 pieces
+  pw_wait_vm<6>();
+  __builtin_amdgcn_s_barrier();
+
+  int cslot = 0, cbias = 0;
+  bool after_epilogue = false;
+  for (int wcur = blockIdx.x; wcur < nwork; wcur += gridDim.x) {
+    const Item it = decode(wcur);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int pf = 0; pf < 4; ++pf) acc[ct][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kc = 0; kc < nk; ++kc) {
+      const int cnt = issue_next();
+      const unsigned char* st = smem + cslot * PW_STAGE;
+      u32x4 wf[2][4], pfr[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          wf[ks][ct] = *reinterpret_cast<const u32x4*>(st + ((wfrag + (unsigned)((32 * (ct >> 1) + 4 * (ct & 1)) * 128)) ^ (unsigned)(ks * 64)));
+#pragma unroll
+        for (int pf = 0; pf < 4; ++pf)
+          pfr[ks][pf] = *reinterpret_cast<const u32x4*>(st + ((pfrag + (unsigned)(pf * 2048)) ^ (unsigned)(ks * 64)));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+          for (int pf = 0; pf < 4; ++pf)
+            acc[ct][pf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks][ct]), __builtin_bit_cast(bf16x8, pfr[ks][pf]),
+                                                                  acc[ct][pf], 0, 0, 0);
+      cslot = cslot == PW_NSTAGE - 1 ? 0 : cslot + 1;
+      // own pieces of the stage after next may stay in flight (and the previous item's stores, issued between the two)
+      if (cnt == 0) pw_wait_vm<0>();
+      else if (after_epilogue) { if (cnt == 7) pw_wait_vm<7 + PW_NSTORE>(); else pw_wait_vm<6 + PW_NSTORE>(); }
+      else { if (cnt == 7) pw_wait_vm<7>(); else pw_wait_vm<6>(); }
+      after_epilogue = false;
+
+      if (kc == nk - 1) {  // ---- epilogue: 8 consecutive channels per lane and fragment pair, 16-byte stores
+        const int ncol = it.n0 + wn * 64;              // first GEMM column of this wave
+        int tap = 0, co0 = ncol;
+        if (TR) { tap = ncol / a.o1; co0 = ncol - tap * a.o1; }
+        const unsigned tapoff = TR ? (unsigned)((tap >> 1) * a.Wout + (tap & 1)) : 0u;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          float bv[8];
+          if (TR) {
+            const float* bl = reinterpret_cast<const float*>(smem + PW_BIAS + cbias * 1024) + wn * 64 + 32 * pr + 8 * q;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl), b1 = *reinterpret_cast<const f32x4*>(bl + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+          }
+#pragma unroll
+          for (int pf = 0; pf < 4; ++pf) {
+            const int p = it.m0 + wm * 64 + pf * 16 + r;
+            unsigned pix;
+            if (TR) { const int j = p % wco; pix = (unsigned)(4 * p - 2 * j) + tapoff; }
+            else pix = (unsigned)p;
+            const unsigned voff = p < mtot ? (pix * (unsigned)a.o1 + (unsigned)(co0 + 32 * pr + 8 * q)) * 2u : PW_SENT;
+            const f32x4 lo = acc[2 * pr][pf], hi = acc[2 * pr + 1][pf];
+            u32x4 d;
+            d.x = pw_pack(lo[0] + bv[0], lo[1] + bv[1]); d.y = pw_pack(lo[2] + bv[2], lo[3] + bv[3]);
+            d.z = pw_pack(hi[0] + bv[4], hi[1] + bv[5]); d.w = pw_pack(hi[2] + bv[6], hi[3] + bv[7]);
+            __builtin_amdgcn_raw_buffer_store_b128(d, rsO, (int)voff, 0, 0);
+          }
+        }
+        cbias ^= 1;
+        after_epilogue = true;
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+}
+
+bool conv_pw_eligible(int mode, int dtype, const ConvArgs& a) {
+  if (dtype != MIA_BF16 || (mode != MODE_T2S2 && mode != MODE_G2S2)) return false;
+  if (a.c2 != 0 || a.o2 != 0 || a.stats != nullptr || !a.vec_in || !a.vec_out) return false;
+  if (a.c1 % 64 != 0 || a.kpad != a.c1 || a.npad != a.o1) return false;
+  const int ntot = mode == MODE_T2S2 ? 4 * a.o1 : a.o1, ktot = mode == MODE_T2S2 ? a.c1 : 4 * a.c1;
+  if (ntot % PW_TN != 0 || ktot < 128 || a.o1 % 64 != 0) return false;
+  if ((mode == MODE_T2S2) != (a.bias != nullptr)) return false;  // forward carries the bias, the gradient none
+  const size_t lim = ((size_t)1 << 32) - ((size_t)1 << 20);
+  if ((size_t)a.N * a.Hin * a.Win * a.c1 * 2 >= lim || (size_t)a.N * a.Hout * a.Wout * a.o1 * 2 >= lim) return false;
+  if ((size_t)4 * a.npad * a.kpad * 2 >= ((size_t)1 << 31)) return false;
+  return true;
+}
+
+static int pw_num_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    return v;
+  }();
+  return n;
+}
+
+int conv_pw_launch(int mode, const ConvArgs& a, hipStream_t st) {
+  const bool tr = mode == MODE_T2S2;
+  const int hco = tr ? a.Hin : a.Hout, wco = tr ? a.Win : a.Wout;  // the coarse grid
+  const int mtot = a.N * hco * wco;
+  const int nk = (tr ? a.c1 : 4 * a.c1) / 64;
+  const int nblocks = (tr ? 4 * a.o1 : a.o1) / PW_TN;
+  const int mtiles = ceil_div(mtot, PW_TM);
+  const int nwork = mtiles * nblocks;
+  const int tile_major = (nblocks > 1 && mtiles % 8 == 0) ? nblocks : 0;
+  const int ncu = pw_num_cus();
+  const dim3 grid(nwork < ncu ? nwork : ncu);
+  if (tr) hipLaunchKernelGGL(conv_pw_kernel<MODE_T2S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
+  else hipLaunchKernelGGL(conv_pw_kernel<MODE_G2S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
+  return MIA_OK;
+}

@@ -756,7 +756,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) 
 
   int stage = 0;
 #ifdef CONV64_STAMPS
-  unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, a_i = 0, a_m = 0, a_w = 0, a_b = 0, a_n = 0;
+  unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, a_i = 0, a_m = 0, a_w = 0, a_b = 0, a_n = 0, c_t0, c_r0, c_t1, c_r1;
+  WSTAMP(c_t0);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_r0)::"memory");
 #endif
   for (; tile < ntiles; tile += a.ksplit) {
     WSTAMP(w0);
@@ -814,7 +816,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) 
 #ifdef CONV64_STAMPS
   if (lane == 0 && bx == 0 && by < 512) {
     unsigned long long* d = wgrad_dbg + ((size_t)by * 4 + wave) * 8;
-    d[0] = a_i; d[1] = a_m; d[2] = a_w; d[3] = a_b; d[4] = 0; d[5] = a_n;
+    WSTAMP(c_t1);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_r1)::"memory");
+    d[0] = a_i; d[1] = a_m; d[2] = a_w; d[3] = a_b; d[4] = 0; d[5] = a_n; d[6] = c_t1 - c_t0; d[7] = c_r1 - c_r0;
   }
 #endif
   float* slab = a.slabs + (size_t)by * TAPS * a.npad * a.kpad;
@@ -1534,6 +1538,19 @@ extern "C" int mia_wgrad_target_blocks(int mode, int dtype) {
   if (mode == MODE_W2S2 && dtype == MIA_BF16 && o.wgrad_w8 != 0) return 512;  // 4 taps: 172 registers, 40 KB LDS -> two workgroups fit a CU
   return 256;
 }
+
+#ifdef CONV64_STAMPS
+/* Diagnostic build only: workgroups of each persistent weight-gradient kernel the runtime keeps resident on one CU. */
+extern "C" int mia_wgrad_debug_occupancy(int which) {
+  int n = -1;
+  hipError_t e = hipErrorInvalidValue;
+  if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_bf16_dma_kernel, 256, 0);
+  else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_bf16_bt_kernel, 512, 0);
+  else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_bf16_bt_s2_kernel, 512, 0);
+  else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_bf16_2wg_kernel<8>, 256, 0);
+  return e == hipSuccess ? n : -1;
+}
+#endif
 
 extern "C" int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x) {
   const int th = wgrad_tile_h(mia_options(), mode, dtype, hy, true);  // the finest tiling any kernel of this mode uses (bounds ksplit)

@@ -12,6 +12,8 @@ struct MiaOptions {
   int conv64_dma;     // 512-thread LDS-DMA 64-channel kernel: 1 two-destination 64 -> (64|64) launches only, 2 every 64 -> 64 launch, 0 never   env MIA_CONV64_DMA   default 1
   int conv_bt;        // big-tile LDS-DMA kernel for the wide stride-1 3x3 bf16 convs          env MIA_CONV_BT       default 1
   int conv_bt_order;  // item order of conv_bt_kernel: 1 = a tile's channel blocks together on one XCD, 0 = channel block slow   env MIA_CONV_BT_ORDER default 1
+  int conv_s2_wide;   // stride-2 3x3 bf16 forward with 128-multiples of output channels on 512-thread 16-row tiles (1: from 128 input channels on, 2: always)   env MIA_CONV_S2_WIDE  default 1
+  int conv_pw;        // ConvTranspose 2x2 stride 2 forward / input gradient (bf16) as one pointwise GEMM on the LDS-DMA ring   env MIA_CONV_PW       default 1
   int conv_mt8;       // 32-row tiles of the tile kernel (experiment)                          env MIA_CONV_MT8      default 0
   int conv64_blocks;  // workgroups of conv64_persist_kernel, 0 = library default (512)        env MIA_CONV64_BLOCKS default 0
   int wgrad_xcd;      // XCD-aware block order of the bf16 weight-gradient kernels             env MIA_WGRAD_XCD     default 1

@@ -621,6 +621,94 @@ def test_kernel_selection_knobs_do_not_change_results(knob):
     assert torch.allclose(on[3], off[3], rtol=1e-4, atol=1e-4 * off[3].abs().max().item())
 
 
+PW_CASES = [  # n, cin, cout, h, w (coarse): ConvTranspose2d(cin -> cout, 2, 2) on conv_pw_kernel -- 64 outputs (a 128-column block
+    # spans two taps), ragged last pixel tile, pixel tiles not a multiple of 8 (column-block-slow item order), odd widths,
+    # more items than CUs, K = 128 (two stages per item) and K = 1024
+    (2, 128, 64, 64, 64), (1, 128, 64, 7, 9), (3, 256, 128, 20, 13), (1, 1024, 512, 8, 8), (1, 512, 256, 16, 16), (4, 128, 64, 128, 96),
+    (1, 192, 96, 24, 24),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", PW_CASES)
+def test_conv_pw_matches_tile_kernel_and_reference(case):
+    """Option conv_pw (csrc/conv_pw.hip): the forward accumulates K in the same order as the tile kernel -> bit-identical; the
+    input gradient sums (tap, channel) in another order -> fp32 rounding only.  Both against F.conv_transpose2d on the
+    bf16-quantised operands (reference: unet.py:142 / :212)."""
+    import mia_hip
+    from mia_hip import BF16, CONV_G2S2, CONV_T2S2, ops
+    dev = _dev()
+    n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(sum(case))
+    dt = torch.bfloat16
+    x = q(torch.randn(n, cin, h, w, generator=g), dt)
+    wt = torch.randn(cin, cout, 2, 2, generator=g) / math.sqrt(cin)
+    b = torch.randn(cout, generator=g)
+    dy = q(torch.randn(n, cout, 2 * h, 2 * w, generator=g), dt)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, q(wt, dt), b, stride=2)
+    yr.backward(dy)
+    xd, dyd, wd = nhwc(x, dt, dev), nhwc(dy, dt, dev), wt.to(dev)
+    pc = ops.PackCache()
+    wf, nf, kf = pc.get(wd, BF16, False)
+    wb, nb, kb = pc.get(wd, BF16, True)
+    outs = {}
+    try:
+        for flag in (1, 0):
+            mia_hip.set_option("conv_pw", flag)
+            y, _, _ = ops.conv_mma(CONV_T2S2, xd, None, wf, nf, kf, False, b.to(dev), cout, (2 * h, 2 * w))
+            dx, _, _ = ops.conv_mma(CONV_G2S2, dyd, None, wb, nb, kb, False, None, cin, (h, w))
+            torch.cuda.synchronize()
+            outs[flag] = (y.clone(), dx.clone())
+    finally:
+        mia_hip.set_option("conv_pw", 1)
+    assert torch.equal(outs[1][0], outs[0][0])
+    assert relerr(outs[1][1].float(), outs[0][1].float()) < 1e-2  # one bf16 ulp (2^-8) where the fp32 sums round apart
+    assert relerr(nchw(outs[1][0]), yr) < TOL[dt]
+    assert relerr(nchw(outs[1][1]), xr.grad) < TOL[dt]
+
+
+S2_WIDE_CASES = [  # n, cin, cout, h, w: 512-thread stride-2 kernel (128-multiples of output channels), ragged 16-row tiles, odd sizes
+    (2, 64, 128, 80, 72), (1, 128, 256, 37, 53), (1, 32, 128, 18, 200), (3, 64, 128, 34, 34), (1, 256, 512, 32, 32),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", S2_WIDE_CASES)
+def test_conv_s2_wide_matches_tile_kernel_and_reference(case):
+    """Option conv_s2_wide (csrc/conv_mma_fast.hip, WC = 2): same chunk / tap order per output element as the 256-thread tile
+    kernel -> bit-identical outputs; the 8-row statistics tiles are summed from other partials (fp32 order).  Both against
+    F.conv2d on the bf16-quantised operands (reference: unet.py:57-66, the strided first block of an encoder level)."""
+    import mia_hip
+    from mia_hip import BF16, CONV_G3S2, ops
+    dev = _dev()
+    n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = q(torch.randn(n, cin, h, w, generator=g), torch.bfloat16)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    yr = F.conv2d(x, q(wt, torch.bfloat16), b, stride=2, padding=1)
+    xd = nhwc(x, torch.bfloat16, dev)
+    wp, npad, kpad = ops.PackCache().get(wt.to(dev), BF16, True)
+    outs = {}
+    try:
+        for flag in (1, 0):
+            mia_hip.set_option("conv_s2_wide", 2 * flag)  # 2: also below 128 input channels
+            y, _, st = ops.conv_mma(CONV_G3S2, xd, None, wp, npad, kpad, False, b.to(dev), cout, (ho, wo), want_stats=True)
+            torch.cuda.synchronize()
+            outs[flag] = (y.clone(), st.clone())
+    finally:
+        mia_hip.set_option("conv_s2_wide", 1)
+    assert torch.equal(outs[1][0], outs[0][0])
+    assert outs[1][1].shape == outs[0][1].shape
+    assert torch.allclose(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-2)
+    assert relerr(nchw(outs[1][0]), yr) < TOL[torch.bfloat16]
+    s = outs[1][1].sum(1).cpu()
+    assert relerr(s[..., 0], yr.sum((2, 3))) < 1e-3 + TOL[torch.bfloat16]
+    assert relerr(s[..., 1], (yr ** 2).sum((2, 3))) < 1e-3 + TOL[torch.bfloat16]
+
+
 BT_CASES = [
     # n, c1, c2, cout, h, w  -- conv_bt.hip: 128 / 96 / 64-channel blocks, ragged 16 x 32 tiles, two sources, two destinations,
     # one tile per workgroup and several (persistent work list: more items than CUs), maps of one tile row

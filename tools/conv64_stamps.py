@@ -38,7 +38,15 @@ def wgrad():
     for _ in range(3):
         ops.conv_wgrad(WGRAD_3S1, x, None, dy, (64, 64, 3, 3), 64, 64)
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.conv_wgrad(WGRAD_3S1, x, None, dy, (64, 64, 3, 3), 64, 64)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"one call (kernel + slab reduce) with stamps: {e0.elapsed_time(e1):.3f} ms")
     l = ctypes.CDLL(os.environ["MIA_HIP_LIB"])
+    print("resident workgroups per CU (runtime occupancy query): dma", l.mia_wgrad_debug_occupancy(0), "bt", l.mia_wgrad_debug_occupancy(1),
+          "bt_s2", l.mia_wgrad_debug_occupancy(2), "2wg", l.mia_wgrad_debug_occupancy(3))
     buf = np.zeros(512 * 4 * 8, dtype=np.uint64)
     assert l.mia_wgrad_debug_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
     d = buf.reshape(512, 4, 8).astype(np.float64)
@@ -53,6 +61,9 @@ def wgrad():
         tot += per
         print(f"{nm:26s} {per:9.0f} cycles / tile / wave")
     print(f"{'sum':26s} {tot:9.0f}   (tiles per workgroup {n[live].mean():.1f}; MFMA issue floor 144 x 16 = 2304)")
+    if d[..., 7][live].min() > 0:
+        clk = (d[..., 6][live] / d[..., 7][live]) * 0.1
+        print(f"loop of one workgroup: {(d[..., 7][live] * 0.01).mean():.1f} us wall (s_memrealtime), in-kernel clock {np.median(clk):.2f} GHz")
 
 
 def bt():
@@ -152,6 +163,8 @@ def main():
         ops.conv_mma(CONV_G3S1, x, None, wp, npad, kpad, False, b, 64, (512, 512), want_stats=True)
     torch.cuda.synchronize()
     l = ctypes.CDLL(os.environ["MIA_HIP_LIB"])
+    print("resident workgroups per CU (runtime occupancy query): dma", l.mia_wgrad_debug_occupancy(0), "bt", l.mia_wgrad_debug_occupancy(1),
+          "bt_s2", l.mia_wgrad_debug_occupancy(2), "2wg", l.mia_wgrad_debug_occupancy(3))
     buf = np.zeros(512 * 4 * 8, dtype=np.uint64)
     rc = l.mia_conv64_debug_read(buf.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0, rc

@@ -60,7 +60,7 @@ def main():
                               2.0 * 4 * c * 2 * c * px_c, by_f + by_c),
             "convT dgrad  ": (lambda: ops.conv_mma(CONV_G2S2, fine, None, wtb, ntb, ktb, False, None, 2 * c, (h, h)),
                               2.0 * 4 * c * 2 * c * px_c, by_f + by_c),
-            "convT wgrad  ": (lambda: ops.conv_wgrad(WGRAD_2S2, fine, None, coarse, wt.shape, c, 2 * c),
+            "convT wgrad  ": (lambda: ops.conv_wgrad(WGRAD_2S2, fine, None, coarse, wt.shape, 2 * c, c),
                               2.0 * 4 * c * 2 * c * px_c, by_f + by_c),
         }
         for name, (fn, fl, by) in runs.items():
