@@ -23,22 +23,47 @@
 //  K2  grid (16-channel group): lanes sweep images.  Instance norm: coefficients per (n,c).  Batch norm: combine
 //      over the batch (with the Dropout2d masks folded in), update running statistics, then per-(n,c) coefficients.
 // ysum[N][C] (optional) keeps sum(y) for the closed-form conv-bias gradient of the backward pass.
-__global__ void norm_fwd_sum_kernel(const float* __restrict__ part, int tiles, int c, float* __restrict__ xa, float* __restrict__ xb) {
-  __shared__ double sh1[16][17], sh2[16][17];
+// INST: instance norm needs nothing beyond its own (n, c) sums, so the coefficients are finished here (same arithmetic as
+// norm_finalize_kernel's instance branch on the same float-rounded sums) and the finalize launch is skipped.
+template <bool INST>
+__global__ __launch_bounds__(1024) void norm_fwd_sum_kernel(const float* __restrict__ part, int tiles, int c, float* __restrict__ xa, float* __restrict__ xb,
+                                    int64_t hw, const float* __restrict__ drop, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                    float* __restrict__ ysum) {
+  // 1024 threads = 16 channels x 64 tile lanes, four independent 8-byte loads in flight per lane: the sums are latency-bound
+  // (16 lanes x one load at a time took 20 us for 1024 tiles)
+  __shared__ double sh1[64][17], sh2[64][17];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int n = blockIdx.x, ch = blockIdx.y * 16 + cl;
   double s1 = 0.0, s2 = 0.0;
-  if (ch < c)
-    for (int t = tl; t < tiles; t += 16) {
-      const float* p = part + (((size_t)n * tiles + t) * c + ch) * 2;
-      s1 += p[0]; s2 += p[1];
+  if (ch < c) {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t* p = reinterpret_cast<const f2_t*>(part) + (size_t)n * tiles * c + ch;
+    int t = tl;
+    for (; t + 192 < tiles; t += 256) {
+      const f2_t v0 = p[(size_t)t * c], v1 = p[(size_t)(t + 64) * c], v2 = p[(size_t)(t + 128) * c], v3 = p[(size_t)(t + 192) * c];
+      s1 += (double)v0.x + (double)v1.x + (double)v2.x + (double)v3.x;
+      s2 += (double)v0.y + (double)v1.y + (double)v2.y + (double)v3.y;
     }
+    for (; t < tiles; t += 64) { const f2_t v = p[(size_t)t * c]; s1 += v.x; s2 += v.y; }
+  }
   sh1[tl][cl] = s1; sh2[tl][cl] = s2;
   __syncthreads();
   if (tl == 0 && ch < c) {
     s1 = 0.0; s2 = 0.0;
-    for (int j = 0; j < 16; ++j) { s1 += sh1[j][cl]; s2 += sh2[j][cl]; }
-    xa[(size_t)n * c + ch] = (float)s1; xb[(size_t)n * c + ch] = (float)s2;
+    for (int j = 0; j < 64; ++j) { s1 += sh1[j][cl]; s2 += sh2[j][cl]; }
+    const size_t idx = (size_t)n * c + ch;
+    if (!INST) { xa[idx] = (float)s1; xb[idx] = (float)s2; return; }
+    const double f1 = (double)(float)s1, f2 = (double)(float)s2, M = (double)hw;
+    const double m = drop ? (double)drop[idx] : 1.0;
+    const double mean = f1 / M;
+    double var = f2 / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(m * m * var + (double)eps);
+    const float a_ = (float)(m * rstd), b_ = (float)(-m * mean * rstd);
+    xa[idx] = a_; xb[idx] = b_;
+    scale[idx] = gamma[ch] * a_; shift[idx] = gamma[ch] * b_ + beta[ch];
+    if (ysum) ysum[idx] = (float)f1;
   }
 }
 
@@ -145,7 +170,15 @@ extern "C" int mia_norm_finalize(const float* partials, int n, int tiles, int c,
   const int cgroups = ceil_div(c, 16);
   const bool need_sums = mode == NORM_INSTANCE || training;
   const bool inline_sums = need_sums && (int64_t)n * tiles <= 1024;  // one launch instead of two when the sums are short
-  if (need_sums && !inline_sums) hipLaunchKernelGGL(norm_fwd_sum_kernel, dim3(n, cgroups), dim3(256), 0, st, partials, tiles, c, xa, xb);
+  if (need_sums && !inline_sums && mode == NORM_INSTANCE) {  // long sums, instance norm: sums and coefficients in ONE launch
+    hipLaunchKernelGGL(norm_fwd_sum_kernel<true>, dim3(n, cgroups), dim3(1024), 0, st, partials, tiles, c, xa, xb, hw, drop_scale, gamma, beta,
+                       eps, scale, shift, ysum);
+    MIA_LAUNCH_CHECK();
+    return MIA_OK;
+  }
+  if (need_sums && !inline_sums)
+    hipLaunchKernelGGL(norm_fwd_sum_kernel<false>, dim3(n, cgroups), dim3(1024), 0, st, partials, tiles, c, xa, xb, hw, nullptr, nullptr, nullptr,
+                       0.f, nullptr, nullptr, nullptr);
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(cgroups), dim3(256), 0, st, n, c, hw, mode, training, drop_scale, gamma, beta, eps,
                      momentum, running_mean, running_var, num_batches, xa, xb, scale, shift, need_sums ? ysum : nullptr, nullptr, 0,
                      inline_sums ? partials : nullptr, tiles);
@@ -187,7 +220,8 @@ extern "C" int mia_bn_sync_local_stats(const float* partials, int n, int tiles, 
   MIA_CHECK_ARG(partials && xa && xb && local && n > 0 && tiles > 0 && c > 0 && hw > 0, "mia_bn_sync_local_stats: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int cgroups = ceil_div(c, 16);
-  hipLaunchKernelGGL(norm_fwd_sum_kernel, dim3(n, cgroups), dim3(256), 0, st, partials, tiles, c, xa, xb);
+  hipLaunchKernelGGL(norm_fwd_sum_kernel<false>, dim3(n, cgroups), dim3(1024), 0, st, partials, tiles, c, xa, xb, hw, nullptr, nullptr, nullptr,
+                     0.f, nullptr, nullptr, nullptr);
   hipLaunchKernelGGL(bn_local_stats_kernel, dim3(cgroups), dim3(256), 0, st, n, c, hw, drop_scale, xa, xb, local);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
