@@ -18,7 +18,7 @@ import torch  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["conv", "dgrad", "wgrad", "block"])
+    ap.add_argument("what", choices=["conv", "dgrad", "wgrad", "block", "convt", "convt_dgrad"])
     ap.add_argument("--c", type=int, default=64)
     ap.add_argument("--cout", type=int, default=None)
     ap.add_argument("--size", type=int, default=512)
@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--stride", type=int, default=1)
     a = ap.parse_args()
-    from mia_hip import CONV_G3S1, CONV_G3S2, WGRAD_3S1, WGRAD_3S2, ops
+    from mia_hip import CONV_G2S2, CONV_G3S1, CONV_G3S2, CONV_T2S2, WGRAD_3S1, WGRAD_3S2, ops
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     cout = a.cout or a.c
@@ -40,8 +40,19 @@ def main():
     wp, npad, kpad = pc.get(w, ops._dt(dt), True)
     wb, npb, kpb = pc.get(w, ops._dt(dt), False)
 
+    if a.what.startswith("convt"):  # ConvTranspose2d(c -> cout, 2, 2): --size is the COARSE side
+        wt = torch.randn(a.c, cout, 2, 2, device=dev) * 0.05
+        pct = ops.PackCache()
+        wtf, ntf, ktf = pct.get(wt, ops._dt(dt), False)
+        wtb, ntb, ktb = pct.get(wt, ops._dt(dt), True)
+        fine = torch.randn(a.batch, 2 * s, 2 * s, cout, device=dev).to(dt)
+
     def run():
-        if a.what == "conv":
+        if a.what == "convt":
+            ops.conv_mma(CONV_T2S2, x, None, wtf, ntf, ktf, False, b, cout, (2 * s, 2 * s))
+        elif a.what == "convt_dgrad":
+            ops.conv_mma(CONV_G2S2, fine, None, wtb, ntb, ktb, False, None, a.c, (s, s))
+        elif a.what == "conv":
             ops.conv_mma(CONV_G3S2 if a.stride == 2 else CONV_G3S1, x, None, wp, npad, kpad, False, b, cout, (so, so), want_stats=True)
         elif a.what == "dgrad":
             ops.conv_mma(CONV_G3S1, dy, None, wb, npb, kpb, True, None, a.c, (s, s))
@@ -55,7 +66,7 @@ def main():
         run()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.iters * 1e3
-    fl = 2.0 * 9 * a.c * cout * so * so * a.batch
+    fl = 2.0 * (4 if a.what.startswith("convt") else 9) * a.c * cout * so * so * a.batch
     print(f"{a.what} c={a.c}->{cout} {s}x{s} b={a.batch} {a.dtype}: {ms:.3f} ms/iter  {fl / ms / 1e9:.1f} TFLOP/s")
 
 
