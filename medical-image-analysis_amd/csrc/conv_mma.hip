@@ -361,7 +361,11 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
   if (opt.conv64 && opt.conv64_dma && (opt.conv64_dma >= 2 || a.o2 != 0) && mt == 4 && conv64_dma_eligible(mode, dtype, a)) rc = conv64_dma_launch(a, st);
   else if (opt.conv64 && mt == 4 && conv64_eligible(mode, dtype, a)) rc = conv64_launch(a, opt.conv64_blocks, st);
   else if (opt.conv_bt && mt == 4 && conv_bt_eligible(mode, dtype, a)) rc = conv_bt_launch(a, opt.conv_bt_order, st);
-  else if (opt.conv_pw && conv_pw_eligible(mode, dtype, a)) rc = conv_pw_launch(mode, a, st);
+  // (strided 3x3 forward as a tap-gathered GEMM: measured 0.62 -> 0.51, 0.44 -> 0.40, 0.37 -> 0.35 ms at 64 / 128 / 256 input channels,
+  // 0.30 -> 0.30 at 512 in isolation (tools/s2_levels.py), but 43.99 vs 43.94 ms inside the cfg3 step on one box: default off;
+  // conv_pw_s2 = 1 stops at 256 input channels, = 2 always)
+  else if (opt.conv_pw && (mode != MODE_G3S2 || opt.conv_pw_s2 >= 2 || (opt.conv_pw_s2 == 1 && c1 <= 256)) && conv_pw_eligible(mode, dtype, a))
+    rc = conv_pw_launch(mode, a, st);
   else if (fast) rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
   else rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);
   if (rc != MIA_OK) return rc;

@@ -57,17 +57,27 @@ __device__ __forceinline__ unsigned pw_pack(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(pw_f32x2{a, b}, pw_bf16x2));
 }
 
+__device__ __forceinline__ float pw_row16_sum(float v) {  // sum over the 16 lanes of a DPP row, left in every lane
+  int iv;
+  iv = __builtin_bit_cast(int, v); v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xF, 0xF, false));
+  iv = __builtin_bit_cast(int, v); v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xF, 0xF, false));
+  iv = __builtin_bit_cast(int, v); v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x141, 0xF, 0xF, false));
+  iv = __builtin_bit_cast(int, v); v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x140, 0xF, 0xF, false));
+  return v;
+}
+
 constexpr int PW_TM = 256, PW_TN = 128;
 constexpr int PW_A = PW_TM * 128, PW_B = PW_TN * 128, PW_STAGE = PW_A + PW_B, PW_NSTAGE = 3;
 constexpr int PW_BIAS = PW_NSTAGE * PW_STAGE;  // two 1 KB slots: the bias of the item being computed / being fetched
-constexpr int PW_LDS = PW_BIAS + 2 * 1024;
+constexpr int PW_RED = PW_BIAS + 2 * 1024;     // [8 waves][64 channels][2] statistics exchange (strided 3x3 forward)
+constexpr int PW_LDS = PW_RED + 8 * 64 * 8;
 constexpr int PW_NSTORE = 8;                   // store instructions per wave and item
 
 }  // namespace
 
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int mtot, int wco, int nk, int mtiles, int nwork, int tile_major) {
-  constexpr bool TR = (MODE == MODE_T2S2);
+  constexpr bool TR = (MODE == MODE_T2S2), S2 = (MODE == MODE_G3S2), BIAS = TR || S2;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[PW_LDS];
   const unsigned lds0 = (unsigned)(size_t)(lds_u8*)smem;
 
@@ -82,7 +92,8 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
   const size_t in_bytes = (size_t)a.N * a.Hin * a.Win * a.c1 * 2, out_bytes = (size_t)a.N * a.Hout * a.Wout * a.o1 * 2;
   const i32x4 rsA = pw_rsrc_words(a.in1, (unsigned)in_bytes);
   const i32x4 rsW = pw_rsrc_words(a.wp, (unsigned)((size_t)4 * a.npad * a.kpad * 2));
-  const i32x4 rsB = pw_rsrc_words(TR ? (const void*)a.bias : a.wp, TR ? (unsigned)(a.o1 * 4) : 0u);
+  const i32x4 rsB = pw_rsrc_words(BIAS ? (const void*)a.bias : a.wp, BIAS ? (unsigned)(a.o1 * 4) : 0u);
+  const i32x4 rsW9 = pw_rsrc_words(a.wp, (unsigned)((size_t)9 * a.npad * a.kpad * 2));  // S2: nine taps
   const rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.out1, 0, (int)(unsigned)out_bytes, 0x00020000);
 
   struct Item { int m0, n0; };
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
   const int lr = lane >> 3;
   const unsigned uA = (unsigned)((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7));
   const unsigned uB = (unsigned)((lane & 7) ^ (((lane >> 4) & 1) | ((wave & 3) << 1)));
-  unsigned va[4], vb[2], vbias = PW_SENT;
+  unsigned va[4], vb[2], vbias = PW_SENT, vmask = 0;
   auto setup_issue = [&](int w) __attribute__((always_inline)) {
     const Item it = decode(w);
 #pragma unroll
@@ -111,36 +122,50 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
       const int p = it.m0 + 8 * wave + 64 * k + lr;
       unsigned base;
       if (TR) base = (unsigned)p * (unsigned)(cin * 2);
-      else { const int j = p % wco; base = (unsigned)(4 * p - 2 * j) * (unsigned)(cin * 2); }  // fine pixel (n, 2i, 2j)
+      else if (S2) {  // output pixel (n, i, j) reads fine pixels (2i + ta - 1, 2j + tb - 1): base = pixel (2i, 2j), six validity bits
+        const int t1 = p / wco, j = p - t1 * wco, n = t1 / a.Hout, i = t1 - n * a.Hout;
+        base = (unsigned)((n * a.Hin + 2 * i) * a.Win + 2 * j) * (unsigned)(cin * 2);
+        const unsigned bits = (i > 0 ? 1u : 0u) | 2u | (2 * i + 1 < a.Hin ? 4u : 0u) | (j > 0 ? 8u : 0u) | 16u | (2 * j + 1 < a.Win ? 32u : 0u);
+        vmask = k == 0 ? bits : (vmask | (bits << (6 * k)));
+      } else { const int j = p % wco; base = (unsigned)(4 * p - 2 * j) * (unsigned)(cin * 2); }  // fine pixel (n, 2i, 2j)
       va[k] = p < mtot ? base + uA * 16u : PW_SENT;
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) vb[k] = (unsigned)(it.n0 + 8 * wave + 64 * k + lr) * kpitch + uB * 16u;
-    if (TR) vbias = lane < 32 ? (unsigned)((it.n0 + 4 * lane) % a.o1) * 4u : PW_SENT;
+    if (BIAS) vbias = lane < 32 ? (unsigned)((it.n0 + 4 * lane) % a.o1) * 4u : PW_SENT;
   };
-  int wi = blockIdx.x, ki = 0, itap = 0, icc = 0, islot = 0, ibias = 0;
+  int wi = blockIdx.x, ki = 0, itap = 0, icc = 0, ita = 0, itb = 0, islot = 0, ibias = 0;
   bool ihave = wi < nwork;
   if (ihave) setup_issue(wi);
   auto issue_next = [&]() __attribute__((always_inline)) -> int {
     if (!ihave) return 0;
     unsigned soffA, soffB;
     if (TR) { soffA = (unsigned)ki * 128u; soffB = soffA; }
+    else if (S2) { soffA = 0u; soffB = (unsigned)itap * (unsigned)a.npad * kpitch + (unsigned)icc * 128u; }
     else {
       soffA = (unsigned)((itap >> 1) * a.Win + (itap & 1)) * (unsigned)(cin * 2) + (unsigned)icc * 128u;
       soffB = (unsigned)itap * (unsigned)a.npad * kpitch + (unsigned)icc * 128u;
     }
     const unsigned dst = lds0 + (unsigned)islot * PW_STAGE + (unsigned)wave * 1024u;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pw_dma16(rsA, va[k], soffA, dst + (unsigned)k * 8192u);
+    for (int k = 0; k < 4; ++k) {
+      unsigned v = va[k];
+      if (S2) {  // tap (ita, itb): a signed pixel offset, rows / columns outside the image read zeros
+        const int toff = ((ita - 1) * a.Win + (itb - 1)) * (cin * 2) + icc * 128;
+        const bool ok = ((vmask >> (6 * k + ita)) & (vmask >> (6 * k + 3 + itb)) & 1u) != 0u && v != PW_SENT;
+        v = ok ? (unsigned)((int)v + toff) : PW_SENT;
+      }
+      pw_dma16(rsA, v, soffA, dst + (unsigned)k * 8192u);
+    }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) pw_dma16(rsW, vb[k], soffB, dst + PW_A + (unsigned)k * 8192u);
+    for (int k = 0; k < 2; ++k) pw_dma16(S2 ? rsW9 : rsW, vb[k], soffB, dst + PW_A + (unsigned)k * 8192u);
     int cnt = 6;
-    if (TR && ki == 0) { pw_dma16(rsB, vbias, 0u, lds0 + PW_BIAS + (unsigned)ibias * 1024u); ibias ^= 1; cnt = 7; }
+    if (BIAS && ki == 0) { pw_dma16(rsB, vbias, 0u, lds0 + PW_BIAS + (unsigned)ibias * 1024u); ibias ^= 1; cnt = 7; }
     islot = islot == PW_NSTAGE - 1 ? 0 : islot + 1;
     ++ki;
-    if (!TR) { if (++icc == cpt) { icc = 0; ++itap; } }
+    if (!TR) { if (++icc == cpt) { icc = 0; ++itap; if (S2 && ++itb == 3) { itb = 0; ++ita; } } }
     if (ki == nk) {
-      ki = 0; itap = 0; icc = 0;
+      ki = 0; itap = 0; icc = 0; ita = 0; itb = 0;
       wi += gridDim.x;
       ihave = wi < nwork;
       if (ihave) setup_issue(wi);
@@ -157,8 +182,8 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
   pw_wait_vm<6>();
   __builtin_amdgcn_s_barrier();
 
-  int cslot = 0, cbias = 0;
-  bool after_epilogue = false;
+  int cslot = 0, cbias = 0, st_m0 = 0, st_n0 = 0;
+  bool after_epilogue = false, stats_pending = false;
   for (int wcur = blockIdx.x; wcur < nwork; wcur += gridDim.x) {
     const Item it = decode(wcur);
     f32x4 acc[4][4];
@@ -202,8 +227,10 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
         const unsigned tapoff = TR ? (unsigned)((tap >> 1) * a.Wout + (tap & 1)) : 0u;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-          float bv[8];
-          if (TR) {
+          float bv[8], s1[8], s2[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+          if (BIAS) {
             const float* bl = reinterpret_cast<const float*>(smem + PW_BIAS + cbias * 1024) + wn * 64 + 32 * pr + 8 * q;
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl), b1 = *reinterpret_cast<const f32x4*>(bl + 4);
 #pragma unroll
@@ -220,30 +247,66 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
             else pix = (unsigned)p;
             const unsigned voff = p < mtot ? (pix * (unsigned)a.o1 + (unsigned)(co0 + 32 * pr + 8 * q)) * 2u : PW_SENT;
             const f32x4 lo = acc[2 * pr][pf], hi = acc[2 * pr + 1][pf];
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
+            if (S2 && a.stats != nullptr) {  // whole tiles only (contract): every pixel counts
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+            }
             u32x4 d;
-            d.x = pw_pack(lo[0] + bv[0], lo[1] + bv[1]); d.y = pw_pack(lo[2] + bv[2], lo[3] + bv[3]);
-            d.z = pw_pack(hi[0] + bv[4], hi[1] + bv[5]); d.w = pw_pack(hi[2] + bv[6], hi[3] + bv[7]);
+            d.x = pw_pack(v[0], v[1]); d.y = pw_pack(v[2], v[3]); d.z = pw_pack(v[4], v[5]); d.w = pw_pack(v[6], v[7]);
             __builtin_amdgcn_raw_buffer_store_b128(d, rsO, (int)voff, 0, 0);
           }
+          if (S2 && a.stats != nullptr) {  // per-wave sums of its 64 pixels: DPP row sums over the 16 pixel lanes
+            float* red = reinterpret_cast<float*>(smem + PW_RED) + (wave * 64 + 32 * pr + 8 * q) * 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float t1 = pw_row16_sum(s1[e]), t2 = pw_row16_sum(s2[e]);
+              if (r == 0) { red[2 * e] = t1; red[2 * e + 1] = t2; }
+            }
+          }
         }
+        if (S2 && a.stats != nullptr) { stats_pending = true; st_m0 = it.m0; st_n0 = it.n0; }
         cbias ^= 1;
         after_epilogue = true;
       }
       __builtin_amdgcn_s_barrier();
+      if (S2 && stats_pending) {
+        // the host's statistics tiles are 8 x 16 pixels = 128 consecutive coarse pixels when whole rows tile evenly (contract): the
+        // 256-pixel block is two entries, wave quarters {0, 1} and {2, 3}
+        stats_pending = false;
+        if (tid < 256) {
+          const int half = tid >> 7, wnn = (tid >> 6) & 1, ch = tid & 63;
+          const float* red = reinterpret_cast<const float*>(smem + PW_RED);
+          const float* ra = red + ((wnn * 4 + 2 * half) * 64 + ch) * 2;
+          const float* rb = ra + 64 * 2;
+          typedef float f2_t __attribute__((ext_vector_type(2)));
+          typedef __attribute__((address_space(1))) f2_t gf2;
+          gf2* dst = (gf2*)(a.stats + ((size_t)(st_m0 / 128 + half) * a.o1 + st_n0 + wnn * 64 + ch) * 2);
+          *dst = f2_t{ra[0] + rb[0], ra[1] + rb[1]};
+        }
+      }
     }
   }
 }
 
 bool conv_pw_eligible(int mode, int dtype, const ConvArgs& a) {
-  if (dtype != MIA_BF16 || (mode != MODE_T2S2 && mode != MODE_G2S2)) return false;
-  if (a.c2 != 0 || a.o2 != 0 || a.stats != nullptr || !a.vec_in || !a.vec_out) return false;
+  if (dtype != MIA_BF16 || (mode != MODE_T2S2 && mode != MODE_G2S2 && mode != MODE_G3S2)) return false;
+  if (a.c2 != 0 || a.o2 != 0 || !a.vec_in || !a.vec_out) return false;
   if (a.c1 % 64 != 0 || a.kpad != a.c1 || a.npad != a.o1) return false;
-  const int ntot = mode == MODE_T2S2 ? 4 * a.o1 : a.o1, ktot = mode == MODE_T2S2 ? a.c1 : 4 * a.c1;
+  const int ntot = mode == MODE_T2S2 ? 4 * a.o1 : a.o1, ktot = mode == MODE_T2S2 ? a.c1 : (mode == MODE_G3S2 ? 9 : 4) * a.c1;
   if (ntot % PW_TN != 0 || ktot < 128 || a.o1 % 64 != 0) return false;
-  if ((mode == MODE_T2S2) != (a.bias != nullptr)) return false;  // forward carries the bias, the gradient none
+  if ((mode != MODE_G2S2) != (a.bias != nullptr)) return false;  // the forwards carry the bias, the gradient none
+  if (mode == MODE_G3S2) {
+    // statistics: the finalize step only sums an image's entries, so any partition of its pixels into the host's tiles_y * tiles_x
+    // entries will do -- here runs of 128 consecutive output pixels (two per block); needs whole 8 x 16 tilings and no block
+    // straddling two images
+    if (a.stats != nullptr && !(a.Wout % 16 == 0 && a.Hout % 8 == 0 && (a.Hout * a.Wout) % PW_TM == 0)) return false;
+  } else if (a.stats != nullptr) return false;
   const size_t lim = ((size_t)1 << 32) - ((size_t)1 << 20);
   if ((size_t)a.N * a.Hin * a.Win * a.c1 * 2 >= lim || (size_t)a.N * a.Hout * a.Wout * a.o1 * 2 >= lim) return false;
-  if ((size_t)4 * a.npad * a.kpad * 2 >= ((size_t)1 << 31)) return false;
+  if ((size_t)9 * a.npad * a.kpad * 2 >= ((size_t)1 << 31)) return false;
   return true;
 }
 
@@ -260,14 +323,15 @@ int conv_pw_launch(int mode, const ConvArgs& a, hipStream_t st) {
   const bool tr = mode == MODE_T2S2;
   const int hco = tr ? a.Hin : a.Hout, wco = tr ? a.Win : a.Wout;  // the coarse grid
   const int mtot = a.N * hco * wco;
-  const int nk = (tr ? a.c1 : 4 * a.c1) / 64;
+  const int nk = (tr ? a.c1 : (mode == MODE_G3S2 ? 9 : 4) * a.c1) / 64;
   const int nblocks = (tr ? 4 * a.o1 : a.o1) / PW_TN;
   const int mtiles = ceil_div(mtot, PW_TM);
   const int nwork = mtiles * nblocks;
   const int tile_major = (nblocks > 1 && mtiles % 8 == 0) ? nblocks : 0;
   const int ncu = pw_num_cus();
   const dim3 grid(nwork < ncu ? nwork : ncu);
-  if (tr) hipLaunchKernelGGL(conv_pw_kernel<MODE_T2S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
+  if (mode == MODE_G3S2) hipLaunchKernelGGL(conv_pw_kernel<MODE_G3S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
+  else if (tr) hipLaunchKernelGGL(conv_pw_kernel<MODE_T2S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
   else hipLaunchKernelGGL(conv_pw_kernel<MODE_G2S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
   return MIA_OK;
 }

@@ -668,6 +668,51 @@ def test_conv_pw_matches_tile_kernel_and_reference(case):
     assert relerr(nchw(outs[1][1]), xr.grad) < TOL[dt]
 
 
+PW_S2_CASES = [  # n, cin, cout, h, w (input): strided 3x3 forward on conv_pw_kernel<G3S2> -- image borders on all four sides, odd input
+    # sizes (the last row / column tap falls outside), K = 9 x 64 .. 9 x 512, with and without the statistics epilogue
+    (2, 64, 128, 64, 64), (1, 128, 256, 32, 64), (3, 64, 128, 31, 63), (1, 512, 1024, 16, 32), (2, 128, 128, 128, 32),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("want_stats", [True, False])
+@pytest.mark.parametrize("case", PW_S2_CASES)
+def test_conv_pw_s2_matches_tile_kernel_and_reference(case, want_stats):
+    """Option conv_pw_s2 (csrc/conv_pw.hip, MODE_G3S2): the strided first conv of an encoder level (unet.py:57-66) as a tap-gathered
+    GEMM.  K is summed tap-major (the tile kernel: chunk-major) -> fp32 order only.  Statistics: another partition of the image's
+    pixels into the same number of entries; their per-image sums are what the norm consumes."""
+    import mia_hip
+    from mia_hip import BF16, CONV_G3S2, ops
+    dev = _dev()
+    n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(sum(case))
+    dt = torch.bfloat16
+    x = q(torch.randn(n, cin, h, w, generator=g), dt)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    yr = F.conv2d(x, q(wt, dt), b, stride=2, padding=1)
+    xd = nhwc(x, dt, dev)
+    wp, npad, kpad = ops.PackCache().get(wt.to(dev), BF16, True)
+    outs = {}
+    try:
+        for flag in (1, 0):
+            mia_hip.set_option("conv_pw_s2", 2 * flag)  # 2: also above 256 input channels
+            y, _, st = ops.conv_mma(CONV_G3S2, xd, None, wp, npad, kpad, False, b.to(dev), cout, (ho, wo), want_stats=want_stats)
+            torch.cuda.synchronize()
+            outs[flag] = (y.clone(), None if st is None else st.clone())
+    finally:
+        mia_hip.set_option("conv_pw_s2", 0)
+    assert relerr(outs[1][0].float(), outs[0][0].float()) < 1e-2  # one bf16 ulp where the fp32 sums round apart
+    assert relerr(nchw(outs[1][0]), yr) < TOL[dt]
+    if want_stats:
+        assert outs[1][1].shape == outs[0][1].shape
+        s1, s0 = outs[1][1].sum(1).cpu(), outs[0][1].sum(1).cpu()
+        assert torch.allclose(s1, s0, rtol=1e-3, atol=1e-1)
+        assert relerr(s1[..., 0], yr.sum((2, 3))) < 1e-3 + TOL[dt]
+        assert relerr(s1[..., 1], (yr ** 2).sum((2, 3))) < 1e-3 + TOL[dt]
+
+
 S2_WIDE_CASES = [  # n, cin, cout, h, w: 512-thread stride-2 kernel (128-multiples of output channels), ragged 16-row tiles, odd sizes
     (2, 64, 128, 80, 72), (1, 128, 256, 37, 53), (1, 32, 128, 18, 200), (3, 64, 128, 34, 34), (1, 256, 512, 32, 32),
 ]
@@ -693,6 +738,7 @@ def test_conv_s2_wide_matches_tile_kernel_and_reference(case):
     wp, npad, kpad = ops.PackCache().get(wt.to(dev), BF16, True)
     outs = {}
     try:
+        mia_hip.set_option("conv_pw_s2", 0)  # (the tap-gathered GEMM would take these launches)
         for flag in (1, 0):
             mia_hip.set_option("conv_s2_wide", 2 * flag)  # 2: also below 128 input channels
             y, _, st = ops.conv_mma(CONV_G3S2, xd, None, wp, npad, kpad, False, b.to(dev), cout, (ho, wo), want_stats=True)
@@ -700,6 +746,7 @@ def test_conv_s2_wide_matches_tile_kernel_and_reference(case):
             outs[flag] = (y.clone(), st.clone())
     finally:
         mia_hip.set_option("conv_s2_wide", 1)
+        mia_hip.set_option("conv_pw_s2", 0)
     assert torch.equal(outs[1][0], outs[0][0])
     assert outs[1][1].shape == outs[0][1].shape
     assert torch.allclose(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-2)
