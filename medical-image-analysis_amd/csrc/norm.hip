@@ -249,10 +249,13 @@ __global__ __launch_bounds__(256) void colreduce_vec_kernel(const T* __restrict_
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ xa, const float* __restrict__ xb,
                                                             int64_t hw, int c, int slabs, float slope, float* __restrict__ part) {
-  constexpr int EPU = Elem<T>::EPU, UPB = CG / EPU, LANES = 256 / UPB;  // CG = channels per block (64, or 32 when c % 64 != 0)
+  // CG = channels per block: 64; 96 when c is a multiple of 96 only (a whole 192-byte pixel row of cfg5's first level per block: 21 pixel
+  // lanes, 4 idle threads); else 32
+  constexpr int EPU = Elem<T>::EPU, UPB = CG / EPU, LANES = 256 / UPB;
   __shared__ float sh[2][LANES][CG + 1];
   const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
   const int u = threadIdx.x % UPB, pl = threadIdx.x / UPB;
+  const bool active = (256 % UPB == 0) || pl < LANES;  // 256 threads are not a multiple of UPB at CG = 96
   const int ch0 = blockIdx.y * CG + u * EPU;
   const int64_t per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
   const size_t base = (size_t)n * hw * c + ch0;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void colreduce_vec_kernel(const T* __restrict_
   };
   const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
   auto ld = [&](const T* ptr, int64_t r) { return *reinterpret_cast<const u32x4*>(ptr + base + r * c); };
-  int64_t r = r0 + pl;
+  int64_t r = active ? r0 + pl : r1;
   for (; r + LANES < r1; r += 2 * LANES) {  // two rows (up to six 16-byte loads) in flight per thread
     const u32x4 p0 = ld(a0, r), q0 = BWD ? ld(a1, r) : zero, t0 = TWO ? ld(a2, r) : zero;
     const u32x4 p1 = ld(a0, r + LANES), q1 = BWD ? ld(a1, r + LANES) : zero, t1 = TWO ? ld(a2, r + LANES) : zero;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void colreduce_vec_kernel(const T* __restrict_
   }
   for (; r < r1; r += LANES) body(ld(a0, r), BWD ? ld(a1, r) : zero, TWO ? ld(a2, r) : zero);
 #pragma unroll
-  for (int e = 0; e < EPU; ++e) { sh[0][pl][u * EPU + e] = s1[e]; sh[1][pl][u * EPU + e] = s2[e]; }
+  for (int e = 0; e < EPU; ++e) if (active) { sh[0][pl][u * EPU + e] = s1[e]; sh[1][pl][u * EPU + e] = s2[e]; }
   __syncthreads();
   if (threadIdx.x < 2 * CG) {
     const int k = threadIdx.x / CG, chl = threadIdx.x % CG;
@@ -341,6 +344,8 @@ __global__ void norm_stats_kernel(const T* __restrict__ y, int64_t hw, int c, in
   do {                                                                                                                    \
     if (c % 64 == 0) { if ((A2) != nullptr) CRV_(T, BWDF, 64, true, A0, A1, A2, SC, SF, XA, XB, SLOPE);                   \
                        else CRV_(T, BWDF, 64, false, A0, A1, A2, SC, SF, XA, XB, SLOPE); }                                \
+    else if (c % 96 == 0) { if ((A2) != nullptr) CRV_(T, BWDF, 96, true, A0, A1, A2, SC, SF, XA, XB, SLOPE);              \
+                            else CRV_(T, BWDF, 96, false, A0, A1, A2, SC, SF, XA, XB, SLOPE); }                           \
     else { if ((A2) != nullptr) CRV_(T, BWDF, 32, true, A0, A1, A2, SC, SF, XA, XB, SLOPE);                               \
            else CRV_(T, BWDF, 32, false, A0, A1, A2, SC, SF, XA, XB, SLOPE); }                                            \
   } while (0)

@@ -87,6 +87,13 @@ def bt():
         for _ in range(3):
             ops.conv_mma(CONV_G3S1, x, None, wp, npad, kpad, False, b, c, (s, s), want_stats=True)
         torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            ops.conv_mma(CONV_G3S1, x, None, wp, npad, kpad, False, b, c, (s, s), want_stats=True)
+        e1.record()
+        torch.cuda.synchronize()
+        wall_ms = e0.elapsed_time(e1) / 4
         l = ctypes.CDLL(os.environ["MIA_HIP_LIB"])
         buf = np.zeros(256 * 8 * 8, dtype=np.uint64)
         assert l.mia_conv_bt_debug_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
@@ -103,6 +110,9 @@ def bt():
             print(f"{nm:26s} {(d[..., i][live] / den[live]).mean():9.0f} cycles / step / wave   (waves 0-3 {(d[:, :4, i][live[:, :4]] / den[:, :4][live[:, :4]]).mean():.0f}, 4-7 {(d[:, 4:, i][live[:, 4:]] / den[:, 4:][live[:, 4:]]).mean():.0f})")
         for i, nm in ((4, "statistics epilogue"), (5, "next-tile prep")):
             print(f"{nm:26s} {(d[..., i][live] / tiles[live]).mean():9.0f} cycles / tile / wave")
+        cyc = d[..., :6].sum(-1)[live].mean()  # the stamped phases cover the loop of a workgroup
+        print(f"launch {wall_ms:.3f} ms (stamped build), {cyc:.0f} stamped cycles per wave -> in-kernel clock ~ {cyc / wall_ms / 1e6:.2f} GHz; "
+              f"matrix pipe busy {2 * 96 * 16 * steps[live].mean() / cyc * 100:.0f} % of the cycles (two waves per SIMD)")
 
 
 def c64dma():
