@@ -32,7 +32,7 @@ __global__ __launch_bounds__(1024) void norm_fwd_sum_kernel(const float* __restr
                                     float* __restrict__ ysum) {
   // 1024 threads = 16 channels x 64 tile lanes, four independent 8-byte loads in flight per lane: the sums are latency-bound
   // (16 lanes x one load at a time took 20 us for 1024 tiles)
-  __shared__ double sh1[64][17], sh2[64][17];
+  __shared__ double sh1[16][17], sh2[16][17];
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int n = blockIdx.x, ch = blockIdx.y * 16 + cl;
   double s1 = 0.0, s2 = 0.0;
@@ -47,11 +47,15 @@ __global__ __launch_bounds__(1024) void norm_fwd_sum_kernel(const float* __restr
     }
     for (; t < tiles; t += 64) { const f2_t v = p[(size_t)t * c]; s1 += v.x; s2 += v.y; }
   }
-  sh1[tl][cl] = s1; sh2[tl][cl] = s2;
+  // the four tile lanes of a wave first (lanes l, l + 16, l + 32, l + 48 hold one channel), then the 16 waves through LDS
+  s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+  s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+  if ((tl & 3) == 0) { sh1[tl >> 2][cl] = s1; sh2[tl >> 2][cl] = s2; }
   __syncthreads();
   if (tl == 0 && ch < c) {
     s1 = 0.0; s2 = 0.0;
-    for (int j = 0; j < 64; ++j) { s1 += sh1[j][cl]; s2 += sh2[j][cl]; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { s1 += sh1[j][cl]; s2 += sh2[j][cl]; }
     const size_t idx = (size_t)n * c + ch;
     if (!INST) { xa[idx] = (float)s1; xb[idx] = (float)s2; return; }
     const double f1 = (double)(float)s1, f2 = (double)(float)s2, M = (double)hw;
