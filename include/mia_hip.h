@@ -84,6 +84,7 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
  *   conv_xcd / wgrad_xcd (MIA_CONV_XCD / MIA_WGRAD_XCD, 1)   blocks sharing an input tile run on one XCD (0: plain grid order)
  *   conv_mt8 (MIA_CONV_MT8, 0)     32-row tiles of the tile kernel (experiment)
  *   wgrad_bt (MIA_WGRAD_BT, 1)     bf16 3x3 stride-1 weight gradients with >= 128 output channels on the 512-thread 128 x 64 block kernel
+ *   wgrad_t2 (MIA_WGRAD_T2, 1)     ConvTranspose 2x2 weight gradient (bf16, >= 128 coarse channels) on the 512-thread three-stage ring
  *   wgrad_dma (MIA_WGRAD_DMA, 1)   bf16 3x3 stride-1 weight gradients on the LDS-DMA ring kernel; with 0, wgrad_w8
  *                                  (MIA_WGRAD_W8, 1) picks the register-staged two-workgroups-per-CU kernel (wgrad_tab: its
  *                                  LDS staging table) and 0 the one-workgroup-per-CU kernel

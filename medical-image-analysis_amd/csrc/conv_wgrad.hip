@@ -1242,6 +1242,193 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16_bt_s2_kernel(const WgArgs a
       }
 }
 
+// ---------------------------------------------------------------- bf16, 512-thread big block, ConvTranspose 2x2 / stride 2 (cdy % 128 == 0)
+// The weight gradient of nn.ConvTranspose2d(c_below, c, 2, 2) (unet.py:142): "x" = the fine output gradient, "dy" = the coarse input,
+// four taps without overlap.  Same block, wave roles, LDS images and transposing reads as wgrad_bf16_bt_s2_kernel with KS = 2 and no
+// padding row / column: x tile = 8 fine rows x 32 pixels (32 pieces), 48 KB per stage -> a ring of THREE stages (tile t + 2 issued one
+// piece per MFMA step of tile t, counted wait for tile t + 1): 32 MFMAs per wave and tile are too few to hide a DMA round trip
+// inside one tile, which the two-stage ring of the 3x3 kernel relies on.
+__global__ __launch_bounds__(512, 2) void wgrad_bf16_bt_t2_kernel(const WgArgs a) {
+  constexpr int KS = 2, TAPS = 4, TH = 4;
+  constexpr int XH = 2 * TH, XBLK = 4, XROW = XBLK * 1024, XW = 32;  // 8 fine rows x 4 blocks of 8 pixels x 128 B
+  constexpr int X_BYTES = XH * XROW, DH_BYTES = TH * 16 * 128, D_BYTES = 2 * DH_BYTES, STAGE = X_BYTES + D_BYTES, NSTAGE = 3;
+  constexpr int XPIECES = XH * XBLK, DPIECES = TH * 2, PIECES = XPIECES + 2 * DPIECES;  // 32 + 8 + 8: piece pc lives at byte 1024 pc
+  constexpr int MAXOWN = PIECES / 8;                                                    // 6 pieces per wave and tile, every wave
+  static_assert(PIECES % 8 == 0, "uniform piece count: one counted wait for all waves");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nh = wave >> 2, kq = wave & 3;
+  const int grp = lane >> 4, i16 = lane & 15, qp = i16 >> 2, pp = i16 & 3;
+  const int kb1 = (a.c1 + 63) / 64, nkb = kb1 + (a.c2 + 63) / 64;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (a.opt & 16) {
+    const int ncol = nkb * (a.npad / 128), slot = bx >> 3;
+    by = (slot / ncol) * 8 + (bx & 7);
+    bx = slot % ncol;
+    if (by >= a.ksplit) return;
+  }
+  const int kblk = bx % nkb, nblk = bx / nkb;
+  const bool second = kblk >= kb1;
+  const int cs = second ? a.c2 : a.c1, kloc = (second ? kblk - kb1 : kblk) * 64;
+  const int n0 = nblk * 128, k0 = (second ? a.c1 : 0) + kloc;
+  const bf16_t* xsrc = static_cast<const bf16_t*>(second ? a.x2 : a.x1);
+  const bf16_t* dy = static_cast<const bf16_t*>(a.dy);
+  const size_t xpix = (size_t)a.Hx * a.Wx, ypix = (size_t)a.Hy * a.Wy;
+
+  // DMA lane constants: lane L of a piece = 16-byte chunk (L&3) of half (L>>5) of pixel row (L>>2)&7 of the 8-pixel block; the
+  // source chunk is un-swizzled by the block's parity within its image row
+  const int dr = (lane >> 2) & 7;
+  const int ch8_0 = 4 * (lane >> 5) + ((lane & 3) ^ ((dr >> 2) & 3)), ch8_1 = 4 * (lane >> 5) + ((lane & 3) ^ ((2 + (dr >> 2)) & 3));
+  const unsigned xlane0 = (unsigned)((dr * cs + kloc + ch8_0 * 8) * 2), xlane1 = (unsigned)((dr * cs + kloc + ch8_1 * 8) * 2);
+  const unsigned dlane0 = (unsigned)((dr * a.cdy + n0 + ch8_0 * 8) * 2), dlane1 = (unsigned)((dr * a.cdy + n0 + ch8_1 * 8) * 2);
+  const bool xok0 = kloc + ch8_0 * 8 < cs, xok1 = kloc + ch8_1 * 8 < cs;
+  const unsigned lds0 = (unsigned)(size_t)(lds_u8*)smem;
+
+  // ---- issue state of the tile being fetched
+  wi32x4 rx, rd;
+  int i_oy0 = 0, i_ox0 = 0;
+  unsigned i_stage = 0;
+  auto prepare = [&](int img, int ty, int tx, unsigned stage_base) {
+    i_oy0 = ty * TH; i_ox0 = tx * 16; i_stage = stage_base;
+    rx = wmake_rsrc_i(xsrc + (size_t)img * xpix * cs, (unsigned)(xpix * cs * 2));
+    rd = wmake_rsrc_i(dy + (size_t)img * ypix * a.cdy, (unsigned)(ypix * a.cdy * 2));
+  };
+  auto issue_piece = [&](auto jc) __attribute__((always_inline)) {
+    constexpr int j = decltype(jc)::value;
+    const int pc = wave + 8 * j;  // wave-uniform piece index
+    if (pc >= PIECES) return;
+    const unsigned dst = i_stage + pc * 1024;
+    if (pc < XPIECES) {
+      const int iy = pc / XBLK, xb = pc - XBLK * iy;
+      const int iy0 = 2 * i_oy0, ix0 = 2 * i_ox0;
+      const int gy = iy0 + iy, gx = ix0 + 8 * xb + dr;
+      const bool ok = ((unsigned)gy < (unsigned)a.Hx) & ((unsigned)gx < (unsigned)a.Wx) & (8 * xb + dr < XW) & ((xb & 1) ? xok1 : xok0);
+      const unsigned off = (unsigned)((gy * a.Wx + ix0 + 8 * xb) * cs * 2) + ((xb & 1) ? xlane1 : xlane0);
+      lds_dma16(rx, ok ? off : WSENT, __builtin_amdgcn_readfirstlane(dst));
+    } else {
+      const int q = pc - XPIECES, h = q >> 3, qq = q & 7;  // 8-pixel block of the dy tile: output row qq >> 1, pixels 8 (qq & 1) ..
+      const int gy = i_oy0 + (qq >> 1), gx = i_ox0 + 8 * (qq & 1) + dr;
+      const bool ok = (gy < a.Hy) & (gx < a.Wy);
+      const unsigned off = (unsigned)((gy * a.Wy + i_ox0 + 8 * (qq & 1)) * a.cdy * 2) + ((qq & 1) ? dlane1 : dlane0) + (unsigned)(h * 128);
+      lds_dma16(rd, ok ? off : WSENT, __builtin_amdgcn_readfirstlane(dst));
+    }
+  };
+#define WG_PIECE(J) issue_piece(std::integral_constant<int, J>{})
+
+  f32x4 acc[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // lane-constant fragment bases (absolute LDS bytes of stage 0; the stage offset is added per tile)
+  const int g1 = grp >> 1, xb0 = 8 * (grp & 1) + qp, sub = 8 * (pp & 1);
+  unsigned dbase[2][2], xbase[KS][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {  // channel tiles c and c + 2 differ by +512 bytes
+    dbase[c][0] = lds0 + X_BYTES + nh * DH_BYTES + swz_off(g1 * 16 + xb0, 2 * c + (pp >> 1)) + sub;
+    dbase[c][1] = lds0 + X_BYTES + nh * DH_BYTES + swz_off(g1 * 16 + xb0 + 4, 2 * c + (pp >> 1)) + sub;
+  }
+#pragma unroll
+  for (int kw = 0; kw < KS; ++kw) {  // input row 4 kb + 2 g1 + kh, input column 2 (output pixel) + kw; +4 output pixels = +8 columns
+    xbase[kw][0] = lds0 + 2 * g1 * XROW + swz_off(2 * xb0 + kw, 2 * kq + (pp >> 1)) + sub;
+    xbase[kw][1] = lds0 + 2 * g1 * XROW + swz_off(2 * xb0 + kw + 8, 2 * kq + (pp >> 1)) + sub;  // (+8 flips the swizzle's bit 1)
+  }
+
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  int tile = by;
+  int t_tx, t_ty, t_img;  // digits of the NEXT tile to issue
+  { int tt = tile; t_tx = tt % a.tiles_x; tt /= a.tiles_x; t_ty = tt % a.tiles_y; t_img = tt / a.tiles_y; }
+  int d_tx, d_ty, d_img;
+  { int tt = a.ksplit; d_tx = tt % a.tiles_x; tt /= a.tiles_x; d_ty = tt % a.tiles_y; d_img = tt / a.tiles_y; }
+  auto advance = [&]() {
+    t_tx += d_tx; if (t_tx >= a.tiles_x) { t_tx -= a.tiles_x; t_ty += 1; }
+    t_ty += d_ty; if (t_ty >= a.tiles_y) { t_ty -= a.tiles_y; t_img += 1; }
+    t_img += d_img;
+  };
+  int issue_tile = tile;
+  unsigned stage = 0, issue_stage = 0;  // ring slot the CURRENT tile is read from / the next tile goes to
+  int issued = 0;
+#pragma unroll 1
+  for (int s = 0; s < 2; ++s) {  // prologue: two tiles in flight
+    if (issue_tile < ntiles) {
+      prepare(t_img, t_ty, t_tx, lds0 + issue_stage * STAGE);
+      WG_PIECE(0); WG_PIECE(1); WG_PIECE(2); WG_PIECE(3); WG_PIECE(4); WG_PIECE(5);
+      advance();
+      ++issued;
+    }
+    issue_tile += a.ksplit;
+    issue_stage = issue_stage == NSTAGE - 1 ? 0 : issue_stage + 1;
+  }
+  if (issued == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXOWN) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (; tile < ntiles; tile += a.ksplit) {
+    const bool more = issue_tile < ntiles;  // uniform
+    if (more) { prepare(t_img, t_ty, t_tx, lds0 + issue_stage * STAGE); advance(); }
+    issue_tile += a.ksplit;
+    issue_stage = issue_stage == NSTAGE - 1 ? 0 : issue_stage + 1;
+    const unsigned so = stage * STAGE;
+
+    u32x4 af[2][4], bf[3];
+    auto load_a = [&](int kb, int c) -> u32x4 {
+      const s16x4 lo = tr_read_at(dbase[c & 1][0] + so + 512 * (c >> 1) + 4096 * kb);
+      const s16x4 hi = tr_read_at(dbase[c & 1][1] + so + 512 * (c >> 1) + 4096 * kb);
+      return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto load_b = [&](int step) -> u32x4 {  // step = kb * 4 + tap
+      const int kb = step / TAPS, t = step % TAPS, kh = t / KS, kw = t % KS;
+      const s16x4 lo = tr_read_at(xbase[kw][0] + so + XROW * (4 * kb + kh));
+      const s16x4 hi = tr_read_at(xbase[kw][1] + so + XROW * (4 * kb + kh));
+      return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) af[0][c] = load_a(0, c);
+    bf[0] = load_b(0);
+    bf[1] = load_b(1);
+#pragma unroll
+    for (int step = 0; step < 2 * TAPS; ++step) {
+      const int kb = step / TAPS, t = step % TAPS;
+      if (step + 2 < 2 * TAPS) bf[(step + 2) % 3] = load_b(step + 2);
+      if (kb == 0) af[1][t] = load_a(1, t);  // second row block's dy fragments behind the first's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kb][c]), __builtin_bit_cast(bf16x8, bf[step % 3]),
+                                                            acc[t][c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // tile t + 2: one piece behind each of the first six steps
+      if (more) {
+        if (step == 0) WG_PIECE(0);
+        if (step == 1) WG_PIECE(1);
+        if (step == 2) WG_PIECE(2);
+        if (step == 3) WG_PIECE(3);
+        if (step == 4) WG_PIECE(4);
+        if (step == 5) WG_PIECE(5);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+    // own pieces of the tile after next may stay in flight; the next tile's have landed
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXOWN) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#undef WG_PIECE
+  float* slab = a.slabs + (size_t)by * TAPS * a.npad * a.kpad;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 64 * nh + c * 16 + 4 * grp + r, k = k0 + kq * 16 + i16;
+        if (kloc + kq * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+      }
+}
+
 // ---------------------------------------------------------------- fp32
 template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgArgs a) {
@@ -1639,6 +1826,9 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   } else if (fast && th == 4 && mode == MODE_W3S2 && o.wgrad_bt && cdy % 128 == 0 && npad % 128 == 0) {
     dim3 bgrid(fgrid.x / 2, fgrid.y);
     hipLaunchKernelGGL(wgrad_bf16_bt_s2_kernel, bgrid, dim3(512), 0, st, a);
+  } else if (fast && th == 4 && mode == MODE_W2S2 && o.wgrad_bt >= 1 && o.wgrad_t2 && cdy % 128 == 0 && npad % 128 == 0) {
+    dim3 bgrid(fgrid.x / 2, fgrid.y);
+    hipLaunchKernelGGL(wgrad_bf16_bt_t2_kernel, bgrid, dim3(512), 0, st, a);
   } else if (fast && th == 4 && mode == MODE_W3S1) {
     hipLaunchKernelGGL(wgrad_bf16_dma_kernel, fgrid, dim3(256), 0, st, a);
   } else if (fast && wgrad_two_wg(o, mode, dtype)) {  // stride-2 / transposed shapes stay on the one-workgroup-per-CU kernel

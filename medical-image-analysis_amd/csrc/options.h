@@ -20,6 +20,7 @@ struct MiaOptions {
   int wgrad_xcd;      // XCD-aware block order of the bf16 weight-gradient kernels             env MIA_WGRAD_XCD     default 1
   int wgrad_dma;      // LDS-DMA ring weight-gradient kernel (3x3 stride 1 bf16)               env MIA_WGRAD_DMA     default 1
   int wgrad_bt;       // 512-thread 128 n x 64 k weight-gradient kernel (3x3 stride 1 bf16, >= 128 output channels)   env MIA_WGRAD_BT      default 1
+  int wgrad_t2;       // ConvTranspose 2x2 weight gradient (bf16, >= 128 coarse channels) on the 512-thread three-stage ring kernel   env MIA_WGRAD_T2      default 1
   int wgrad_tab;      // table-driven staging of wgrad_bf16_2wg_kernel                         env MIA_WGRAD_TAB     default 1
   int wgrad_w8;       // two-workgroups-per-CU weight-gradient kernels                         env MIA_WGRAD_W8      default 1
   int stream_blocks;  // target block count of the norm / activation streaming passes          env MIA_STREAM_BLOCKS default 32768

@@ -668,6 +668,35 @@ def test_conv_pw_matches_tile_kernel_and_reference(case):
     assert relerr(nchw(outs[1][1]), xr.grad) < TOL[dt]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 128, 64, 64, 64), (1, 256, 128, 17, 23), (3, 128, 64, 9, 40), (1, 1024, 512, 8, 8), (1, 384, 192, 20, 12)])
+def test_wgrad_t2_matches_fast_kernel_and_reference(case):
+    """Option wgrad_t2 (csrc/conv_wgrad.hip::wgrad_bf16_bt_t2_kernel): the ConvTranspose2d 2x2 weight gradient on the 512-thread
+    three-stage ring; fp32 slabs of exact bf16 products -> agreement with the 256-thread kernel and with autograd to fp32 summation
+    order (reference: unet.py:142)."""
+    import mia_hip
+    from mia_hip import WGRAD_2S2, ops
+    dev = _dev()
+    n, cin, cout, h, w = case  # ConvTranspose2d(cin -> cout): coarse h x w, fine 2h x 2w
+    g = torch.Generator().manual_seed(sum(case))
+    dt = torch.bfloat16
+    x = q(torch.randn(n, cin, h, w, generator=g), dt)
+    wt = (torch.randn(cin, cout, 2, 2, generator=g) / math.sqrt(cin)).requires_grad_(True)
+    dout = q(torch.randn(n, cout, 2 * h, 2 * w, generator=g), dt)
+    F.conv_transpose2d(x, wt, None, stride=2).backward(dout)
+    xd, dd = nhwc(x, dt, dev), nhwc(dout, dt, dev)
+    outs = {}
+    try:
+        for flag in (1, 0):
+            mia_hip.set_option("wgrad_t2", flag)
+            outs[flag] = ops.conv_wgrad(WGRAD_2S2, dd, None, xd, wt.shape, cin, cout).clone()
+            torch.cuda.synchronize()
+    finally:
+        mia_hip.set_option("wgrad_t2", 1)
+    assert relerr(outs[1], wt.grad) < 1e-4 and relerr(outs[0], wt.grad) < 1e-4
+    assert torch.allclose(outs[1], outs[0], rtol=1e-4, atol=1e-4 * outs[0].abs().max().item())
+
+
 PW_S2_CASES = [  # n, cin, cout, h, w (input): strided 3x3 forward on conv_pw_kernel<G3S2> -- image borders on all four sides, odd input
     # sizes (the last row / column tap falls outside), K = 9 x 64 .. 9 x 512, with and without the statistics epilogue
     (2, 64, 128, 64, 64), (1, 128, 256, 32, 64), (3, 64, 128, 31, 63), (1, 512, 1024, 16, 32), (2, 128, 128, 128, 32),
