@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
     import mia_hip
-    from mia_hip import BF16, CONV_G2S2, CONV_G3S1, CONV_G3S2, CONV_T2S2, WGRAD_3S1, WGRAD_3S2, ops
+    from mia_hip import BF16, CONV_G2S2, CONV_G3S1, CONV_G3S2, CONV_T2S2, WGRAD_2S2, WGRAD_3S1, WGRAD_3S2, ops
     dev = torch.device("cuda:0")
     rng = random.Random(a.seed)
     bad = 0
@@ -49,7 +49,7 @@ def main():
         return x1, x0
 
     for case in range(a.cases):
-        kind = rng.choice(["conv_bt", "conv_pw", "conv_s2_wide", "conv64_dma", "wgrad_bt", "wgrad_bt_s2", "conv_pw_s2"])
+        kind = rng.choice(["conv_bt", "conv_pw", "conv_s2_wide", "conv64_dma", "wgrad_bt", "wgrad_bt_s2", "conv_pw_s2", "wgrad_t2"])
         n = rng.choice([1, 2, 3])
         h, w = rng.randint(3, 70), rng.randint(3, 90)
         msg, ok = "", True
@@ -110,6 +110,12 @@ def main():
             r1, r0 = ab("conv64_dma", 2, fn)
             ok = relerr(r1[0], r0[0]) < 1e-2 and (r1[1] is None or relerr(r1[1], r0[1]) < 1e-2)
             msg = f"two-destination={two} flip={flip}"
+        elif kind == "wgrad_t2":
+            cin, cout = rng.choice([(128, 64), (256, 128), (384, 192), (512, 256)])
+            x, dout = t(n, h, w, cin), t(n, 2 * h, 2 * w, cout)
+            g1, g0 = ab("wgrad_t2", 1, lambda: ops.conv_wgrad(WGRAD_2S2, dout, None, x, (cin, cout, 2, 2), cin, cout))
+            ok = relerr(g1, g0) < 1e-4
+            msg = f"cin={cin} cout={cout} relerr {relerr(g1, g0):.1e}"
         else:
             s2 = kind == "wgrad_bt_s2"
             cin, cout = rng.choice([(64, 128), (128, 128), (128, 256), (192, 384)])
