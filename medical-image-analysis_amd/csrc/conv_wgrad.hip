@@ -1717,6 +1717,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float* __
   }
 }
 
+// The same with four consecutive k per thread (16-byte slab loads; kk % 4 == 0): the 64-channel level's 75 MB of slabs took 52 us with
+// 4-byte loads.  Per element the slabs are added in the same order as in wgrad_reduce_small_kernel.
+__global__ __launch_bounds__(256) void wgrad_reduce_small4_kernel(const float* __restrict__ slabs, int ksplit, int taps, int npad,
+                                                                  int kpad, float* __restrict__ grad, int nn, int kk, int accumulate) {
+  __shared__ f32x4 sh[8][33];
+  const int e = threadIdx.x & 31, zl = threadIdx.x >> 5;
+  const int kq = kk >> 2, total = nn * kq * taps;
+  const int i = blockIdx.x * 32 + e;  // (t, n, k / 4), k fastest
+  const size_t sstride = (size_t)taps * npad * kpad;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  int t = 0, n = 0, k4 = 0;
+  if (i < total) {
+    k4 = i % kq; n = (i / kq) % nn; t = i / (kq * nn);
+    const float* src = slabs + ((size_t)t * npad + n) * kpad + 4 * k4;
+    int z = zl;
+    for (; z + 24 < ksplit; z += 32) {
+      f32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(src + (size_t)(z + 8 * j) * sstride);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += v[j];
+    }
+    for (; z < ksplit; z += 8) s += *reinterpret_cast<const f32x4*>(src + (size_t)z * sstride);
+  }
+  sh[zl][e] = s;
+  __syncthreads();
+  if (zl == 0 && i < total) {
+    f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r += sh[j][e];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float* dst = grad + ((size_t)n * kk + 4 * k4 + c) * taps + t;
+      *dst = accumulate ? *dst + r[c] : r[c];
+    }
+  }
+}
+
 // One thread per (n, k): consecutive lanes walk consecutive k, so every slab read is a coalesced row segment; the taps
 // of one (n, k) are adjacent in the parameter layout [n][k][taps], so a wave's stores tile a contiguous span.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit, int taps, int npad,
@@ -1870,9 +1908,15 @@ extern "C" int mia_wgrad_reduce(const float* slabs, int ksplit, int taps, int np
   // many slabs: split them over 8 lanes per element (the per-(n,k) kernel below walks all `ksplit` slabs serially, which is
   // latency bound -- 57 us for 75 MB at 512 slabs); few slabs: one thread per (n,k), all taps
   if ((total < 32768 || ksplit >= 8) && total * taps < ((int64_t)1 << 31)) {
-    const int blocks = (int)((total * taps + 31) / 32);
-    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs, ksplit,
-                       taps, npad, kpad, grad, nn, kk, accumulate);
+    if (kk % 4 == 0 && kpad % 4 == 0 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0) {
+      const int blocks = (int)((total / 4 * taps + 31) / 32);
+      hipLaunchKernelGGL(wgrad_reduce_small4_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs, ksplit,
+                         taps, npad, kpad, grad, nn, kk, accumulate);
+    } else {
+      const int blocks = (int)((total * taps + 31) / 32);
+      hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs, ksplit,
+                         taps, npad, kpad, grad, nn, kk, accumulate);
+    }
   } else {
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs, ksplit,
