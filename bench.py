@@ -152,12 +152,11 @@ def parity_gate_benchmarked(dev, channels, dt):
     top2 = ref.topk(2, dim=1).values
     safe = (top2[:, 0] - top2[:, 1]) > 2 * tol
     mism = int((out.argmax(1)[safe] != ref.argmax(1)[safe]).sum())
-    pg, pc = out.argmax(1), ref.argmax(1)
-    dices = [losses_ref.hard_dice(pg == k, pc == k) if (pc == k).any() else 1.0 for k in range(3)]
-    return {"config": f"UNet {channels} {size}x{size} bs2 {dt} (benchmarked widths and dtype) vs fp32 CPU oracle",
+    # no label-map Dice here: a random-init net's label maps sit on near-ties (see `parity_trained` for the Dice gate)
+    return {"config": f"UNet {channels} {size}x{size} bs2 {dt} (benchmarked widths and dtype, RANDOM-INIT weights: logit bound only) "
+                      f"vs fp32 CPU oracle",
             "max_abs_logit_diff": err, "logit_range": rng, "tolerance": tol, "loss_diff": abs(loss - ref_loss),
-            "label_map_mismatch_px_outside_tolerance_margin": mism, "hard_dice_gpu_vs_cpu_labelmaps": min(dices),
-            "ok": bool(err < tol and mism == 0)}
+            "label_map_mismatch_px_outside_tolerance_margin": mism, "ok": bool(err < tol and mism == 0)}
 
 
 def ellipse_set(n, s, seed=1337):

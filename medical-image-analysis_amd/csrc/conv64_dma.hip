@@ -41,7 +41,7 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 }
 // One LDS-DMA piece (64 lanes x 16 B -> lds_dst + 16 L); see conv_bt.hip::dma16.
 __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned voff, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

@@ -51,7 +51,7 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 // one statement (hipcc uses M0 for nothing else in this kernel); s_nop 4 covers the VALU-written-SGPR -> VMEM hazard of the
 // descriptor / offset operands, which hipcc does not pad inside an asm statement.
 __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory", "m0");
 }
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));

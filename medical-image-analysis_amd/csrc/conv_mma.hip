@@ -289,15 +289,20 @@ static int dispatch(int mode, const ConvArgs& a, int mt, int nt, int grid_y, hip
 }
 
 // Tile-domain geometry shared with the host (stats buffer sizing): see include/mia_hip.h.
-extern "C" int mia_conv_mma_tiles(int mode, int hout, int wout, int* tiles_y, int* tiles_x, int* tile_h) {
+static void conv_tiles(const MiaOptions& opt, int mode, int hout, int wout, int* tiles_y, int* tiles_x, int* tile_h) {
   const bool tmode = (mode == MODE_T3S2 || mode == MODE_T2S2);
   const int hd = tmode ? (hout + 1) / 2 : hout, wd = tmode ? (wout + 1) / 2 : wout;
   int mt = (mode == MODE_G3S2 || mode == MODE_G2S2) ? 2 : (hd > 8 ? 4 : 2);
-  if (mia_options().conv_mt8 && mode == MODE_G3S1 && hd >= 32) mt = 8;
+  if (opt.conv_mt8 && mode == MODE_G3S1 && hd >= 32) mt = 8;
   const int th = 4 * mt;
   if (tiles_y) *tiles_y = ceil_div(hd, th);
   if (tiles_x) *tiles_x = ceil_div(wd, 16);
   if (tile_h) *tile_h = th;
+}
+
+extern "C" int mia_conv_mma_tiles(int mode, int hout, int wout, int* tiles_y, int* tiles_x, int* tile_h) {
+  const MiaOptions opt = mia_options();
+  conv_tiles(opt, mode, hout, wout, tiles_y, tiles_x, tile_h);
   return MIA_OK;
 }
 
@@ -329,7 +334,7 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
   a.N = n; a.Hin = hin; a.Win = win; a.Hout = hout; a.Wout = wout;
   a.npad = npad; a.kpad = kpad; a.flip = flip_taps;
   int th;
-  mia_conv_mma_tiles(mode, hout, wout, &a.tiles_y, &a.tiles_x, &th);
+  conv_tiles(opt, mode, hout, wout, &a.tiles_y, &a.tiles_x, &th);  // same snapshot as the launch below
   int mt = th / 4;
   const int nout = o1 + o2;
   const int nt = nout > 32 ? 4 : (nout > 16 ? 2 : 1);

@@ -47,7 +47,7 @@ __device__ __forceinline__ i32x4 pw_rsrc_words(const void* p, unsigned bytes) {
 __device__ __forceinline__ void pw_dma16(i32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
   soff = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);        // wave-uniform by construction; tells hipcc so
   lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);
-  asm volatile("s_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void pw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

@@ -596,7 +596,7 @@ __device__ __forceinline__ void lds_dma16(wi32x4 rsrc, unsigned voff, unsigned l
   // M0 = wave-uniform LDS byte address of the 1 KB piece.  M0 is written and read inside this one statement and not restored:
   // hipcc uses M0 for nothing else in these kernels (checked in the ISA: no other reference to m0), and a save / restore
   // pair per piece is two more scalar instructions in the phase that has to hide behind the other workgroup's MFMAs.
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory", "m0");
 }
 
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) {

@@ -4,6 +4,11 @@
 // entry point takes ONE snapshot (`const MiaOptions o = mia_options();`) and passes it down, so a call never sees two values
 // of an option.  The fields are atomics: set / get / snapshot are safe from any thread.  Nothing else in the library reads
 // getenv or keeps a lazily-initialised knob.
+//
+// Geometry queries (mia_conv_mma_tiles, mia_wgrad_geometry, mia_wgrad_target_blocks) size the caller's statistics / slab
+// buffers in a SEPARATE call from the launch that fills them.  The options that change that geometry (conv_mt8, wgrad_dma,
+// wgrad_bt, wgrad_t2, wgrad_w8) are A/B knobs: mia_set_option on them must not race with compute calls of another thread
+// (set them between steps; the Python side does -- tools/ab_option.py).  Everything else may change at any time.
 #pragma once
 
 struct MiaOptions {

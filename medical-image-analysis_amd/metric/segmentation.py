@@ -63,7 +63,8 @@ def label_dice(pred: torch.Tensor, labels: torch.Tensor, k1: int) -> Tuple[torch
 
 
 @torch.no_grad()
-def valid_slices(model, processor, image_batch: torch.Tensor, label_batch: torch.Tensor, num_classes: int, loss_fn=None):
+def valid_slices(model, processor, image_batch: torch.Tensor, label_batch: torch.Tensor, num_classes: int, loss_fn=None,
+                 do_denoise: bool = False):
     """One validation step of `ALTrainer.valid_slices` (al_trainer.py:1415-1474) chained on the GPU:
     `processor.preprocess` (bilinear resize to the model size, unet_processor.py:35-47) -> eval forward ->
     `softmax(1).argmax(1)` -> (loss on labels nearest-resized to the output size, :1433-1449) -> `processor.postprocess`
@@ -71,23 +72,30 @@ def valid_slices(model, processor, image_batch: torch.Tensor, label_batch: torch
     `metric_all[b]` = Dice(pred > 0, label > 0), `metric_per_cls[b, c-1]` = Dice(pred == c, label == c), c = 1..num_classes,
     0 for an empty prediction (:1463-1472, :1539-1556).  Hausdorff / ASD / Jaccard columns of the reference's [B,4] arrays are
     CPU medpy / SimpleITK work and are not produced.  Returns (metric_all [B], metric_per_cls [B, num_classes], loss, pred)
-    -- device tensors, no host sync."""
+    -- device tensors, no host sync.  `do_denoise` is the reference's `config.postprocess_mask` (al_trainer.py:1445): the cv2
+    connected-component filter (unet_processor.py:72-135) is not built (cv2 is not importable), so True raises.  The model's
+    train / eval mode is restored on every exit path."""
     from transforms.hip import functional_hip as FH
+    if do_denoise:
+        raise NotImplementedError("valid_slices(do_denoise=True): the cv2 mask denoise (unet_processor.py:72-135) is not built")
     dev = next(model.parameters()).device
     image = image_batch.to(dev, dtype=torch.float32)
     label = label_batch.to(dev).long()
     was_training = model.training
     model.eval()
-    x = processor.preprocess(image)
-    output = model(x)
-    pred, _, _ = predict_and_dice(output)
-    loss = None
-    if loss_fn is not None:
-        ll = label
-        if pred.shape[-2:] != label.shape[-2:]:
-            ll = FH.resize_nearest(label.unsqueeze(1), int(output.shape[-2]), int(output.shape[-1])).squeeze(1)
-        loss = loss_fn(output, ll)
-    pred = processor.postprocess(pred, label.shape[-2:], do_denoise=False)
+    try:
+        x = processor.preprocess(image)
+        output = model(x)
+        pred, _, _ = predict_and_dice(output)
+        loss = None
+        if loss_fn is not None:
+            ll = label
+            if pred.shape[-2:] != label.shape[-2:]:
+                ll = FH.resize_nearest(label.unsqueeze(1), int(output.shape[-2]), int(output.shape[-1])).squeeze(1)
+            loss = loss_fn(output, ll)
+        pred = processor.postprocess(pred, label.shape[-2:], do_denoise=False)
+    finally:
+        model.train(was_training)
     k1 = num_classes + 1
     dice, counts = label_dice(pred, label, k1)
     n = float(label.shape[-2] * label.shape[-1])
@@ -95,6 +103,4 @@ def valid_slices(model, processor, image_batch: torch.Tensor, label_batch: torch
     pf, gf = n - p0, n - g0                       # |pred > 0|, |label > 0|
     inter = n - p0 - g0 + i0                      # |pred > 0 & label > 0| = N - |pred == 0 or label == 0|
     metric_all = torch.where(pf > 0, 2.0 * inter / (pf + gf).clamp_min(1.0), torch.zeros_like(pf))
-    if was_training:
-        model.train()
     return metric_all, dice[:, 1:], loss, pred

@@ -6,6 +6,7 @@ parameters as Python lists (uploaded as tiny device arrays); ``apply`` = list of
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import Optional, Sequence
 
 import torch
@@ -74,29 +75,40 @@ class ParamArena:
         if self.dry:
             self.items.append(np.ascontiguousarray(arr))
             return torch.empty(arr.shape, dtype=torch.float32 if arr.dtype == np.float32 else torch.int32, device="meta")
-        v = self.views[self.k]
-        if tuple(v.shape) != tuple(arr.shape):
-            raise MiaError("ParamArena: the real pass asked for a different parameter array than the dry pass")
+        if self.k >= len(self.views):
+            raise MiaError("ParamArena: the real pass asked for more parameter arrays than the dry pass registered")
+        v, reg = self.views[self.k], self.items[self.k]
+        # the k-th request of the real pass must be the k-th array of the dry pass: same shape, dtype AND bytes (a stage whose
+        # apply_batch is not pure w.r.t. host state -- RNG draws, counters -- would otherwise run on the wrong parameters)
+        if tuple(reg.shape) != tuple(arr.shape) or reg.dtype != arr.dtype or not np.array_equal(reg, arr):
+            raise MiaError("ParamArena: the real pass asked for a different parameter array than the dry pass "
+                           "(apply_batch must be pure with respect to host state)")
         self.k += 1
         return v
 
 
-_ARENA: Optional[ParamArena] = None  # set by transforms.gpu_pipeline.BatchedAugment around one batch
+_TLS = threading.local()  # the active arena is per THREAD: two pipelines in two worker threads never share one
 
 
 def set_arena(arena: Optional[ParamArena]) -> None:
-    global _ARENA
-    _ARENA = arena
+    """Set by transforms.gpu_pipeline.BatchedAugment around one batch (calling thread only)."""
+    _TLS.arena = arena
+
+
+def _arena() -> Optional[ParamArena]:
+    return getattr(_TLS, "arena", None)
 
 
 def _dry() -> bool:
-    return _ARENA is not None and _ARENA.dry
+    a = _arena()
+    return a is not None and a.dry
 
 
 def dev_array(arr: np.ndarray, dev) -> torch.Tensor:
     """float32 / int32 host array -> device tensor: a slice of the batch's single upload when an arena is active."""
-    if _ARENA is not None:
-        return _ARENA.take(arr)
+    a = _arena()
+    if a is not None:
+        return a.take(arr)
     return torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
 
 

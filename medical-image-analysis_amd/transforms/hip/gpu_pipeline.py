@@ -67,8 +67,13 @@ class BatchedAugment:
         FH.set_arena(arena)
         try:
             arena.begin_dry()
+            rng_before = torch.get_rng_state()
             self._run(torch.empty(images.shape, dtype=images.dtype, device="meta"),
                       torch.empty(labels.shape, dtype=labels.dtype, device="meta"), params, b)
+            # contract: `apply_batch` is pure w.r.t. host state -- every random draw happens in `draw()` above, in the
+            # reference's order; a stage that drew inside apply_batch would draw twice (dry + real) and shift the stream
+            if not torch.equal(rng_before, torch.get_rng_state()):
+                raise RuntimeError("BatchedAugment: a stage's apply_batch consumed the torch CPU generator; draws belong in draw()")
             arena.upload()
             images, labels, nbytes = self._run(images, labels, params, b)
         finally:

@@ -99,7 +99,8 @@ class RandomGaussianNoise(BaseTransform):
             noise = torch.stack([p[1] if p is not None else torch.zeros(images.shape[1:]) for p in params]).to(images.device)
             return FH.elementwise(images, FH.EW_NOISE, aux=noise, apply=on), labels
         seed = next((p[1] for p in params if p is not None), 0)
-        self._ctr += 1
+        if not FH._dry():  # the dry (parameter-collecting) pass of BatchedAugment must leave host state alone
+            self._ctr += 1
         return FH.noise_clip(images, [p[0] if p else 0.0 for p in params], seed, self._ctr, on), labels
 
     def get_params_dict(self):

@@ -15,6 +15,10 @@ Pinning status
   `scheduler/lr_scheduler.py` and `transforms/*.py` in the dev container and
   writes `tests/golden/*.npz`; `tests/test_oracle_golden.py` checks this
   restatement against those vectors.
+* active-learning selectors (entropy / confidence / margin scores, k-centre
+  greedy, k-means feature standardisation, BADGE gradient embeddings): PINNED
+  since round 4 by `tests/golden/selectors.npz`, produced by the reference's own
+  selector classes (`oracle/_refload.Ref.load_selectors`).
 * transforms whose arithmetic lives in torchvision (RandomAffine,
   RandomRotation, RandomCrop2D, JointResize, RandomGaussianBlur,
   RandomContrast, RandomBrightness): PARITY UNPINNED.  torchvision is a

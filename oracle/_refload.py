@@ -10,6 +10,12 @@ Recipe: ``models/unet/unet.py:6`` has an *unused*
 torchvision at module level; torchvision is not installed.  Empty placeholder
 modules satisfy those imports; no reference arithmetic is replaced -- every
 function that would actually *call* into torchvision is simply not used here.
+
+Selectors (``Ref.load_selectors``, round 4): ``activelearning/*.py`` import ``h5py`` (absent) and
+``datasets.active_dataset`` (the reference's dataset package needs PIL / h5py / skimage) at module level, the first only
+for the ``feature_path`` option and the second only for a type annotation.  Both get EMPTY placeholders for the duration
+of the import; ``utils`` is the reference's own ``utils/common.py`` loaded by path.  The selector arithmetic
+(softmax scores, ``kcenter_greedy``, feature standardisation, gradient embeddings) is the reference's, unmodified.
 """
 from __future__ import annotations
 
@@ -83,3 +89,45 @@ class Ref:
         self.t_image = _load("_ref_transforms.image_transform", os.path.join(REF_SRC, "transforms", "image_transform.py"))
         self.t_joint = _load("_ref_transforms.joint_transform", os.path.join(REF_SRC, "transforms", "joint_transform.py"))
         self.t_norm = _load("_ref_transforms.normalization", os.path.join(REF_SRC, "transforms", "normalization.py"))
+
+    def load_selectors(self):
+        """Load the reference's `activelearning` modules by path (see the module docstring).  Returns a namespace with
+        `entropy`, `confidence`, `margin`, `coreset`, `kmean`, `badge`, `random` modules."""
+        saved = {k: sys.modules.get(k) for k in ("h5py", "datasets", "datasets.active_dataset", "utils")}
+        h5 = types.ModuleType("h5py")
+
+        class _NoH5:
+            def __init__(self, *a, **k):
+                raise RuntimeError("h5py is not installed; the feature_path option is parity-unpinned")
+
+        h5.File = _NoH5
+        h5.Dataset = _NoH5
+        ds = types.ModuleType("datasets")
+        ds.__path__ = []
+        dsa = types.ModuleType("datasets.active_dataset")
+
+        class ActiveDataset:  # annotation only; the generator passes a duck-typed stand-in
+            pass
+
+        dsa.ActiveDataset = ActiveDataset
+        ds.active_dataset = dsa
+        try:
+            sys.modules["h5py"] = h5
+            sys.modules["datasets"] = ds
+            sys.modules["datasets.active_dataset"] = dsa
+            sys.modules["utils"] = _load("_ref_utils_common", os.path.join(REF_SRC, "utils", "common.py"))
+            ap = types.ModuleType("_ref_al")
+            ap.__path__ = [os.path.join(REF_SRC, "activelearning")]
+            sys.modules["_ref_al"] = ap
+            ns = types.SimpleNamespace()
+            _load("_ref_al.active_selector", os.path.join(REF_SRC, "activelearning", "active_selector.py"))
+            for short in ("random", "entropy", "confidence", "margin", "coreset", "kmean", "badge"):
+                setattr(ns, short, _load(f"_ref_al.{short}_selector",
+                                         os.path.join(REF_SRC, "activelearning", f"{short}_selector.py")))
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+        return ns

@@ -204,6 +204,94 @@ def gen_transforms(ref):
     np.savez_compressed(os.path.join(OUT, "transforms.npz"), **d)
 
 
+class _SelDS(torch.utils.data.Dataset):
+    """List-of-dicts dataset with the `image_idx` member the reference selectors read."""
+
+    def __init__(self, images, names):
+        self.images, self.image_idx = images, list(names)
+
+    def __len__(self):
+        return len(self.image_idx)
+
+    def __getitem__(self, i):
+        return {"image": self.images[i], "case_name": self.image_idx[i]}
+
+
+class _SelActive:
+    """Duck-typed stand-in for datasets/active_dataset.py:ActiveDataset (the four members the selectors touch)."""
+
+    def __init__(self, images, n_labeled):
+        names = [f"case_{i:02d}" for i in range(len(images))]
+        self.labeled_dataset = _SelDS(images[:n_labeled], names[:n_labeled])
+        self.pool_dataset = _SelDS(images[n_labeled:], names[n_labeled:])
+
+    def get_size(self):
+        return len(self.labeled_dataset), len(self.pool_dataset)
+
+    def get_pool_dataset(self):
+        return self.pool_dataset
+
+    def get_train_dataset(self):
+        return self.labeled_dataset
+
+
+def gen_selectors(ref):
+    """the reference's own selector classes (entropy / confidence / margin / coreset / k-means / BADGE) driven
+    by the reference UNet on a synthetic pool; `kcenter_greedy` on a fixed distance matrix."""
+    al = ref.load_selectors()
+    torch.manual_seed(7)
+    model = ref.unet.UNet(2, 1, 3, [8, 16, 32], normalization="instance", dropout_prob=None)
+    g = torch.Generator().manual_seed(9)
+    images = torch.rand(14, 1, 32, 32, generator=g)
+    images *= torch.linspace(0.2, 3.0, 14).view(-1, 1, 1, 1)  # spread the uncertainty: no near-tie rankings
+    n_labeled = 4
+    ad = _SelActive(images, n_labeled)
+    cpu = torch.device("cpu")
+    d = {"images": _np(images), "n_labeled": np.int64(n_labeled)}
+    for k, v in model.state_dict().items():
+        d["init/" + k] = _np(v)
+    model.eval()
+    with torch.no_grad():
+        d["pool_logits"] = _np(model(images[n_labeled:]))
+        d["enc_feature"] = _np(model.get_enc_feature(images))
+    for short, cls in (("entropy", al.entropy.EntropySelector), ("confidence", al.confidence.ConfidenceSelector),
+                       ("margin", al.margin.MarginSelector)):
+        sel = cls(batch_size=4, num_workers=0, pin_memory=False)
+        scores, names = sel.cal_scores(ad, model, cpu)
+        d[f"{short}/scores"] = _np(torch.stack(scores))
+        d[f"{short}/names"] = np.array(names)
+        d[f"{short}/picks3"] = np.array(sel.select_next_batch(ad, 3, model, cpu))
+    for metric, crit in (("cosine", "min"), ("l2", "min"), ("l2", "mean")):
+        cs = al.coreset.CoresetSelector(batch_size=5, num_workers=0, pin_memory=False, metric=metric, coreset_criteria=crit)
+        core, all_list, _, feats, dist = cs.cal_scores(ad, model, cpu)
+        key = f"coreset_{metric}_{crit}"
+        d[key + "/core"], d[key + "/all"], d[key + "/feats"], d[key + "/dist"] = core, all_list, feats, dist
+        d[key + "/picks4"] = np.array(cs.select_next_batch(ad, 4, model, cpu))
+    rg = np.random.default_rng(5)
+    pts = rg.normal(size=(24, 6))
+    dm = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+    d["kcenter/dist"] = dm
+    d["kcenter/init"] = np.array([0, 5, 9])
+    for crit in ("min", "mean"):
+        d[f"kcenter/{crit}_b6"] = np.array(sorted(int(i) for i in al.coreset.kcenter_greedy(dm, 24, 6, [0, 5, 9], crit)))
+    km = al.kmean.KMeanSelector(batch_size=5, num_workers=0, pin_memory=False, metric="l2")
+    lf, pf, ln, pn, p2l = km.cal_scores(ad, model, cpu)
+    d["kmean/labeled_feats"], d["kmean/pool_feats"], d["kmean/pool2labeled"] = lf, pf, p2l
+    d["kmean/pool_names"] = pn
+    np.random.seed(0)
+    d["kmean/picks3_npseed0"] = np.array(sorted(km.select_next_batch(ad, 3, model, cpu)))
+    comp = ref.compound.DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss)
+    bd = al.badge.BADGESelector(dice_loss=comp.dice_loss, ce_loss=comp.ce_loss, batch_size=1, num_workers=0, pin_memory=False)
+    bn, be = bd.cal_scores(ad, model, cpu)
+    d["badge/names"], d["badge/embeds"] = bn, be
+    # labelled set empty -> random pick (entropy_selector.py:62-70)
+    ad0 = _SelActive(images, 0)
+    torch.manual_seed(5)
+    d["entropy/picks5_empty_seed5"] = np.array(al.entropy.EntropySelector(4, 0, False).select_next_batch(ad0, 5, model, cpu))
+    np.savez_compressed(os.path.join(OUT, "selectors.npz"), **d)
+    print("selectors", sum(np.asarray(v).nbytes for v in d.values()) // 1024, "KiB raw")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -215,7 +303,7 @@ def main():
     gen_unet(ref, "res", "instance", [4, 8, 16], 32, block_type="res")
     gen_losses(ref)
     gen_poly(ref)
-    gen_transforms(ref)
+    gen_selectors(ref)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden total", tot // 1024, "KiB")
 

@@ -3,9 +3,11 @@
 * acquisition scores: entropy_selector.py:42-49, confidence_selector.py:42-47, margin_selector.py:42-48
 * k-centre greedy: coreset_selector.py:19-52, restated literally (re-slices the distance matrix every round)
 * row standardisation of encoder features: kmean_selector.py:98-104
-PARITY UNPINNED: the reference's selector modules import h5py and its dataset package at module level (neither is
-importable here) and the reference has no tests or fixtures for them, so these restatements follow the cited lines by
-reading only; the tests compare the HIP kernels and the incremental k-centre against THESE functions.
+PINNED (round 4): `oracle/_refload.Ref.load_selectors` imports the reference's own selector modules (empty placeholders for
+`h5py` -- only the `feature_path` option uses it -- and for the `datasets.active_dataset` type annotation), and
+`oracle/gen_golden.gen_selectors` drives them with the reference UNet on a synthetic pool -> `tests/golden/selectors.npz`;
+`tests/test_oracle_golden.py::test_selectors_oracle_vs_reference_vectors` checks these restatements against it.  Still
+unpinned: features read from `feature_path` *.h5 files (h5py is not importable here).
 """
 from __future__ import annotations
 

@@ -152,3 +152,45 @@ def test_full_width_fp32_logits_vs_oracle_256():
     top2 = want.topk(2, dim=1).values
     safe = (top2[:, 0] - top2[:, 1]) > 2e-4
     assert (got.argmax(1)[safe] == want.argmax(1)[safe]).all()
+
+
+def test_cfg2_full_size_fp32_properties():
+    """cfg2 at its own shape -- [64..1024], 256x256, batch 32, fp32 -- through size-independent properties:
+    instance-norm logits of 32 images == the same images in groups of 8 (bit-exact), one image of the batch against the CPU
+    oracle (1e-4), a train step's gradients run-to-run identical, a few steps lower the loss, everything finite."""
+    from losses.compound_losses import DiceAndCELoss
+    from oracle import unet_ref
+    from training.engine import TrainEngine
+    dev = _dev()
+    x, y = _batch(32, 256, seed=11)
+    batch = {"image": x.to(dev), "label": y.to(dev)}
+    m = _model(dev, torch.float32).eval()
+    with torch.no_grad():
+        full = m(batch["image"]).clone()
+        for i in range(0, 32, 8):
+            assert torch.equal(m(batch["image"][i:i + 8]), full[i:i + 8]), i
+    assert full.shape == (32, 3, 256, 256) and torch.isfinite(full).all()
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    with torch.no_grad():
+        want = unet_ref.unet_forward(params, x[17:18], normalization="instance", training=False)
+    got = full[17:18].cpu()
+    assert float((got - want).abs().max()) < 1e-4
+    top2 = want.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2e-4
+    assert (got.argmax(1)[safe] == want.argmax(1)[safe]).all()
+    del full
+    loss_fn = DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss)
+    eng = TrainEngine(m, loss_fn, "adam", {"weight_decay": 5e-4}, start_lr=1e-3, num_iters=100, lr_warmup_iter=0)
+    grads = []
+    for _ in range(2):
+        m.train()
+        loss = loss_fn(m(batch["image"]), batch["label"])
+        eng.optimizer.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append(eng.optimizer.flat_grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert torch.isfinite(grads[0]).all() and float(grads[0].abs().max()) > 0
+    losses = [eng.train_step(batch).item() for _ in range(5)]
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses

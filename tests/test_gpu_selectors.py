@@ -124,3 +124,57 @@ def test_feature_selectors_and_badge():
     picks = bd.select_next_batch(ad, 3, model, dev)
     assert len(picks) == 3 and set(picks) <= set(ad.pool_dataset.image_idx)
     assert all(q.grad is None or float(q.grad.abs().sum()) == 0.0 for q in model.parameters())  # model.zero_grad() after each embed
+
+
+def test_selectors_match_reference_vectors():
+    """SURVEY 8(f)2, pinned: the HIP selectors against `tests/golden/selectors.npz`, written by the REFERENCE's own
+    selector classes driving the reference UNet (`oracle/gen_golden.gen_selectors`): scores, picks, encoder features,
+    distance matrices, k-centre picks, standardised k-means features, BADGE gradient embeddings."""
+    from activelearning import (BADGESelector, ConfidenceSelector, CoresetSelector, EntropySelector, KMeanSelector,
+                                MarginSelector)
+    from activelearning.selectors import kcenter_greedy
+    from losses.compound_losses import DiceAndCELoss
+    from models.unet import UNet
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "selectors.npz"), allow_pickle=False))
+    dev = torch.device("cuda:0")
+    model = UNet(2, 1, 3, [8, 16, 32], normalization="instance", dropout_prob=None)
+    model.load_state_dict({k[5:]: torch.from_numpy(v.copy()) for k, v in d.items() if k.startswith("init/")})
+    model = model.to(dev)
+    images = torch.from_numpy(d["images"])
+    nl = int(d["n_labeled"])
+    ad = _ActiveDataset(images, nl)
+    for short, cls in (("entropy", EntropySelector), ("confidence", ConfidenceSelector), ("margin", MarginSelector)):
+        sel = cls(batch_size=4, num_workers=0, pin_memory=False)
+        scores, names = sel.cal_scores(ad, model, dev)
+        np.testing.assert_allclose(torch.stack(scores).cpu().numpy(), d[f"{short}/scores"], rtol=2e-4, atol=2e-6, err_msg=short)
+        assert list(names) == list(d[f"{short}/names"])
+        assert sel.select_next_batch(ad, 3, model, dev) == list(d[f"{short}/picks3"]), short
+    for metric, crit in (("cosine", "min"), ("l2", "min"), ("l2", "mean")):
+        key = f"coreset_{metric}_{crit}"
+        cs = CoresetSelector(batch_size=5, num_workers=0, pin_memory=False, metric=metric, coreset_criteria=crit)
+        core, all_list, _, feats, dist = cs.cal_scores(ad, model, dev)
+        assert list(core) == list(d[key + "/core"]) and list(all_list) == list(d[key + "/all"])
+        np.testing.assert_allclose(feats, d[key + "/feats"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(dist, d[key + "/dist"], rtol=2e-3, atol=1e-6)
+        assert sorted(cs.select_next_batch(ad, 4, model, dev)) == sorted(d[key + "/picks4"].tolist()), key
+    for crit in ("min", "mean"):  # the incremental k-centre against the reference's re-slicing one
+        got = kcenter_greedy(d["kcenter/dist"], 24, 6, d["kcenter/init"].tolist(), crit)
+        assert sorted(int(i) for i in got) == d[f"kcenter/{crit}_b6"].tolist(), crit
+    km = KMeanSelector(batch_size=5, num_workers=0, pin_memory=False, metric="l2")
+    lf, pf, ln, pn, p2l = km.cal_scores(ad, model, dev)
+    np.testing.assert_allclose(pf, d["kmean/pool_feats"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(lf, d["kmean/labeled_feats"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(p2l, d["kmean/pool2labeled"], rtol=1e-3, atol=1e-3)
+    assert list(pn) == list(d["kmean/pool_names"])
+    np.random.seed(0)  # kmeans_plusplus(random_state=None) draws from numpy's global generator, as in the reference run
+    assert sorted(km.select_next_batch(ad, 3, model, dev)) == d["kmean/picks3_npseed0"].tolist()
+    loss = DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss)
+    bd = BADGESelector(dice_loss=loss.dice_loss, ce_loss=loss.ce_loss, batch_size=1, num_workers=0, pin_memory=False)
+    bn, be = bd.cal_scores(ad, model, dev)
+    assert list(bn) == list(d["badge/names"])
+    np.testing.assert_allclose(be, d["badge/embeds"], rtol=2e-3, atol=2e-6)
+    ad0 = _ActiveDataset(images, 0)
+    torch.manual_seed(5)
+    assert EntropySelector(4, 0, False).select_next_batch(ad0, 5, model, dev) == list(d["entropy/picks5_empty_seed5"])

@@ -211,3 +211,53 @@ def test_elastic_restatement_known_answers():
     rnd = torch.randn(2, 4, 4, generator=g) * 5
     out = R.apply_elastic(lab, rnd)
     assert set(out.unique().tolist()) <= {0, 1, 2} and out.shape == lab.shape
+
+
+def test_selectors_oracle_vs_reference_vectors():
+    """`oracle/selectors_ref.py` against vectors the reference's own selector classes produced
+    (entropy_selector.py:42-49, confidence_selector.py:42-47, margin_selector.py:42-48, coreset_selector.py:19-52,
+    kmean_selector.py:95-104, badge_selector.py:19-34), driven by the reference UNet in `oracle/gen_golden.gen_selectors`."""
+    from oracle import selectors_ref as S
+    d = load("selectors.npz")
+    p = params_from(d)
+    images = torch.from_numpy(d["images"])
+    nl = int(d["n_labeled"])
+    with torch.no_grad():
+        logits = unet_ref.unet_forward(p, images[nl:], "instance", training=False)
+        feats = unet_ref.enc_feature(p, images, "instance").numpy()
+    np.testing.assert_allclose(logits.numpy(), d["pool_logits"], atol=1e-6)
+    np.testing.assert_allclose(feats, d["enc_feature"], atol=1e-6)
+    ref_logits = torch.from_numpy(d["pool_logits"])
+    names = [f"case_{i:02d}" for i in range(len(images))]
+    for short, fn in (("entropy", S.entropy_score), ("confidence", S.confidence_score), ("margin", S.margin_score)):
+        got = fn(ref_logits)
+        np.testing.assert_allclose(got.numpy(), d[f"{short}/scores"], rtol=1e-6, atol=1e-7, err_msg=short)
+        assert list(d[f"{short}/names"]) == names[nl:]
+        order = torch.sort(got, descending=True)[1][:3]
+        assert [names[nl + int(i)] for i in order] == list(d[f"{short}/picks3"]), short
+    for crit in ("min", "mean"):
+        got = S.kcenter_greedy(d["kcenter/dist"], 24, 6, d["kcenter/init"].tolist(), crit)
+        assert sorted(int(i) for i in got) == d[f"kcenter/{crit}_b6"].tolist(), crit
+    from sklearn.metrics import pairwise_distances
+    for metric, crit in (("cosine", "min"), ("l2", "min"), ("l2", "mean")):
+        key = f"coreset_{metric}_{crit}"
+        np.testing.assert_allclose(d[key + "/feats"], d["enc_feature"], atol=0)
+        dm = pairwise_distances(d["enc_feature"], metric=metric)
+        np.testing.assert_allclose(dm / dm.sum(), d[key + "/dist"], rtol=1e-5, atol=1e-9)
+        got = S.kcenter_greedy(d[key + "/dist"], len(images), 4, np.arange(nl), crit)
+        assert sorted(names[int(i)] for i in got) == sorted(d[key + "/picks4"].tolist()), key
+    np.testing.assert_allclose(S.row_standardise(d["enc_feature"][nl:]), d["kmean/pool_feats"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(S.row_standardise(d["enc_feature"][:nl]), d["kmean/labeled_feats"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pairwise_distances(d["kmean/pool_feats"], d["kmean/labeled_feats"], metric="l2"),
+                               d["kmean/pool2labeled"], rtol=1e-5, atol=1e-6)
+    # BADGE gradient embedding = d(CE + Dice on the pseudo labels) / d(decoder.seg_output.weight), one image per batch
+    for i in range(len(images) - nl):
+        q = {k: v.clone().requires_grad_(k == "decoder.seg_output.weight") for k, v in p.items()}
+        out = unet_ref.unet_forward(q, images[nl + i:nl + i + 1], "instance", training=False)
+        pred = out.softmax(1).argmax(1)
+        loss = losses_ref.ce_loss(out, pred) + losses_ref.dice_loss(out, pred, 2, do_bg=True)
+        (gr,) = torch.autograd.grad(loss, q["decoder.seg_output.weight"])
+        np.testing.assert_allclose(gr.flatten().numpy(), d["badge/embeds"][i], rtol=1e-4, atol=1e-7)
+    torch.manual_seed(5)
+    idx = torch.sort(torch.rand(len(images)), descending=True)[1][:5]
+    assert [names[int(i)] for i in idx] == list(d["entropy/picks5_empty_seed5"])
