@@ -221,16 +221,17 @@ def parity_gate_trained(dev, channels, dt, steps=60, size=128, nimg=16, batch=8,
 
 
 def pmc_traffic(config, batch, dt):
-    """HBM bytes per canonical conv launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_canonical_conv.json:
-    2 x FETCH_SIZE -- gfx950 half-count correction -- + WRITE_SIZE, separate --pmc passes, tools/pmc_conv64.sh)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_canonical_conv.json")
+    """Measured HBM bytes per launch of every kernel of the canonical block, from the committed rocprofv3 PMC passes
+    (profiles/r04_pmc_canonical_block.json, written by tools/r4_pmc_block.sh + tools/r4_pmc_block.py: FETCH_SIZE and WRITE_SIZE in
+    separate --pmc passes; bytes = (2 x FETCH_SIZE -- gfx950 half-count correction -- + WRITE_SIZE) x 1024).  {kernel: bytes} or None."""
+    path = os.path.join(ROOT, "profiles", "r04_pmc_canonical_block.json")
     try:
         rec = json.load(open(path))
     except Exception:
         return None
     if rec.get("config") != config or rec.get("batch") != batch or rec.get("dtype") != dt:
         return None
-    return 2.0 * rec["FETCH_SIZE_KB"] * 1024 + rec["WRITE_SIZE_KB"] * 1024
+    return {k: v["hbm_bytes"] for k, v in rec["kernels"].items() if "hbm_bytes" in v}
 
 
 def main():
@@ -267,6 +268,9 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the ring kernels of the gradient all-reduce run in the CUs TrainEngine reserves (dp_reserve_cus = 8, one per XCD):
+        # 8 channels move cfg3's 124 MB in a few ms against ~30 ms of backward, and the compute grids never wait for a CU
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -417,13 +421,15 @@ def main():
             esz = 2 if dt == "bf16" else 4
             abytes = 2.0 * c0 * size * size * batch * esz + 9 * c0 * c0 * esz
             ach = flops / (avg_ms * 1e-3) / 1e12
-            traffic = pmc_traffic(args.config, batch, dt)
+            pmc = pmc_traffic(args.config, batch, dt) or {}
             persistent = dt == "bf16" and c0 == 64 and mia_hip.get_option("conv64") != 0
+            fused = persistent and ops.FUSE_NL  # both canonical launches consume the previous block's raw output (normalise-on-load)
             bigtile = (not persistent and dt == "bf16" and mia_hip.get_option("conv_bt") != 0 and c0 % 32 == 0 and c0 >= 64 and
                        any(c0 % n == 0 for n in (128, 96, 64)))  # conv_bt_eligible (csrc/conv_bt.hip)
-            kname = (f"conv64_persist_kernel {c0}->{c0} 3x3 @{size}x{size} x{batch}" if persistent else
+            kname = (f"conv64_persist_kernel<{'NL' if fused else 'plain'}> {c0}->{c0} 3x3 @{size}x{size} x{batch}" if persistent else
                      f"conv_bt_kernel<{128 if c0 % 128 == 0 else 96 if c0 % 96 == 0 else 64}-channel blocks> {c0}->{c0} 3x3 @{size}x{size} x{batch}" if bigtile else
                      f"conv_mma_fast_kernel<{dt},G3S1,MT4,NT4> {c0}->{c0} 3x3 @{size}x{size} x{batch}") + " (encoder.levels.0.1 / decoder.levels.3.1)"
+            traffic = pmc.get("conv_nl" if fused else "conv_or_dgrad")
             gbs = abytes / (avg_ms * 1e-3) / 1e9
             t_hbm, t_mfma = abytes / (PEAK_HBM_GBS * 1e9), flops / (PEAK_MFMA_TFLOPS[dt] * 1e12)
             mfma = {"achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS[dt], "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS[dt], 4)}
@@ -434,25 +440,41 @@ def main():
                         "avg_launch_ms": round(avg_ms, 4), "launches": len(kt), "flops_per_launch": flops,
                         "algorithmic_bytes_per_launch": abytes, "mfma": mfma, "hbm": hbmr}
             # THE BLOCK (north_star: ">= 70 % of HBM roofline on the fused 3x3 conv block"; SURVEY 8d prices it at read x once +
-            # write z once): conv launch + statistics finalize + normalise / LeakyReLU apply, all three timed here.  The conv's
-            # raw output y makes one extra HBM round trip between conv and apply, so the block's traffic is ~2x algorithmic.
+            # write z once).  Fused (round 4): the conv takes the previous block's RAW output and normalises on load, writes its
+            # own raw output + statistics, and its own norm + LeakyReLU is applied on load by ITS consumer -- for
+            # decoder.levels.3.1 that is the head kernel, so that block is conv + finalize and nothing else: one activation read,
+            # one written.  encoder.levels.0.1 (same conv) still needs an apply pass because the consumers of its output (the
+            # stride-2 conv of level 1, the decoder's two-source LDS-DMA conv and their weight gradients) cannot transform on
+            # load; that block is reported beside it as `encoder_block` (conv + finalize + apply).
             torch.cuda.synchronize()
             fin = [a_.elapsed_time(b_) for a_, b_ in block_log["finalize"]]
             app = [a_.elapsed_time(b_) for a_, b_ in block_log["apply"]]
-            if fin and app:
-                fin_ms, app_ms = sum(fin) / len(fin), sum(app) / len(app)
-                blk_ms = avg_ms + fin_ms + app_ms
+
+            def _block(parts, desc, tr):
+                blk_ms = sum(parts.values())
                 bgbs = abytes / (blk_ms * 1e-3) / 1e9
-                roof = {"bound": "hbm", "achieved": round(bgbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(bgbs / PEAK_HBM_GBS, 4),
-                        "traffic": (traffic + 2.0 * c0 * size * size * batch * esz) if traffic else None,
-                        "kernel": f"PlainBlock {c0}->{c0} @{size}x{size} x{batch}: conv + norm_finalize + norm_act_fwd (blocks.py:83-102)",
-                        "avg_launch_ms": round(blk_ms, 4), "parts_ms": {"conv": round(avg_ms, 4), "norm_finalize": round(fin_ms, 4),
-                                                                         "norm_act_fwd": round(app_ms, 4)},
+                return {"bound": "hbm", "achieved": round(bgbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(bgbs / PEAK_HBM_GBS, 4),
+                        "traffic": tr, "kernel": desc, "avg_launch_ms": round(blk_ms, 4), "parts_ms": {k: round(v, 4) for k, v in parts.items()},
                         "launches": len(kt), "algorithmic_bytes_per_launch": abytes, "flops_per_launch": flops,
                         "mfma": {"achieved": round(flops / (blk_ms * 1e-3) / 1e12, 2), "peak": PEAK_MFMA_TFLOPS[dt], "unit": "TFLOP/s",
-                                 "frac": round(flops / (blk_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS[dt], 4)},
-                        "conv": conv_rec}
+                                 "frac": round(flops / (blk_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS[dt], 4)}}
+
+            if fin and app:
+                fin_ms, app_ms = sum(fin) / len(fin), sum(app) / len(app)
+                tsum = lambda *ks: (sum(pmc[k] for k in ks) if all(k in pmc for k in ks) else None)
+                unf = _block({"conv": avg_ms, "norm_finalize": fin_ms, "norm_act_fwd": app_ms},
+                             f"PlainBlock {c0}->{c0} @{size}x{size} x{batch} (encoder.levels.0.1): conv{' (normalise-on-load)' if fused else ''} + "
+                             "norm_finalize + norm_act_fwd (blocks.py:83-102)",
+                             tsum("conv_nl" if fused else "conv_or_dgrad", "norm_finalize", "norm_act_fwd"))
+                if fused:
+                    roof = _block({"conv_nl": avg_ms, "norm_finalize": fin_ms},
+                                  f"fused PlainBlock {c0}->{c0} @{size}x{size} x{batch} (decoder.levels.3.1): conv64_persist_kernel<NL> (normalises "
+                                  "its input on load, writes raw output + statistics) + norm_finalize; its own norm + LeakyReLU is applied "
+                                  "on load by its consumer, the head kernel (blocks.py:83-102, unet.py:157-176)", tsum("conv_nl", "norm_finalize"))
+                    roof["encoder_block"] = unf
+                else:
+                    roof = unf
+                roof["conv"] = conv_rec
             else:
                 roof = conv_rec
         if roof is not None:

@@ -90,6 +90,12 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
  *                                  LDS staging table) and 0 the one-workgroup-per-CU kernel
  *   stream_blocks (MIA_STREAM_BLOCKS, 32768)   target block count of the norm / activation streaming passes
  *   stem_mfma (MIA_STEM_MFMA, 1)   matrix-core stem kernel for fp32 images
+ *   reserve_cus (MIA_RESERVE_CUS, 0)   CUs the persistent kernels leave free (0..64, rounded so that the grids stay
+ *                                  multiples of 8): the grids of conv_bt / conv_pw / conv64 / conv64_dma shrink to CUs - k
+ *                                  workgroups (same work items: bit-identical results) and mia_wgrad_target_blocks follows
+ *                                  (different split-K count: deterministic, not bit-identical across settings).  Set by
+ *                                  the data-parallel trainer (training/engine.py) so that RCCL's ring kernels find CUs
+ *                                  while a persistent kernel runs (all-reduce overlapped with backward)
  * Do not change wgrad_* between mia_wgrad_geometry and the mia_conv_wgrad it sizes.  The Python loader applies
  * MIA_OPTIONS="name=value,..." through mia_set_option.  Unknown name: MIA_EARG. */
 int mia_set_option(const char* name, int value);
@@ -104,6 +110,20 @@ int mia_conv_mma_tiles(int mode, int hout, int wout, int* tiles_y, int* tiles_x,
 int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const void* in2, int c2, const void* wpack, int npad,
                  int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2, int o2,
                  float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream);
+
+/* Fused PlainBlock, consumer side ("normalise-on-load"; SURVEY 8b export list: conv3x3 with "optional fused normalise +
+ * LeakyReLU on load taking per-(n,c) scale/shift").  Replaces, for a PlainBlock whose only consumer is the next block's conv
+ * (the two blocks of one encoder / decoder level, unet.py:54-76, 157-173), the producer's InstanceNorm/BatchNorm + LeakyReLU
+ * pass (blocks.py:98-102): y_in is the producer's RAW conv output [N][H][W][c1] and the conv stages
+ * x = lrelu(in_scale[n][c] * y + in_shift[n][c]) (fp32 fma, select, round to nearest even: bit for bit what
+ * mia_norm_act_fwd would have written), zero padding applied to x.  in_scale / in_shift = the `scale` / `shift` rows that
+ * mia_norm_finalize wrote ([N][c1], Dropout2d multipliers folded in).  One source, one destination, forward taps.
+ * mia_conv_nl_supported: 1 if a kernel serves the shape (today: 3x3 stride 1, bf16, 64 -> 64 channels, H > 8), else 0 --
+ * the caller then materialises the activation with mia_norm_act_fwd and uses mia_conv_mma. */
+int mia_conv_nl_supported(int mode, int dtype, int c1, int nout, int hout, int wout);
+int mia_conv_mma_nl(int mode, int dtype, const void* y_in, int c1, const float* in_scale, const float* in_shift, float slope,
+                    const void* wpack, int npad, int kpad, const float* bias, void* out, int nout, float* stat_partials,
+                    int n, int hin, int win, int hout, int wout, void* stream);
 
 /* Stem: Conv2d(1, C0, 3, padding=1) (first encoder block, unet.py:54-66 with input_channels=1): HBM-streaming VALU
  * kernels (9 FMAs per output; MFMA would idle 31/32 of its K).  x is the [N][H][W] image in x_dtype (fp32 or bf16),
@@ -125,6 +145,14 @@ int mia_wgrad_target_blocks(int mode, int dtype); /* split-K workgroups to aim f
 int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x);
 int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const void* x2, int c2, const void* dy, int cdy,
                    float* slabs, int ksplit, int npad, int kpad, int n, int hx, int wx, int hy, int wy, void* stream);
+/* mia_conv_wgrad with normalise-on-load of x (backward half of the fused PlainBlock, see mia_conv_mma_nl): y_in is the raw
+ * conv output of the PRODUCING block, x = lrelu(in_scale[n][k] * y + in_shift[n][k]) is formed while the tile is staged (zero
+ * outside the image), so the activation the weight gradient of blocks.py:83-90 contracts with is never read from memory.
+ * 3x3 stride 1, bf16, one source; slabs / ksplit / reduce exactly as for mia_conv_wgrad. */
+int mia_wgrad_nl_supported(int mode, int dtype, int c1, int cdy);
+int mia_conv_wgrad_nl(int mode, int dtype, const void* y_in, int c1, const float* in_scale, const float* in_shift, float slope,
+                      const void* dy, int cdy, float* slabs, int ksplit, int npad, int kpad, int n, int hx, int wx, int hy,
+                      int wy, void* stream);
 int mia_wgrad_reduce(const float* slabs, int ksplit, int taps, int npad, int kpad, float* grad, int nn, int kk,
                      int accumulate, void* stream);
 

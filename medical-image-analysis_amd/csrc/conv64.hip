@@ -87,9 +87,19 @@ extern "C" int mia_conv64_debug_read(unsigned long long* host_out) {
 #define STAMP(var) do { } while (0)
 #endif
 
+// NL = normalise-on-load (the "fused block": reference blocks.py:98-102 of the PRODUCING block folded into this conv): `a.in1`
+// holds the producer's raw conv output y and the staged value is bf16(lrelu(scale[n][c] * y + shift[n][c])) -- the same fp32
+// fma / select / round-to-nearest-even as norm_act_fwd_stream_kernel, so the conv sees bit for bit the activation the apply
+// pass would have written, and that pass (read y + write z) never runs.  The transform sits in commit() (between the two tile
+// barriers, beside the co-resident workgroup's MFMAs): per 16-byte unit 2 x 4 unpack + 4 v_pk_fma + 4 v_pk_mul + 8 v_max + 4
+// v_cvt_pk; the 16 x 2 coefficients of a thread's channels come from a 512-byte LDS table refreshed per tile by threads
+// 0..127 (one extra VGPR across the matrix phase).  Zero padding is padding of z, not of y: halo units outside the image
+// are forced back to zero (border tiles only; 6 validity bits per thread).
+template <bool NL>
 __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a, int total_tiles, int tiles_per_img, int run, int n_base) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + (NL ? 2 * C * 4 : 0)];
   u32x4* ldsA = reinterpret_cast<u32x4*>(smem);
+  float* cf = reinterpret_cast<float*>(smem + LDS_BYTES);  // NL: [0, 64) scale, [64, 128) shift of the image being committed
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
   bf16_t* out = static_cast<bf16_t*>(n_base ? a.out2 : a.out1);
 
   u32x4 pf[2 * A_IT];
+  float cpf = 0.f;            // NL: this thread's entry of the fetched tile's coefficient table (threads 0..127)
   auto fetch = [&](const Tile& t) {
     const rsrc_t rs = make_rsrc(in + (size_t)t.img * ipix * C, img_bytes);
     const int iy0 = t.ty * TH - 1, ix0 = t.tx * TW - 1;
@@ -155,6 +166,9 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
     asm volatile("" : "+v"(p4v));
     const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= a.Hin && ix0 + IW <= a.Win;  // uniform: no border tests needed
     const int tile_off = (iy0 * a.Win + ix0) * (C * 2) + g * 16;
+    if constexpr (NL) {
+      if (wave < 2) cpf = (wave == 0 ? a.nl_scale : a.nl_shift)[(size_t)t.img * C + lane];  // wave-uniform pointer: wave 0 = scales, wave 1 = shifts
+    }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int pix = p4v + 64 * i, iy = pix / IW, ix = pix - iy * IW;
@@ -172,7 +186,50 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
       pf[2 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 64, 0);
     }
   };
-  auto commit = [&]() {
+  // NL: one 16-byte unit (8 bf16 channels: dword d = channels 2d | 2d+1) -> bf16(lrelu(sc * y + sh)), zero if !keep.
+  // Packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32: one issue slot per channel PAIR); per dword 2 unpack + pk_fma + pk_mul +
+  // 2 v_max + v_cvt_pk (+ v_and in border tiles).
+  auto xform = [&](const u32x4& raw, const f32x4& sa, const f32x4& sb, const f32x4& ha, const f32x4& hb, auto mask_tag, unsigned keep) -> u32x4 {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    u32x4 o;
+    const f32x2_t sl2 = {a.nl_slope, a.nl_slope};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const unsigned w = raw[d];
+      const f32x2_t sc = d == 0 ? f32x2_t{sa[0], sa[1]} : d == 1 ? f32x2_t{sa[2], sa[3]} : d == 2 ? f32x2_t{sb[0], sb[1]} : f32x2_t{sb[2], sb[3]};
+      const f32x2_t sh = d == 0 ? f32x2_t{ha[0], ha[1]} : d == 1 ? f32x2_t{ha[2], ha[3]} : d == 2 ? f32x2_t{hb[0], hb[1]} : f32x2_t{hb[2], hb[3]};
+      const f32x2_t x = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
+      const f32x2_t v = __builtin_elementwise_fma(sc, x, sh);
+      const f32x2_t m = v * sl2;
+      const unsigned r = pack_bf16x2(__builtin_fmaxf(v[0], m[0]), __builtin_fmaxf(v[1], m[1]));  // max(v, slope v) == (v > 0 ? v : slope v), 0 <= slope <= 1
+      o[d] = MASK ? (r & keep) : r;
+    }
+    return o;
+  };
+  auto commit = [&](const Tile& t) {
+    if constexpr (NL) {
+      const f32x4* cf4 = reinterpret_cast<const f32x4*>(cf);  // channels 8g .. 8g+7 (half 0) and 32 + 8g .. (half 1)
+      const int iy0 = t.ty * TH - 1, ix0 = t.tx * TW - 1;
+      const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + IH <= a.Hin && ix0 + IW <= a.Win;  // uniform
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // one channel half at a time: 16 coefficient registers live, not 32
+        const f32x4 sa = cf4[8 * h + 2 * g], sb = cf4[8 * h + 2 * g + 1], ha = cf4[16 + 8 * h + 2 * g], hb = cf4[17 + 8 * h + 2 * g];
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) pf[2 * i + h] = xform(pf[2 * i + h], sa, sb, ha, hb, std::false_type{}, 0u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!interior) {  // border tile: halo units outside the image go back to zero (validity recomputed as in fetch)
+        int p4v = p4;
+        asm volatile("" : "+v"(p4v));
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+          const int pix = p4v + 64 * i, iy = pix / IW, ix = pix - iy * IW;
+          const unsigned keep = 0u - (unsigned)(((unsigned)(iy0 + iy) < (unsigned)a.Hin) & ((unsigned)(ix0 + ix) < (unsigned)a.Win));
+#pragma unroll
+          for (int d = 0; d < 4; ++d) { pf[2 * i][d] &= keep; pf[2 * i + 1][d] &= keep; }
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       ldsA[g * NPA + p4 + 64 * i] = pf[2 * i];
@@ -184,7 +241,11 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
   if (t >= total_tiles) return;  // uniform per workgroup
   Tile cur = decode(t);
   fetch(cur);
-  commit();
+  if constexpr (NL) {
+    if (tid < 2 * C) cf[tid] = cpf;
+    __syncthreads();
+  }
+  commit(cur);
   __syncthreads();
 
 #ifdef CONV64_STAMPS
@@ -295,9 +356,12 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
     acc_f += ts1 - ts0; acc_m += ts2 - ts1; acc_e += ts3 - ts2; ntl += 1;
 #endif
     if (!more) break;
+    if constexpr (NL) {  // nobody reads the table outside commit(): safe to refresh it in front of the barrier
+      if (tid < 2 * C) cf[tid] = cpf;
+    }
     __syncthreads();  // every wave has read the current image out of LDS
     STAMP(ts4);
-    commit();
+    commit(nxt);
     __syncthreads();
     STAMP(ts5);
 #ifdef CONV64_STAMPS
@@ -316,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
 
 bool conv64_eligible(int mode, int dtype, const ConvArgs& a) {
   if (mode != MODE_G3S1 || dtype != MIA_BF16) return false;
+  if (a.nl_scale != nullptr && (a.o2 != 0 || a.nl_shift == nullptr || !(a.nl_slope >= 0.f && a.nl_slope <= 1.f))) return false;
   if (a.c1 != C || a.c2 != 0 || a.o1 != C || (a.o2 != 0 && a.o2 != C) || a.npad != a.o1 + a.o2 || a.kpad != C) return false;
   if (!a.vec_in || !a.vec_out) return false;
   if ((size_t)a.Hin * a.Win * C * 2 >= ((size_t)1 << 31)) return false;
@@ -323,15 +388,20 @@ bool conv64_eligible(int mode, int dtype, const ConvArgs& a) {
   return true;
 }
 
-int conv64_launch(const ConvArgs& a, int blocks_override, hipStream_t st) {
+int conv64_launch(const ConvArgs& a, int blocks_override, int reserve, hipStream_t st) {
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   const int total = a.N * tiles_per_img;
   // two workgroups per CU (256 CUs); a multiple of 8 so the per-XCD runs tile the step exactly
-  int nblk = total < 512 ? ((total + 7) / 8) * 8 : 512;
+  const int cap = 2 * persistent_cus(256, reserve);  // two workgroups per CU
+  int nblk = total < cap ? ((total + 7) / 8) * 8 : cap;
   if (blocks_override >= 8 && blocks_override % 8 == 0 && blocks_override <= nblk) nblk = blocks_override;  // option conv64_blocks (diagnostics)
   const int run = nblk / 8;
-  hipLaunchKernelGGL(conv64_persist_kernel, dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, 0);
+  if (a.nl_scale != nullptr) {
+    hipLaunchKernelGGL(conv64_persist_kernel<true>, dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, 0);
+    return MIA_OK;
+  }
+  hipLaunchKernelGGL(conv64_persist_kernel<false>, dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, 0);
   if (a.o2 == C)  // second destination (e.g. the up-sampled half of a decoder block's input gradient): same input, next 64 filters
-    hipLaunchKernelGGL(conv64_persist_kernel, dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, C);
+    hipLaunchKernelGGL(conv64_persist_kernel<false>, dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, C);
   return MIA_OK;
 }

@@ -426,11 +426,10 @@ static int cd_num_cus() {
   return n;
 }
 
-int conv64_dma_launch(const ConvArgs& a, hipStream_t st) {
+int conv64_dma_launch(const ConvArgs& a, int reserve, hipStream_t st) {
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   const int total = a.N * tiles_per_img;
-  int ncu = cd_num_cus() & ~7;
-  if (ncu < 8) ncu = 8;
+  const int ncu = persistent_cus(cd_num_cus(), reserve);
   const int nblk = total < ncu ? ((total + 7) / 8) * 8 : ncu;  // one workgroup per CU; a multiple of 8: per-XCD runs tile the step
   const int run = nblk / 8;
   if (a.o2 == C) hipLaunchKernelGGL(conv64_dma_kernel<128>, dim3(nblk), dim3(512), 0, st, a, total, tiles_per_img, run);

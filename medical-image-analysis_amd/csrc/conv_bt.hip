@@ -625,21 +625,21 @@ static int bt_num_cus() {  // one persistent workgroup per CU (device-properties
 }
 
 template <int WC, int NCT, int MT>
-static void bt_launch(const ConvArgs& a, int nch, int order, hipStream_t st) {
+static void bt_launch(const ConvArgs& a, int nch, int order, int reserve, hipStream_t st) {
   const int tx32 = (a.tiles_x + 1) / 2;
   const int ptiles = a.N * a.tiles_y * tx32;
   const int nb = (a.o1 + a.o2) / nch;
   const int nwork = ptiles * nb;
-  const int ncu = bt_num_cus();
+  const int ncu = reserve > 0 ? persistent_cus(bt_num_cus(), reserve) : bt_num_cus();
   const int tile_major = (order != 0 && nb > 1 && ptiles % 8 == 0) ? nb : 0;
   hipLaunchKernelGGL((conv_bt_kernel<WC, NCT, MT>), dim3(nwork < ncu ? nwork : ncu), dim3(512), 0, st, a, ptiles, tx32, nwork, tile_major);
 }
 
-int conv_bt_launch(const ConvArgs& a, int order, hipStream_t st) {
+int conv_bt_launch(const ConvArgs& a, int order, int reserve, hipStream_t st) {
   const int nch = bt_nch(a);
-  if (nch == 128) bt_launch<2, 4, 8>(a, nch, order, st);
-  else if (nch == 96) bt_launch<2, 3, 8>(a, nch, order, st);
-  else if (nch == 64) bt_launch<1, 4, 4>(a, nch, order, st);
+  if (nch == 128) bt_launch<2, 4, 8>(a, nch, order, reserve, st);
+  else if (nch == 96) bt_launch<2, 3, 8>(a, nch, order, reserve, st);
+  else if (nch == 64) bt_launch<1, 4, 4>(a, nch, order, reserve, st);
   else return MIA_EARG;
   return MIA_OK;
 }

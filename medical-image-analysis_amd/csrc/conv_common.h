@@ -15,6 +15,9 @@ struct ConvArgs {
   int st_tiles_y;  // rows of the statistics tile grid (8-row tiles under the 512-thread stride-2 kernel's 16-row tiles; else = tiles_y)
   int vec_in, vec_out;
   int xcd;  // fast kernel: XCD-aware block order (the blocks that share an input tile run on one XCD, back to back)
+  // normalise-on-load (mia_conv_mma_nl): in1 is the RAW conv output y of the producing PlainBlock and the kernel forms
+  // lrelu(nl_scale[n][c] * y + nl_shift[n][c]) while staging it; nullptr = in1 is an ordinary activation
+  const float* nl_scale = nullptr; const float* nl_shift = nullptr; float nl_slope = 0.f;
 };
 
 __device__ __forceinline__ int pi16(int r) {
@@ -52,6 +55,13 @@ template <> struct Mma<float> {
 };
 
 
+// `reserve_cus` (option of the same name): the persistent kernels below size their grids to the CU count; under data parallelism
+// RCCL's ring kernels need somewhere to run WHILE a persistent kernel owns the chip, and because the work lists are static
+// (workgroup b takes items b, b + G, ...) a workgroup that cannot be placed would not lose a share of the work but run AFTER
+// the others: one occupied CU doubles the launch.  With k CUs reserved the grids use (CUs - k) workgroups (a multiple of 8: one
+// free CU per XCD for k = 8); the items are the same, so results are bit-identical for every k.
+inline int persistent_cus(int ncu, int reserve) { int v = (ncu - reserve) & ~7; return v < 8 ? 8 : v; }
+
 // conv_mma_fast.hip: branch-free variant (buffer loads/stores with hardware OOB zero-fill); returns false when the
 // shape does not meet its alignment contract and the generic kernel must be used.
 bool conv_mma_fast_eligible(int dtype, const ConvArgs& a, int nt);
@@ -60,19 +70,19 @@ int conv_mma_fast_launch(int mode, int dtype, const ConvArgs& a, int mt, int nt,
 // conv64.hip: persistent 64 -> 64 channel 3x3 / stride-1 bf16 kernel with register-resident weights (the canonical block
 // launch of the benchmark and its input gradient); false = shape outside its contract.
 bool conv64_eligible(int mode, int dtype, const ConvArgs& a);
-int conv64_launch(const ConvArgs& a, int blocks_override, hipStream_t st);
+int conv64_launch(const ConvArgs& a, int blocks_override, int reserve_cus, hipStream_t st);
 
 // conv_bt.hip: 512-thread "big tile" LDS-DMA kernel for the stride-1 3x3 bf16 convs with >= 64-channel blocks (levels >= 1
 // of the network, the decoder's two-source convs, cfg5's 96-multiples); false = shape outside its contract.
 bool conv_bt_eligible(int mode, int dtype, const ConvArgs& a);
-int conv_bt_launch(const ConvArgs& a, int order /* option conv_bt_order: 1 = tile-major item order */, hipStream_t st);
+int conv_bt_launch(const ConvArgs& a, int order /* option conv_bt_order: 1 = tile-major item order */, int reserve_cus, hipStream_t st);
 
 // conv64_dma.hip: second generation of the 64 -> 64 (| 64) kernel: 512 threads per CU, LDS-DMA ring of three input tiles, one
 // barrier per tile; both destinations of a two-destination input gradient in one pass.
 bool conv64_dma_eligible(int mode, int dtype, const ConvArgs& a);
-int conv64_dma_launch(const ConvArgs& a, hipStream_t st);
+int conv64_dma_launch(const ConvArgs& a, int reserve_cus, hipStream_t st);
 
 // conv_pw.hip: ConvTranspose2d 2x2 / stride 2 forward (MODE_T2S2) and input gradient (MODE_G2S2), bf16, as one pointwise GEMM
 // per launch (512 threads per CU, LDS-DMA ring of three 64-wide K stages); false = shape outside its contract.
 bool conv_pw_eligible(int mode, int dtype, const ConvArgs& a);
-int conv_pw_launch(int mode, const ConvArgs& a, hipStream_t st);
+int conv_pw_launch(int mode, const ConvArgs& a, int reserve_cus, hipStream_t st);

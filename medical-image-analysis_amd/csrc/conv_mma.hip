@@ -306,9 +306,10 @@ extern "C" int mia_conv_mma_tiles(int mode, int hout, int wout, int* tiles_y, in
   return MIA_OK;
 }
 
-extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const void* in2, int c2, const void* wpack,
-                            int npad, int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2,
-                            int o2, float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream) {
+static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void* in2, int c2, const void* wpack,
+                        int npad, int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2,
+                        int o2, float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream,
+                        const float* nl_scale, const float* nl_shift, float nl_slope) {
   MIA_CHECK_ARG(mode >= 0 && mode <= MODE_G1, "mia_conv_mma: bad mode %d", mode);
   MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_conv_mma: bad dtype %d", dtype);
   MIA_CHECK_ARG(in1 && wpack && out1 && c1 > 0 && o1 > 0 && c2 >= 0 && o2 >= 0, "mia_conv_mma: null/empty operand");
@@ -333,6 +334,7 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
   a.out1 = out1; a.out2 = out2; a.o1 = o1; a.o2 = o2; a.stats = stat_partials;
   a.N = n; a.Hin = hin; a.Win = win; a.Hout = hout; a.Wout = wout;
   a.npad = npad; a.kpad = kpad; a.flip = flip_taps;
+  a.nl_scale = nl_scale; a.nl_shift = nl_shift; a.nl_slope = nl_slope;
   int th;
   conv_tiles(opt, mode, hout, wout, &a.tiles_y, &a.tiles_x, &th);  // same snapshot as the launch below
   int mt = th / 4;
@@ -363,17 +365,49 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
     return MIA_EUNSUPPORTED;
   }
   // conv64_dma: 1 = the one-pass two-destination input gradient only (measured faster there), 2 = every 64 -> 64 launch
-  if (opt.conv64 && opt.conv64_dma && (opt.conv64_dma >= 2 || a.o2 != 0) && mt == 4 && conv64_dma_eligible(mode, dtype, a)) rc = conv64_dma_launch(a, st);
-  else if (opt.conv64 && mt == 4 && conv64_eligible(mode, dtype, a)) rc = conv64_launch(a, opt.conv64_blocks, st);
-  else if (opt.conv_bt && mt == 4 && conv_bt_eligible(mode, dtype, a)) rc = conv_bt_launch(a, opt.conv_bt_order, st);
+  if (nl_scale != nullptr) {  // normalise-on-load: the register-staged 64-channel kernel is the one consumer that transforms
+    if (!(mt == 4 && conv64_eligible(mode, dtype, a))) {
+      mia_set_error("mia_conv_mma_nl: shape outside the normalise-on-load kernel's contract (ask mia_conv_nl_supported first)");
+      return MIA_EUNSUPPORTED;
+    }
+    rc = conv64_launch(a, opt.conv64_blocks, opt.reserve_cus, st);
+  }
+  else if (opt.conv64 && opt.conv64_dma && (opt.conv64_dma >= 2 || a.o2 != 0) && mt == 4 && conv64_dma_eligible(mode, dtype, a)) rc = conv64_dma_launch(a, opt.reserve_cus, st);
+  else if (opt.conv64 && mt == 4 && conv64_eligible(mode, dtype, a)) rc = conv64_launch(a, opt.conv64_blocks, opt.reserve_cus, st);
+  else if (opt.conv_bt && mt == 4 && conv_bt_eligible(mode, dtype, a)) rc = conv_bt_launch(a, opt.conv_bt_order, opt.reserve_cus, st);
   // (strided 3x3 forward as a tap-gathered GEMM: measured 0.62 -> 0.51, 0.44 -> 0.40, 0.37 -> 0.35 ms at 64 / 128 / 256 input channels,
   // 0.30 -> 0.30 at 512 in isolation (tools/s2_levels.py), but 43.99 vs 43.94 ms inside the cfg3 step on one box: default off;
   // conv_pw_s2 = 1 stops at 256 input channels, = 2 always)
   else if (opt.conv_pw && (mode != MODE_G3S2 || opt.conv_pw_s2 >= 2 || (opt.conv_pw_s2 == 1 && c1 <= 256)) && conv_pw_eligible(mode, dtype, a))
-    rc = conv_pw_launch(mode, a, st);
+    rc = conv_pw_launch(mode, a, opt.reserve_cus, st);
   else if (fast) rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
   else rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);
   if (rc != MIA_OK) return rc;
   MIA_LAUNCH_CHECK();
   return MIA_OK;
+}
+
+extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const void* in2, int c2, const void* wpack,
+                            int npad, int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2,
+                            int o2, float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream) {
+  return conv_mma_run(mode, dtype, in1, c1, in2, c2, wpack, npad, kpad, flip_taps, bias, out1, o1, out2, o2, stat_partials, n, hin,
+                      win, hout, wout, stream, nullptr, nullptr, 0.f);
+}
+
+// Normalise-on-load forward conv (the fused PlainBlock, SURVEY 8b export list "conv3x3_nhwc ... optional fused normalise +
+// LeakyReLU on load taking per-(n,c) scale / shift"): see include/mia_hip.h.
+extern "C" int mia_conv_nl_supported(int mode, int dtype, int c1, int nout, int hout, int wout) {
+  (void)wout;
+  return (mode == MODE_G3S1 && dtype == MIA_BF16 && c1 == 64 && nout == 64 && hout > 8) ? 1 : 0;
+}
+
+extern "C" int mia_conv_mma_nl(int mode, int dtype, const void* y_in, int c1, const float* in_scale, const float* in_shift,
+                               float slope, const void* wpack, int npad, int kpad, const float* bias, void* out, int nout,
+                               float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream) {
+  MIA_CHECK_ARG(in_scale != nullptr && in_shift != nullptr, "mia_conv_mma_nl: null coefficient arrays");
+  MIA_CHECK_ARG(slope >= 0.f && slope <= 1.f, "mia_conv_mma_nl: slope %g outside [0, 1]", (double)slope);
+  MIA_CHECK_ARG(mia_conv_nl_supported(mode, dtype, c1, nout, hout, wout), "mia_conv_mma_nl: unsupported shape (mode %d dtype %d %d -> %d)",
+                mode, dtype, c1, nout);
+  return conv_mma_run(mode, dtype, y_in, c1, nullptr, 0, wpack, npad, kpad, 0, bias, out, nout, nullptr, 0, stat_partials, n, hin, win,
+                      hout, wout, stream, in_scale, in_shift, slope);
 }

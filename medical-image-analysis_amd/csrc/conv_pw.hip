@@ -319,7 +319,7 @@ static int pw_num_cus() {
   return n;
 }
 
-int conv_pw_launch(int mode, const ConvArgs& a, hipStream_t st) {
+int conv_pw_launch(int mode, const ConvArgs& a, int reserve, hipStream_t st) {
   const bool tr = mode == MODE_T2S2;
   const int hco = tr ? a.Hin : a.Hout, wco = tr ? a.Win : a.Wout;  // the coarse grid
   const int mtot = a.N * hco * wco;
@@ -328,7 +328,7 @@ int conv_pw_launch(int mode, const ConvArgs& a, hipStream_t st) {
   const int mtiles = ceil_div(mtot, PW_TM);
   const int nwork = mtiles * nblocks;
   const int tile_major = (nblocks > 1 && mtiles % 8 == 0) ? nblocks : 0;
-  const int ncu = pw_num_cus();
+  const int ncu = reserve > 0 ? persistent_cus(pw_num_cus(), reserve) : pw_num_cus();
   const dim3 grid(nwork < ncu ? nwork : ncu);
   if (mode == MODE_G3S2) hipLaunchKernelGGL(conv_pw_kernel<MODE_G3S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
   else if (tr) hipLaunchKernelGGL(conv_pw_kernel<MODE_T2S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);

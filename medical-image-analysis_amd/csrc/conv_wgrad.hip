@@ -32,6 +32,9 @@ struct WgArgs {
   int tiles_x, tiles_y;
   int vec_x, vec_dy;
   int opt;  // bit 0: table-driven staging of interior tiles (wgrad_bf16_2wg_kernel)
+  // normalise-on-load (mia_conv_wgrad_nl): x1 is the RAW conv output y of the producing PlainBlock; the kernel stages
+  // lrelu(nl_scale[n][k] * y + nl_shift[n][k]) (zero outside the image); nullptr = x1 is an ordinary activation
+  const float* nl_scale = nullptr; const float* nl_shift = nullptr; float nl_slope = 0.f;
 };
 
 template <int MODE> struct WGeo {
@@ -356,15 +359,20 @@ extern "C" int mia_wgrad_debug_read(unsigned long long* host_out) {
 #define WSTAMP(var) do { } while (0)
 #endif
 
-template <int TH>
+// NL = normalise-on-load of the x operand (see conv64.hip: the consumer-side half of the fused PlainBlock): x1 holds the
+// producer's raw conv output and commit() turns each staged 16-byte unit into bf16(lrelu(scale * y + shift)) -- bit for bit the
+// activation mia_norm_act_fwd would have written -- with the coefficients of the tile's image in a 512-byte LDS table
+// (threads 0..127 fetch one entry each with the tile), and halo units outside the image forced back to zero.
+template <int TH, bool NL = false>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) {
   constexpr int KS = 3, PAD = 1, TAPS = 9;
   constexpr int XH = TH - 1 + KS, XW = 15 + KS, XP = 32;
   constexpr int X_IT = (XH * XW + 31) / 32, D_IT = TH * 16 / 32;  // 32 pixels x 8 chunks per staging iteration
   constexpr int X_BYTES = XH * XP * 128, D_BYTES = TH * 16 * 128;
   static_assert(X_IT == 6 && D_IT == 4, "the staging table below is laid out for TH = 8");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[X_BYTES + D_BYTES + 4 * 256 * 16];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[X_BYTES + D_BYTES + 4 * 256 * 16 + (NL ? 512 : 0)];
   u32x4* tab = reinterpret_cast<u32x4*>(smem + X_BYTES + D_BYTES);  // [4][256]: per-thread staging constants, see below
+  float* cft = reinterpret_cast<float*>(smem + X_BYTES + D_BYTES + 4 * 256 * 16);  // NL: [0, 64) scale, [64, 128) shift (this k block, committed tile's image)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -420,9 +428,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) 
   }
 
   u32x4 px[X_IT], pd[D_IT];
+  float cpf = 0.f;  // NL: this thread's entry of the fetched tile's coefficient table
   auto fetch = [&](int img, int ty, int tx) {
     const int oy0 = ty * TH, ox0 = tx * 16;
     const int iy0 = oy0 - PAD, ix0 = ox0 - PAD;
+    if constexpr (NL) {
+      if (wave < 2) {  // wave 0 fetches the 64 scales, wave 1 the 64 shifts: the array pointer stays scalar
+        const float* cp = wave == 0 ? a.nl_scale : a.nl_shift;
+        int lv = lane;
+        asm volatile("" : "+v"(lv));  // recomputed per tile: a hoisted 64-bit lane address would be spilled around the tile loop
+        const int ch = kloc + lv;
+        cpf = ch < cs ? cp[(unsigned)(img * cs + ch)] : 0.f;  // scalar base + 32-bit lane offset
+      }
+    }
     if ((a.opt & 1) && iy0 >= 0 && ix0 >= 0 && iy0 + XH <= a.Hx && ix0 + XW <= a.Wx && oy0 + TH <= a.Hy && ox0 + 16 <= a.Wy) {
       const size_t xorg = (size_t)iy0 * a.Wx + ix0, dorg = (size_t)oy0 * a.Wy + ox0;
       const wrsrc_t rx = wmake_rsrc(xsrc + ((size_t)img * xpix + xorg) * cs, (unsigned)((xpix - xorg) * cs * 2));
@@ -461,9 +479,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) 
       pd[i] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)((off & (unsigned)okm) | (WSENT & ~(unsigned)okm)), 0, 0);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int ty, int tx) {
     int p8v = p8;
     asm volatile("" : "+v"(p8v));
+    if constexpr (NL) {
+      const f32x4* cf4 = reinterpret_cast<const f32x4*>(cft);
+      const int iy0 = ty * TH - PAD, ix0 = tx * 16 - PAD;
+      const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + XH <= a.Hx && ix0 + XW <= a.Wx;  // uniform
+      typedef float nl_f32x2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 nl_bf16x2 __attribute__((ext_vector_type(2)));
+      const nl_f32x2 sl2 = {a.nl_slope, a.nl_slope};
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {  // dwords 0,1 then 2,3 of every unit: 8 coefficient registers live at a time
+        const f32x4 sc = cf4[2 * ch8 + hf], sh = cf4[16 + 2 * ch8 + hf];
+#pragma unroll
+        for (int i = 0; i < X_IT; ++i) {
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {  // packed fp32 math: one issue slot per channel pair (v_pk_fma_f32, v_pk_mul_f32)
+            const unsigned w = px[i][2 * hf + d];
+            const nl_f32x2 x = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
+            const nl_f32x2 v = __builtin_elementwise_fma(nl_f32x2{sc[2 * d], sc[2 * d + 1]}, x, nl_f32x2{sh[2 * d], sh[2 * d + 1]});
+            const nl_f32x2 m = v * sl2;
+            // (channels past `cs` carry scale = shift = 0 in the table: lrelu(0) = 0)
+            px[i][2 * hf + d] = __builtin_bit_cast(unsigned, __builtin_convertvector(nl_f32x2{__builtin_fmaxf(v[0], m[0]), __builtin_fmaxf(v[1], m[1])}, nl_bf16x2));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!interior) {  // border tile: halo units outside the image go back to zero
+#pragma unroll
+        for (int i = 0; i < X_IT; ++i) {
+          const int pix = p8v + 32 * i, iy = pix / XW, ix = pix - iy * XW;
+          const unsigned keep = 0u - (unsigned)(((unsigned)(iy0 + iy) < (unsigned)a.Hx) & ((unsigned)(ix0 + ix) < (unsigned)a.Wx));
+#pragma unroll
+          for (int d = 0; d < 4; ++d) px[i][d] &= keep;
+        }
+      }
+    }
     const u32x4 t2 = tab[512 + tid], t3 = tab[768 + tid];
     *reinterpret_cast<u32x4*>(smem + t2.z) = px[0];
     *reinterpret_cast<u32x4*>(smem + t2.w) = px[1];
@@ -504,9 +556,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_2wg_kernel(const WgArgs a) 
 #endif
   for (; tile < ntiles; tile += a.ksplit) {
     WSTAMP(w0);
+    if constexpr (NL) {  // the table is read in commit() only, i.e. between the two barriers below
+      if (tid < 128) cft[tid] = cpf;
+    }
     __syncthreads();  // previous tile's fragment reads are done
     WSTAMP(w1);
-    commit();
+    commit(t_ty, t_tx);
     WSTAMP(w2);
     __syncthreads();
     WSTAMP(w3);
@@ -1795,10 +1850,14 @@ static bool wgrad_two_wg(const MiaOptions& o, int mode, int dtype) {  // option 
 /* split-K workgroups to aim for: one per CU, or two where the kernel is built for two workgroups per CU */
 extern "C" int mia_wgrad_target_blocks(int mode, int dtype) {
   const MiaOptions o = mia_options();
-  if (wgrad_two_wg(o, mode, dtype)) return 512;
-  if (mode == MODE_W3S2 && dtype == MIA_BF16 && o.wgrad_bt && o.wgrad_dma) return 512;  // 128 n x 64 k blocks: half as many column blocks
-  if (mode == MODE_W2S2 && dtype == MIA_BF16 && o.wgrad_w8 != 0) return 512;  // 4 taps: 172 registers, 40 KB LDS -> two workgroups fit a CU
-  return 256;
+  int per_cu = 1;
+  if (wgrad_two_wg(o, mode, dtype)) per_cu = 2;
+  else if (mode == MODE_W3S2 && dtype == MIA_BF16 && o.wgrad_bt && o.wgrad_dma) per_cu = 2;  // 128 n x 64 k blocks: half as many column blocks
+  else if (mode == MODE_W2S2 && dtype == MIA_BF16 && o.wgrad_w8 != 0) per_cu = 2;  // 4 taps: 172 registers, 40 KB LDS -> two workgroups fit a CU
+  // option reserve_cus: the split count follows the CUs left to the persistent kernels (a different split count is a
+  // different -- still fixed -- fp32 summation order of the slabs: deterministic per setting, not bit-identical across settings)
+  const int cus = o.reserve_cus > 0 ? ((256 - o.reserve_cus) & ~7) : 256;
+  return per_cu * (cus < 8 ? 8 : cus);
 }
 
 #ifdef CONV64_STAMPS
@@ -1821,9 +1880,9 @@ extern "C" int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tile
   return MIA_OK;
 }
 
-extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const void* x2, int c2, const void* dy,
-                              int cdy, float* slabs, int ksplit, int npad, int kpad, int n, int hx, int wx, int hy,
-                              int wy, void* stream) {
+static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const void* x2, int c2, const void* dy,
+                          int cdy, float* slabs, int ksplit, int npad, int kpad, int n, int hx, int wx, int hy,
+                          int wy, void* stream, const float* nl_scale, const float* nl_shift, float nl_slope) {
   MIA_CHECK_ARG(mode >= 0 && mode <= MODE_W2S2, "mia_conv_wgrad: bad mode %d", mode);
   MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_conv_wgrad: bad dtype");
   MIA_CHECK_ARG(x1 && dy && slabs && c1 > 0 && c2 >= 0 && cdy > 0, "mia_conv_wgrad: null/empty operand");
@@ -1837,6 +1896,7 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   WgArgs a;
   a.x1 = x1; a.x2 = x2; a.c1 = c1; a.c2 = c2; a.dy = dy; a.cdy = cdy; a.slabs = slabs;
   a.N = n; a.Hx = hx; a.Wx = wx; a.Hy = hy; a.Wy = wy; a.npad = npad; a.kpad = kpad; a.ksplit = ksplit;
+  a.nl_scale = nl_scale; a.nl_shift = nl_shift; a.nl_slope = nl_slope;
   const int epu = dtype == MIA_BF16 ? 8 : 4;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vec_x = (c1 % epu == 0) && (c2 % epu == 0) && al16(x1) && (x2 == nullptr || al16(x2));
@@ -1853,6 +1913,17 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   if (fast && o.wgrad_xcd && ksplit % 8 == 0) {  // bf16 fast kernels: 1-D grid in XCD-aware order (a split count below 8 would leave XCDs idle)
     a.opt |= 16;
     fgrid = dim3(fgrid.x * (unsigned)(ceil_div(ksplit, 8) * 8), 1);
+  }
+  if (nl_scale != nullptr) {  // normalise-on-load: the register-staged two-workgroup kernel is the one that transforms
+    if (!(fast && mode == MODE_W3S1 && c2 == 0)) {
+      mia_set_error("mia_conv_wgrad_nl: shape outside the normalise-on-load kernel's contract (ask mia_wgrad_nl_supported first)");
+      return MIA_EUNSUPPORTED;
+    }
+    a.tiles_y = ceil_div(hy, 8);
+    a.tiles_x = ceil_div(wy, 16);
+    hipLaunchKernelGGL((wgrad_bf16_2wg_kernel<8, true>), fgrid, dim3(256), 0, st, a);
+    MIA_LAUNCH_CHECK();
+    return MIA_OK;
   }
   const int th = wgrad_tile_h(o, mode, dtype, hy, fast);
   a.tiles_y = ceil_div(hy, th);
@@ -1897,6 +1968,28 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
   }
   MIA_LAUNCH_CHECK();
   return MIA_OK;
+}
+
+extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const void* x2, int c2, const void* dy,
+                              int cdy, float* slabs, int ksplit, int npad, int kpad, int n, int hx, int wx, int hy,
+                              int wy, void* stream) {
+  return conv_wgrad_run(mode, dtype, x1, c1, x2, c2, dy, cdy, slabs, ksplit, npad, kpad, n, hx, wx, hy, wy, stream, nullptr, nullptr, 0.f);
+}
+
+// Weight gradient with normalise-on-load of x (the backward half of the fused PlainBlock): see include/mia_hip.h.
+extern "C" int mia_wgrad_nl_supported(int mode, int dtype, int c1, int cdy) {
+  return (mode == MODE_W3S1 && dtype == MIA_BF16 && c1 % 8 == 0 && cdy % 8 == 0) ? 1 : 0;
+}
+
+extern "C" int mia_conv_wgrad_nl(int mode, int dtype, const void* y_in, int c1, const float* in_scale, const float* in_shift,
+                                 float slope, const void* dy, int cdy, float* slabs, int ksplit, int npad, int kpad, int n,
+                                 int hx, int wx, int hy, int wy, void* stream) {
+  MIA_CHECK_ARG(in_scale != nullptr && in_shift != nullptr, "mia_conv_wgrad_nl: null coefficient arrays");
+  MIA_CHECK_ARG(slope >= 0.f && slope <= 1.f, "mia_conv_wgrad_nl: slope %g outside [0, 1]", (double)slope);
+  MIA_CHECK_ARG(mia_wgrad_nl_supported(mode, dtype, c1, cdy), "mia_conv_wgrad_nl: unsupported shape (mode %d dtype %d %d x %d)", mode,
+                dtype, c1, cdy);
+  return conv_wgrad_run(mode, dtype, y_in, c1, nullptr, 0, dy, cdy, slabs, ksplit, npad, kpad, n, hx, wx, hy, wy, stream, in_scale,
+                        in_shift, slope);
 }
 
 extern "C" int mia_wgrad_reduce(const float* slabs, int ksplit, int taps, int npad, int kpad, float* grad, int nn,

@@ -30,6 +30,7 @@ struct MiaOptions {
   int wgrad_w8;       // two-workgroups-per-CU weight-gradient kernels                         env MIA_WGRAD_W8      default 1
   int stream_blocks;  // target block count of the norm / activation streaming passes          env MIA_STREAM_BLOCKS default 32768
   int stem_mfma;      // matrix-core stem kernel for fp32 images                               env MIA_STEM_MFMA     default 1
+  int reserve_cus;    // CUs the persistent kernels leave free (grids of conv_bt / conv_pw / conv64 / conv64_dma, split-K target of the weight gradients): room for RCCL's ring kernels under data parallelism   env MIA_RESERVE_CUS   default 0
 };
 
 MiaOptions mia_options();  // consistent snapshot, by value

@@ -217,7 +217,9 @@ def conv_tiles(mode: int, hout: int, wout: int) -> int:
 
 def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: torch.Tensor, npad: int, kpad: int,
              flip: bool, bias: Optional[torch.Tensor], nout: int, out_hw: Tuple[int, int], want_stats: bool = False,
-             out_split: Optional[int] = None):
+             out_split: Optional[int] = None, nl=None):
+    """nl = (coefs [5, N, C] of the producing block, slope): x1 is that block's RAW conv output and the kernel normalises on
+    load (`mia_conv_mma_nl`; the fused PlainBlock)."""
     n, hin, win, c1 = x1.shape
     c2 = 0 if x2 is None else x2.shape[3]
     hout, wout = out_hw
@@ -236,8 +238,13 @@ def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: tor
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("mia_conv_mma", mode, _dt(x1), _p(x1), c1, _p(x2), c2, _p(wpack), npad, kpad, int(flip), _p(bias), _p(out1), o1,
-         _p(out2), o2, _p(stats), n, hin, win, hout, wout, _stream())
+    if nl is not None:
+        assert x2 is None and out_split is None and not flip
+        call("mia_conv_mma_nl", mode, _dt(x1), _p(x1), c1, _p(nl[0][2]), _p(nl[0][3]), _c_float(nl[1]), _p(wpack), npad, kpad,
+             _p(bias), _p(out1), o1, _p(stats), n, hin, win, hout, wout, _stream())
+    else:
+        call("mia_conv_mma", mode, _dt(x1), _p(x1), c1, _p(x2), c2, _p(wpack), npad, kpad, int(flip), _p(bias), _p(out1), o1,
+             _p(out2), o2, _p(stats), n, hin, win, hout, wout, _stream())
     if probe is not None:
         e1.record()
         probe.pairs.append((e0, e1, tag, (mode, c1 + c2, nout, n, hout, wout)))
@@ -248,8 +255,9 @@ WGRAD_TARGET_BLOCKS = int(__import__('os').environ.get('MIA_WGRAD_BLOCKS', '0'))
 
 
 def conv_wgrad(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], dy: torch.Tensor, grad_shape, nn: int, kk: int,
-               out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Weight gradient in the parameter's native layout (fp32), written into `out` when given."""
+               out: Optional[torch.Tensor] = None, nl=None) -> torch.Tensor:
+    """Weight gradient in the parameter's native layout (fp32), written into `out` when given.  nl = (coefs, slope): x1 is the
+    producing block's raw conv output, normalised on load (`mia_conv_wgrad_nl`)."""
     n, hx, wx, c1 = x1.shape
     c2 = 0 if x2 is None else x2.shape[3]
     _, hy, wy, cdy = dy.shape
@@ -263,8 +271,13 @@ def conv_wgrad(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], dy: torc
     target = WGRAD_TARGET_BLOCKS or lib().mia_wgrad_target_blocks(mode, dtype)
     ksplit = max(1, min(ntiles, -(-target // base), 1024))
     slabs = torch.empty((ksplit, taps, npad, kpad), device=x1.device, dtype=torch.float32)
-    call("mia_conv_wgrad", mode, dtype, _p(x1), c1, _p(x2), c2, _p(dy), cdy, _p(slabs), ksplit, npad, kpad, n, hx, wx, hy,
-         wy, _stream())
+    if nl is not None:
+        assert x2 is None
+        call("mia_conv_wgrad_nl", mode, dtype, _p(x1), c1, _p(nl[0][2]), _p(nl[0][3]), _c_float(nl[1]), _p(dy), cdy, _p(slabs),
+             ksplit, npad, kpad, n, hx, wx, hy, wy, _stream())
+    else:
+        call("mia_conv_wgrad", mode, dtype, _p(x1), c1, _p(x2), c2, _p(dy), cdy, _p(slabs), ksplit, npad, kpad, n, hx, wx, hy,
+             wy, _stream())
     grad = out if out is not None else torch.empty(grad_shape, device=x1.device, dtype=torch.float32)
     call("mia_wgrad_reduce", _p(slabs), ksplit, taps, npad, kpad, _p(grad), nn, kk, 0, _stream())
     return grad
@@ -414,6 +427,60 @@ def _norm_finalize(cfg: NormCfg, stats, gamma, beta, n, cout, hw, coefs):
     return sync
 
 
+class LazyAct:
+    """Output of a PlainBlock whose normalisation + LeakyReLU (blocks.py:98-102) is NOT materialised: `y` is the raw conv
+    output (it carries the autograd history and, by convention, the gradient delivered to it is d loss / d z), `coefs`
+    the block's [5, N, C] coefficient table (rows 2 / 3 = scale / shift with Dropout2d folded in).  The next block's conv
+    and weight gradient form z = lrelu(scale * y + shift) on load (`mia_conv_mma_nl`, `mia_conv_wgrad_nl`)."""
+    __slots__ = ("y", "coefs", "slope")
+
+    def __init__(self, y, coefs, slope):
+        self.y, self.coefs, self.slope = y, coefs, slope
+
+    @property
+    def shape(self):
+        return self.y.shape
+
+    @property
+    def dtype(self):
+        return self.y.dtype
+
+    @property
+    def device(self):
+        return self.y.device
+
+    def materialize(self) -> torch.Tensor:
+        return LazyMaterializeFn.apply(self.y, self.coefs, self.slope)
+
+
+class LazyMaterializeFn(torch.autograd.Function):
+    """z = lrelu(scale * y + shift) as a tensor (a consumer outside the fused kernels' contract).  The gradient passes
+    through unchanged: the producer expects d loss / d z on its raw-output handle (see LazyAct)."""
+
+    @staticmethod
+    def forward(ctx, y, coefs, slope):
+        n, h, w, c = y.shape
+        z = torch.empty_like(y)
+        call("mia_norm_act_fwd", _p(y), _p(z), _dt(y), _p(coefs[2]), _p(coefs[3]), n, _c_i64(h * w), c, _c_float(slope), _stream())
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        return dz, None, None
+
+
+FUSE_NL = __import__('os').environ.get('MIA_FUSE_NL', '1') != '0'  # A/B knob: 0 = every block materialises its activation
+
+
+def nl_supported(dtype, cin: int, cout: int, h: int, w: int, train: bool) -> bool:
+    """Can a stride-1 3x3 block with these shapes consume its predecessor's raw output (normalise-on-load)?"""
+    if not FUSE_NL or dtype != torch.bfloat16:
+        return False
+    if not lib().mia_conv_nl_supported(CONV_G3S1, BF16, cin, cout, h, w):
+        return False
+    return (not train) or bool(lib().mia_wgrad_nl_supported(WGRAD_3S1, BF16, cin, cout))
+
+
 class PlainBlockFn(torch.autograd.Function):
     """Fused reference PlainBlock (src/models/unet/blocks.py:66-105) on NHWC tensors.
 
@@ -421,8 +488,10 @@ class PlainBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, weight, bias, gamma, beta, stride: int, cfg: NormCfg, out_dtype=None, slope: float = LRELU_SLOPE,
-                dup: bool = False):
-        """dup=True returns the output TWICE (two tensors on one storage): a skip tensor has two consumers, and handing
+                dup: bool = False, lazy: bool = False, nl_coefs=None, nl_slope: float = LRELU_SLOPE):
+        """lazy=True: the norm + LeakyReLU pass is skipped and (y, coefs) is returned for a `LazyAct` (the next block
+        normalises on load).  nl_coefs: x1 is such a raw output of the previous block (its coefficient table).
+        dup=True returns the output TWICE (two tensors on one storage): a skip tensor has two consumers, and handing
         each its own output makes autograd deliver their gradients separately to backward, which sums them on load inside
         the norm kernels instead of autograd launching an `add` over the full activation."""
         ctx.dup = dup
@@ -432,10 +501,14 @@ class PlainBlockFn(torch.autograd.Function):
         x2 = None if x2 is None else x2.contiguous()
         out_dtype = out_dtype or x1.dtype
         cout_ = weight.shape[0]
+        assert not (lazy and dup)
+        ctx.nl = None
         stem = (weight.shape[1] == 1 and x2 is None and stride == 1 and x1.shape[3] == 1 and not x1.requires_grad
-                and cout_ % (8 if out_dtype == torch.bfloat16 else 4) == 0 and cout_ <= 256)
+                and cout_ % (8 if out_dtype == torch.bfloat16 else 4) == 0 and cout_ <= 256 and nl_coefs is None)
         if stem:
-            z = PlainBlockFn._stem_forward(ctx, x1, weight, bias, gamma, beta, cfg, out_dtype, slope)
+            z = PlainBlockFn._stem_forward(ctx, x1, weight, bias, gamma, beta, cfg, out_dtype, slope, lazy)
+            if lazy:
+                return z
             return (z, z.view(z.shape)) if dup else z
         if x1.dtype != out_dtype:
             x1 = cast_nhwc(x1, out_dtype)
@@ -451,16 +524,25 @@ class PlainBlockFn(torch.autograd.Function):
         wp, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=True)
         mode = CONV_G3S2 if stride == 2 else CONV_G3S1
         fixed = cfg.mode == NORM_BATCH and not cfg.training  # eval batch norm: running statistics, no batch sums needed
-        y, _, stats = conv_mma(mode, x1, x2, wp, npad, kpad, False, bias.detach().float(), cout, (ho, wo), want_stats=not fixed)
+        nl = None if nl_coefs is None else (nl_coefs, float(nl_slope))
+        if nl is not None and (x2 is not None or stride != 1):
+            raise MiaError("normalise-on-load serves one-source stride-1 blocks only")
+        y, _, stats = conv_mma(mode, x1, x2, wp, npad, kpad, False, bias.detach().float(), cout, (ho, wo), want_stats=not fixed,
+                               nl=nl)
         dev = x1.device
         coefs = torch.empty((5, n, cout), device=dev, dtype=torch.float32)  # xa, xb, scale, shift, sum_y
         ctx.sync = _norm_finalize(cfg, stats, gamma, beta, n, cout, ho * wo, coefs)
+        ctx.stride, ctx.mode, ctx.fixed, ctx.stem, ctx.slope = stride, cfg.mode, fixed, False, slope
+        ctx.small = (bias, beta)  # identities only (gradient destinations); values are not needed in backward
+        ctx.nl_slope = float(nl_slope)
+        if lazy:  # the consumer normalises on load: no apply pass, no activation tensor
+            ctx.save_for_backward(x1, x2, y, coefs, weight, gamma, nl_coefs)
+            ctx.mark_non_differentiable(coefs)
+            return y, coefs
         z = torch.empty_like(y)
         call("mia_norm_act_fwd", _p(y), _p(z), dtype, _p(coefs[2]), _p(coefs[3]), n, _c_i64(ho * wo), cout,
              _c_float(slope), _stream())
-        ctx.save_for_backward(x1, x2, y, coefs, weight, gamma)
-        ctx.stride, ctx.mode, ctx.fixed, ctx.stem, ctx.slope = stride, cfg.mode, fixed, False, slope
-        ctx.small = (bias, beta)  # identities only (gradient destinations); values are not needed in backward
+        ctx.save_for_backward(x1, x2, y, coefs, weight, gamma, nl_coefs)
         return (z, z.view(z.shape)) if dup else z
 
     @staticmethod
@@ -474,7 +556,7 @@ class PlainBlockFn(torch.autograd.Function):
         return z, coefs
 
     @staticmethod
-    def _stem_forward(ctx, x1, weight, bias, gamma, beta, cfg, out_dtype, slope):
+    def _stem_forward(ctx, x1, weight, bias, gamma, beta, cfg, out_dtype, slope, lazy=False):
         n, h, w, _ = x1.shape
         cout = weight.shape[0]
         dev = x1.device
@@ -484,20 +566,27 @@ class PlainBlockFn(torch.autograd.Function):
         if not w2.is_contiguous():
             w2 = w2.contiguous()
         call("mia_stem_fwd", _p(x1), _dt(x1), _p(w2), _p(bias.detach()), _p(y), _dt(y), _p(stats), n, h, w, cout, _stream())
-        z, coefs = PlainBlockFn._norm_act(ctx, y, stats, gamma, beta, cfg, n, cout, h * w, slope)
-        ctx.save_for_backward(x1, None, y, coefs, weight, gamma)
         ctx.stride, ctx.mode, ctx.fixed, ctx.stem, ctx.slope = 1, cfg.mode, cfg.mode == NORM_BATCH and not cfg.training, True, slope
         ctx.small = (bias, beta)
+        ctx.nl_slope = LRELU_SLOPE
+        if lazy:
+            coefs = torch.empty((5, n, cout), device=dev, dtype=torch.float32)
+            ctx.sync = _norm_finalize(cfg, stats, gamma, beta, n, cout, h * w, coefs)
+            ctx.save_for_backward(x1, None, y, coefs, weight, gamma, None)
+            ctx.mark_non_differentiable(coefs)
+            return y, coefs
+        z, coefs = PlainBlockFn._norm_act(ctx, y, stats, gamma, beta, cfg, n, cout, h * w, slope)
+        ctx.save_for_backward(x1, None, y, coefs, weight, gamma, None)
         return z
 
     @staticmethod
     def backward(ctx, *grads):
-        x1, x2, y, coefs, weight, gamma = ctx.saved_tensors
+        x1, x2, y, coefs, weight, gamma, nl_coefs = ctx.saved_tensors
         dtype = _dt(y)
         n, ho, wo, cout = y.shape
         pieces = [g_.contiguous() for g_ in grads if g_ is not None]
         if not pieces:
-            return (None,) * 11
+            return (None,) * 14
         dz, dz2 = pieces[0], (pieces[1] if len(pieces) > 1 else None)
         if dz2 is not None and not (lib().mia_norm_two_piece_ok(dtype, cout) and dz.data_ptr() % 16 == 0 and dz2.data_ptr() % 16 == 0):
             dz, dz2 = dz + dz2, None  # shapes outside the vectorised kernels: one explicit sum
@@ -532,9 +621,10 @@ class PlainBlockFn(torch.autograd.Function):
             if dw is None:
                 dw = torch.empty(weight.shape, device=dev, dtype=torch.float32)
             call("mia_stem_wgrad", _p(x1), _dt(x1), _p(dy), dtype, _p(ws), _p(dw), n, ho, wo, cout, 0, _stream())
-            return None, None, dw, dbias, dgamma, dbeta, None, None, None, None, None
+            return (None, None, dw, dbias, dgamma, dbeta) + (None,) * 8
         wmode = WGRAD_3S2 if ctx.stride == 2 else WGRAD_3S1
-        dw = conv_wgrad(wmode, x1, x2, dy, weight.shape, cout, cin, out=grad_dest(weight))
+        dw = conv_wgrad(wmode, x1, x2, dy, weight.shape, cout, cin, out=grad_dest(weight),
+                        nl=None if nl_coefs is None else (nl_coefs, ctx.nl_slope))
         dx1 = dx2 = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             wb, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=False)
@@ -552,7 +642,7 @@ class PlainBlockFn(torch.autograd.Function):
                 if want:
                     sums = colsum(st.view(-1, 2 * cin)).view(cin, 2)[c1:, 0]
                     _hint_colsum(dx2, sums)
-        return dx1, dx2, dw, dbias, dgamma, dbeta, None, None, None, None, None
+        return (dx1, dx2, dw, dbias, dgamma, dbeta) + (None,) * 8
 
 
 class PlainBlockHeadFn(torch.autograd.Function):
@@ -573,7 +663,9 @@ class PlainBlockHeadFn(torch.autograd.Function):
         return cout % 32 == 0 and lib().mia_head_norm_eligible(_dt(dtype), n, _c_i64(h * w), cout, k1) > 0
 
     @staticmethod
-    def forward(ctx, x1, weight, bias, gamma, beta, cfg: NormCfg, head_w, head_b, slope: float = LRELU_SLOPE):
+    def forward(ctx, x1, weight, bias, gamma, beta, cfg: NormCfg, head_w, head_b, slope: float = LRELU_SLOPE, nl_coefs=None,
+                nl_slope: float = LRELU_SLOPE):
+        """nl_coefs: x1 is the previous block's RAW conv output with that coefficient table (normalise-on-load)."""
         _need_dev(x1, weight, head_w)
         x1 = x1.contiguous()
         dtype = _dt(x1)
@@ -583,21 +675,23 @@ class PlainBlockHeadFn(torch.autograd.Function):
             raise RuntimeError(f"conv weight expects {weight.shape[1]} input channels, got {c1}")
         wp, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=True)
         fixed = cfg.mode == NORM_BATCH and not cfg.training
-        y, _, stats = conv_mma(CONV_G3S1, x1, None, wp, npad, kpad, False, bias.detach().float(), cout, (h, w), want_stats=not fixed)
+        y, _, stats = conv_mma(CONV_G3S1, x1, None, wp, npad, kpad, False, bias.detach().float(), cout, (h, w), want_stats=not fixed,
+                               nl=None if nl_coefs is None else (nl_coefs, float(nl_slope)))
         coefs = torch.empty((5, n, cout), device=x1.device, dtype=torch.float32)  # xa, xb, scale, shift, sum_y
         ctx.sync = _norm_finalize(cfg, stats, gamma, beta, n, cout, h * w, coefs)
+        ctx.nl_slope = float(nl_slope)
         w2 = head_w.detach().reshape(k1, cout).contiguous()
         logits = torch.empty((n, h, w, k1), device=x1.device, dtype=torch.float32)
         call("mia_head_norm_fwd", _p(y), dtype, _p(coefs[2]), _p(coefs[3]), _c_float(slope), _p(w2), _p(head_b.detach()),
              _p(logits), n, _c_i64(h * w), cout, k1, _c_i64(h * w * k1), _c_i64(1), _c_i64(k1), _stream())
-        ctx.save_for_backward(x1, y, coefs, weight, gamma, head_w)
+        ctx.save_for_backward(x1, y, coefs, weight, gamma, head_w, nl_coefs)
         ctx.mode, ctx.fixed, ctx.slope = cfg.mode, cfg.mode == NORM_BATCH and not cfg.training, slope
         ctx.small = (bias, beta, head_b)
         return logits.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dl):
-        x1, y, coefs, weight, gamma, head_w = ctx.saved_tensors
+        x1, y, coefs, weight, gamma, head_w, nl_coefs = ctx.saved_tensors
         bias_p, beta_p, head_b = ctx.small
         dtype = _dt(y)
         n, h, w, cout = y.shape
@@ -631,12 +725,13 @@ class PlainBlockHeadFn(torch.autograd.Function):
              _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]), _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout,
              ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs, _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta),
              _p(dbias), 0, _stream())
-        dw = conv_wgrad(WGRAD_3S1, x1, None, dy, weight.shape, cout, cin, out=grad_dest(weight))
+        dw = conv_wgrad(WGRAD_3S1, x1, None, dy, weight.shape, cout, cin, out=grad_dest(weight),
+                        nl=None if nl_coefs is None else (nl_coefs, ctx.nl_slope))
         dx1 = None
         if ctx.needs_input_grad[0]:
             wb, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=False)
             dx1, _, _ = conv_mma(CONV_G3S1, dy, None, wb, npad, kpad, True, None, cin, (h, w))
-        return dx1, dw, dbias, dgamma, dbeta, None, dwh.reshape(head_w.shape), dbh, None
+        return dx1, dw, dbias, dgamma, dbeta, None, dwh.reshape(head_w.shape), dbh, None, None, None
 
 
 # ------------------------------------------------------------------ ConvTranspose2d(k=2, s=2)

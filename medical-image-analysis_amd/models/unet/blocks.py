@@ -101,11 +101,27 @@ class PlainBlock(nn.Module):
                                norm.num_batches_tracked, drop, sync=self.batch_sync)
         return ops.NormCfg(NORM_INSTANCE, self.training, norm.eps, 0.1, None, None, None, drop)
 
-    def forward_nhwc(self, x1, x2=None, out_dtype=None, dup=False):
-        """dup=True: the output twice (one storage), for a tensor with two consumers -- see ops.PlainBlockFn.forward."""
+    def consumes_lazy(self, producer: "PlainBlock", h: int, w: int, dtype) -> bool:
+        """True when this block can take `producer`'s output as an `ops.LazyAct` (raw conv output + coefficient table): the
+        fused PlainBlock -- the producer's norm + LeakyReLU pass (blocks.py:98-102) is folded into this block's conv and
+        weight gradient, and its activation tensor is never written.  `h, w` = this block's input size."""
+        conv = self.all[0]
+        return (self.stride == 1 and producer.all[0].out_channels == conv.in_channels and producer.batch_sync is None
+                and ops.nl_supported(dtype, conv.in_channels, conv.out_channels, h, w, torch.is_grad_enabled()))
+
+    def forward_nhwc(self, x1, x2=None, out_dtype=None, dup=False, lazy=False):
+        """dup=True: the output twice (one storage), for a tensor with two consumers -- see ops.PlainBlockFn.forward.
+        lazy=True: returns an `ops.LazyAct` (the caller checked `next_block.consumes_lazy`); x1 may itself be one."""
         conv, norm = self.all[0], self.all[2]
-        return ops.PlainBlockFn.apply(x1, x2, conv.weight, conv.bias, norm.weight, norm.bias, self.stride,
-                                      self._cfg(x1.shape[0], x1.device), out_dtype, ops.LRELU_SLOPE, dup)
+        nl_coefs, nl_slope = None, ops.LRELU_SLOPE
+        if isinstance(x1, ops.LazyAct):
+            if x2 is None and self.stride == 1:
+                nl_coefs, nl_slope, x1 = x1.coefs, x1.slope, x1.y
+            else:
+                x1 = x1.materialize()
+        out = ops.PlainBlockFn.apply(x1, x2, conv.weight, conv.bias, norm.weight, norm.bias, self.stride,
+                                     self._cfg(x1.shape[0], x1.device), out_dtype, ops.LRELU_SLOPE, dup, lazy, nl_coefs, nl_slope)
+        return ops.LazyAct(out[0], out[1], ops.LRELU_SLOPE) if lazy else out
 
     def forward_head_nhwc(self, x1, head):
         """This block followed by the 1x1 head `head` (nn.Conv2d) in one fused node, or None when the fused kernels do
@@ -113,10 +129,20 @@ class PlainBlock(nn.Module):
         conv, norm = self.all[0], self.all[2]
         if self.stride != 1 or x1.dtype not in (torch.float32, torch.bfloat16):
             return None
-        cfg = self._cfg(x1.shape[0], x1.device)
-        if not ops.PlainBlockHeadFn.eligible(x1, conv.weight, head.weight, cfg, x1.dtype):
+        lazy_in = x1 if isinstance(x1, ops.LazyAct) else None
+        if lazy_in is not None:
+            x1 = lazy_in.y
+        if not ops.PlainBlockHeadFn.eligible(x1, conv.weight, head.weight, self._cfg_probe(), x1.dtype):
             return None
+        cfg = self._cfg(x1.shape[0], x1.device)
+        if lazy_in is not None:
+            return ops.PlainBlockHeadFn.apply(x1, conv.weight, conv.bias, norm.weight, norm.bias, cfg, head.weight, head.bias,
+                                              ops.LRELU_SLOPE, lazy_in.coefs, lazy_in.slope)
         return ops.PlainBlockHeadFn.apply(x1, conv.weight, conv.bias, norm.weight, norm.bias, cfg, head.weight, head.bias)
+
+    def _cfg_probe(self) -> ops.NormCfg:
+        """NormCfg for eligibility questions only: no dropout mask is drawn (a pooled mask must survive until the real call)."""
+        return ops.NormCfg(_NORM_MODE[self.normalization], self.training, sync=self.batch_sync)
 
     def forward(self, x):
         dt = x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32

@@ -42,7 +42,8 @@ class UNetEncoder(nn.Module):
         skips = []
         last = len(self.levels) - 1
         for l, s in enumerate(self.levels):
-            x = s[0].forward_nhwc(x, out_dtype=compute_dtype if l == 0 else None)
+            od = compute_dtype if l == 0 else None
+            x = s[0].forward_nhwc(x, out_dtype=od, lazy=True) if _pair_is_fused(s, x, od) else s[0].forward_nhwc(x, out_dtype=od)
             if l < last and isinstance(s[1], PlainBlock) and torch.is_grad_enabled():
                 # a level's output feeds the next level AND the decoder: two outputs on one storage, so each consumer's
                 # gradient reaches the block separately and is summed on load in its norm backward (no `add` pass)
@@ -63,6 +64,18 @@ class UNetEncoder(nn.Module):
         """adaptive_avg_pool2d(bottleneck, 1).view(B, -1)  (reference unet.py:87-91)."""
         b = self.forward_nhwc(ops.to_nhwc(x, _compute_dtype(self, x)))[-1]
         return ops.global_avg_pool(b)
+
+
+def _pair_is_fused(level, x, out_dtype=None, x2=None) -> bool:
+    """The two PlainBlocks of a level (unet.py:54-76, 157-173) run as a fused pair when the second block's kernels can
+    normalise on load: the first block then hands over its raw conv output (`ops.LazyAct`) and never writes its activation."""
+    b0, b1 = level[0], level[1]
+    if not (isinstance(b0, PlainBlock) and isinstance(b1, PlainBlock)):
+        return False
+    h, w = x.shape[1], x.shape[2]
+    if b0.stride == 2:
+        h, w = (h + 1) // 2, (w + 1) // 2
+    return b1.consumes_lazy(b0, h, w, out_dtype or x.dtype)
 
 
 def _compute_dtype(module, x):
@@ -119,14 +132,16 @@ class UNetDecoder(nn.Module):
         for l, feat in enumerate(skips):
             up = self.upsamples[l]
             x = ops.ConvTranspose2x2Fn.apply(x, up.weight, up.bias)
-            x = self.levels[l][0].forward_nhwc(feat, x)  # cat([skip, up], 1) folded into the conv's two-source read
+            # cat([skip, up], 1) folded into the conv's two-source read
+            b0 = self.levels[l][0]
+            x = b0.forward_nhwc(feat, x, lazy=True) if _pair_is_fused(self.levels[l], feat) else b0.forward_nhwc(feat, x)
             last = self.levels[l][1]
             if fuse_head and l == len(skips) - 1 and isinstance(last, PlainBlock):
                 # nobody but the segmentation head reads the last block's output: one fused node, no activation tensor
                 seg = last.forward_head_nhwc(x, self.seg_output)
                 if seg is not None:
                     return seg, None, ds_outputs, ds_feats
-            x = last.forward_nhwc(x)
+            x = last.forward_nhwc(x)  # (accepts an ops.LazyAct)
             if return_ds and self.deep_supervision and (l in self.ds_layer_list):
                 head = self.ds[l][0]
                 ds_feats.append(x)

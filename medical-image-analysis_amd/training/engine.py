@@ -182,6 +182,9 @@ class FlatOptimizer:
         self.param_groups[0].update({k: v for k, v in sd["param_groups"][0].items()})
 
 
+DP_RESERVE_CUS = int(os.environ.get("MIA_DP_RESERVE_CUS", "8"))  # default CU reservation of a multi-rank TrainEngine
+
+
 class GradBucketReducer:
     """Bucketed all-reduce of FlatOptimizer.flat_grad overlapped with backward (one process per GPU)."""
 
@@ -251,13 +254,25 @@ class TrainEngine:
     def __init__(self, model, loss_fn, optimizer_name: str = "adam", optimizer_kwargs: Optional[dict] = None,
                  start_lr: float = 1e-3, num_iters: int = 4000, lr_warmup_iter: int = 250, lr_interval: int = 1,
                  lr_scheduler_name: str = "poly", grad_norm: float = 10.0, process_group=None, bucket_bytes: int = 16 << 20,
-                 sync_batchnorm: Optional[bool] = None, force_reducer: bool = False):
+                 sync_batchnorm: Optional[bool] = None, force_reducer: bool = False, dp_reserve_cus: Optional[int] = None):
         """force_reducer: see GradBucketReducer(force=...).
+        dp_reserve_cus: CUs the persistent conv / weight-gradient kernels leave free for RCCL's ring kernels (library option
+        `reserve_cus`, include/mia_hip.h).  None (default) = DP_RESERVE_CUS (8: one CU per XCD) when the group has more than
+        one rank, else untouched; 0 = never reserve.  Why: the persistent kernels take one 512-thread workgroup per CU on a
+        STATIC work list, so a collective kernel that sits on a CU when the next compute kernel launches does not slow that
+        kernel by 1/256 -- the displaced workgroup runs after the others and the launch takes twice as long.  Pair it with
+        NCCL_MAX_NCHANNELS <= dp_reserve_cus (bench.py does) so the ring kernels fit into the reserved CUs.
         sync_batchnorm: None (default) = ON whenever the model holds batch-norm blocks and the process group has more
         than one rank, so N ranks x bs reproduce one process at N*bs (`normalization="batch"` is the al_train
         default, train.py:25); False keeps per-rank statistics (DDP-without-SyncBN behaviour) and says so once."""
         self.model = model
         world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if dp_reserve_cus is None:
+            dp_reserve_cus = DP_RESERVE_CUS if world > 1 else None
+        self.dp_reserve_cus = dp_reserve_cus
+        if dp_reserve_cus is not None and next(model.parameters()).is_cuda:
+            import mia_hip
+            mia_hip.set_option("reserve_cus", int(dp_reserve_cus))
         if world > 1:
             from models.unet.blocks import PlainBlock, ResidualBlock, convert_sync_batchnorm
             # ResidualBlock counts too: convert_sync_batchnorm raises NotImplementedError for it, which is the honest

@@ -190,13 +190,12 @@ def test_cfg1_tiny_fp32_engine_step_vs_oracle():
     x, y = _batch(n, size, seed=1337, k1=k1)
     lr = train_ref.poly_lr(0, 1e-3, 4000, 250)
     ref_logits, ref_loss, ref_grads, ref_gn, ref_post = _oracle_step(state, x, y, k1, norm, lr)
+    _, _, g64, _, _ = _oracle_step(state, x, y, k1, norm, lr, dtype=torch.float64)
     eng = TrainEngine(m, _loss_fn(k1), "adamw", {"weight_decay": 5e-4}, start_lr=1e-3, num_iters=4000, lr_warmup_iter=250)
     loss = eng.train_step({"image": x.to(dev), "label": y.to(dev)})
     assert abs(loss.item() - ref_loss) < 1e-4
     assert abs(eng.optimizer.last_norm[0].item() - ref_gn) / ref_gn < 2e-3
-    for name, p in m.named_parameters():
-        ref = ref_grads[name]
-        assert float((p.grad.cpu() - ref).abs().max()) < 2e-3 * max(float(ref.abs().max()), 1e-3), name
+    _check_grads_vs_exact([(n_, p.grad) for n_, p in m.named_parameters()], ref_grads, g64)
     for k, v in m.state_dict().items():
         assert float((v.cpu() - ref_post[k]).abs().max()) < 2.5 * lr + 1e-6, k
     m.eval()

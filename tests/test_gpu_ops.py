@@ -950,3 +950,162 @@ def test_wgrad_bt_stride2_matches_fast_kernel_and_reference(case):
         mia_hip.set_option("wgrad_bt", 1)
     assert relerr(on, wr.grad) < 1e-4 and relerr(off, wr.grad) < 1e-4
     assert torch.allclose(on, off, rtol=1e-4, atol=1e-4 * off.abs().max().item())
+
+
+# ---------------------------------------------------------------- fused PlainBlock: normalise-on-load (round 4)
+NL_CASES = [(2, 37, 53), (1, 16, 16), (3, 64, 48), (2, 128, 128), (1, 9, 200), (5, 33, 17)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", NL_CASES)
+def test_conv_and_wgrad_normalise_on_load_match_materialised_path(case):
+    """`mia_conv_mma_nl` / `mia_conv_wgrad_nl` (the consumer half of the fused PlainBlock, blocks.py:98-102 folded into the next
+    conv) against the two-pass path they replace -- `mia_norm_act_fwd` then `mia_conv_mma` / `mia_conv_wgrad` -- on the same
+    raw producer output and coefficient table.  The forward must be BIT-IDENTICAL (same fp32 fma / select / RNE, same conv
+    kernel); the weight gradient is bit-identical to the register-staged kernel it is built on (option wgrad_dma = 0) and
+    within fp32 summation order of the default LDS-DMA kernel.  Ragged tiles, border tiles, several images, image count not
+    a divisor of the tile walk; per-(n, c) coefficients of both signs incl. zero scale (Dropout2d-dropped channels)."""
+    import mia_hip
+    from mia_hip import CONV_G3S1, WGRAD_3S1, call, ops
+    from mia_hip.ops import _c_float, _c_i64, _p, _stream
+    dev = _dev()
+    n, h, w = case
+    c = 64
+    g = torch.Generator().manual_seed(100 + n * h + w)
+    y = (torch.randn(n, h, w, c, generator=g) * 1.5).to(dev, torch.bfloat16)
+    coefs = torch.zeros(5, n, c)
+    coefs[2] = torch.randn(n, c, generator=g)            # scale (both signs)
+    coefs[3] = torch.randn(n, c, generator=g) * 0.7      # shift
+    coefs[2][:, 5] = 0.0                                 # a dropped channel: z = lrelu(shift)
+    coefs[2][0, 9], coefs[3][0, 9] = 0.0, 0.0
+    coefs = coefs.to(dev)
+    wt = (torch.randn(c, c, 3, 3, generator=g) / 24).to(dev)
+    bias = torch.randn(c, generator=g).to(dev)
+    dy = torch.randn(n, h, w, c, generator=g).to(dev, torch.bfloat16)
+    slope = 0.01
+    pc = ops.PackCache()
+    wp, npad, kpad = pc.get(wt, mia_hip.BF16, True)
+    z = torch.empty_like(y)
+    call("mia_norm_act_fwd", _p(y), _p(z), mia_hip.BF16, _p(coefs[2]), _p(coefs[3]), n, _c_i64(h * w), c, _c_float(slope), _stream())
+    ref, _, ref_stats = ops.conv_mma(CONV_G3S1, z, None, wp, npad, kpad, False, bias, c, (h, w), want_stats=True)
+    if not ops.nl_supported(torch.bfloat16, c, c, h, w, True):
+        assert h <= 8
+        return
+    got, _, got_stats = ops.conv_mma(CONV_G3S1, y, None, wp, npad, kpad, False, bias, c, (h, w), want_stats=True, nl=(coefs, slope))
+    assert torch.equal(got, ref)
+    assert torch.equal(got_stats, ref_stats)
+    # torch-CPU fp32 math on the same bf16 operands
+    zc = z.float().cpu().permute(0, 3, 1, 2)
+    want = F.conv2d(zc, wt.cpu().to(torch.bfloat16).float(), bias.cpu(), padding=1)
+    assert relerr(nchw(got), want) < 1e-2
+    # weight gradient
+    dw_ref = ops.conv_wgrad(WGRAD_3S1, z, None, dy, wt.shape, c, c)
+    dw_nl = ops.conv_wgrad(WGRAD_3S1, y, None, dy, wt.shape, c, c, nl=(coefs, slope))
+    want_dw = torch.nn.grad.conv2d_weight(zc, wt.shape, dy.float().cpu().permute(0, 3, 1, 2), padding=1)
+    assert relerr(dw_nl, want_dw) < 2e-4 and relerr(dw_ref, want_dw) < 2e-4
+    assert relerr(dw_nl, dw_ref) < 2e-5
+    old = mia_hip.get_option("wgrad_dma")
+    try:
+        mia_hip.set_option("wgrad_dma", 0)
+        dw_2wg = ops.conv_wgrad(WGRAD_3S1, z, None, dy, wt.shape, c, c)
+    finally:
+        mia_hip.set_option("wgrad_dma", old)
+    assert torch.equal(dw_nl, dw_2wg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm,drop", [("instance", None), ("batch", None), ("instance", 0.3)])
+def test_fused_level_pairs_match_unfused_model(norm, drop):
+    """A bf16 UNet whose level-0 blocks are 64 channels wide runs stem -> encoder.levels.0.1 and decoder.levels.-1.0 ->
+    decoder.levels.-1.1 (+ head) as fused pairs (ops.LazyAct).  Against the same model with `ops.FUSE_NL = False`: logits
+    and every input-side gradient bit-identical, the two consumer blocks' weight gradients within fp32 summation order (a
+    different weight-gradient kernel serves them), in train and eval mode, with Dropout2d masks and batch norm."""
+    from losses.compound_losses import DiceAndCELoss
+    from mia_hip import ops
+    from models.unet import UNet
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(3, 1, 48, 80, generator=g).to(dev)
+    lab = torch.randint(0, 3, (3, 48, 80), generator=g).to(dev)
+    loss_fn = DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss)
+    res = {}
+    old = ops.FUSE_NL
+    try:
+        for fuse in (False, True):
+            ops.FUSE_NL = fuse
+            torch.manual_seed(11)
+            m = UNet(2, 1, 3, [64, 128], normalization=norm, dropout_prob=drop).to(dev)
+            m.set_compute_dtype(torch.bfloat16)
+            gp = torch.Generator().manual_seed(17)  # the same perturbation of the norm affine vectors / biases in both runs
+            with torch.no_grad():
+                for p in m.parameters():
+                    if p.ndim == 1:
+                        p.add_(0.1 * torch.randn(p.shape, generator=gp).to(dev))
+            m.train()
+            torch.manual_seed(5)  # Dropout2d masks come from the device generator
+            torch.cuda.manual_seed(5)
+            out = m(x)
+            loss = loss_fn(out, lab)
+            loss.backward()
+            grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+            m.eval()
+            with torch.no_grad():
+                ev = m(x).clone()
+                feat = m.get_pixel_feature(x)[1].clone()
+            res[fuse] = (out.detach().clone(), loss.item(), grads, ev, feat)
+    finally:
+        ops.FUSE_NL = old
+    a, b = res[False], res[True]
+    assert torch.equal(a[0], b[0]) and a[1] == b[1]
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    consumers = ("encoder.levels.0.1.all.0.weight", "decoder.levels.0.1.all.0.weight")
+    for k in a[2]:
+        if k in consumers:
+            assert relerr(b[2][k], a[2][k]) < 5e-5, k
+        else:
+            assert torch.equal(a[2][k], b[2][k]), k
+
+
+@pytest.mark.gpu
+def test_reserve_cus_keeps_results(monkeypatch):
+    """Library option `reserve_cus` (room for RCCL's ring kernels under data parallelism; include/mia_hip.h): the persistent
+    grids of conv_bt / conv_pw / conv64 / conv64_dma shrink to CUs - k workgroups over the SAME work items -- logits and every
+    activation gradient bit-identical for k in {0, 8, 24}; the weight gradients' split-K count follows k (another fixed fp32
+    summation order): equal within 1e-5 of the tensor's max, and run-to-run identical at a given k."""
+    import mia_hip
+    from losses.compound_losses import DiceAndCELoss
+    from models.unet import UNet
+    dev = _dev()
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(2, 1, 128, 160, generator=g).to(dev)
+    lab = torch.randint(0, 3, (2, 128, 160), generator=g).to(dev)
+    loss_fn = DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss)
+    torch.manual_seed(21)
+    m = UNet(2, 1, 3, [64, 128, 256], normalization="instance", dropout_prob=None).to(dev)
+    m.set_compute_dtype(torch.bfloat16)
+    m.train()
+    old = mia_hip.get_option("reserve_cus")
+    res = {}
+    try:
+        for k in (0, 8, 24, 8):
+            mia_hip.set_option("reserve_cus", k)
+            m.zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            out = m(xin)
+            loss_fn(out, lab).backward()
+            rec = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+            if k in res:  # second run at k = 8: bit-identical to the first
+                assert torch.equal(rec[0], res[k][0])
+                for n in rec[1]:
+                    assert torch.equal(rec[1][n], res[k][1][n]), n
+            res[k] = rec
+    finally:
+        mia_hip.set_option("reserve_cus", old)
+    for k in (8, 24):
+        assert torch.equal(res[k][0], res[0][0])
+        for n, gk in res[k][1].items():
+            g0 = res[0][1][n]
+            if n.endswith("all.0.weight") or "upsamples" in n and n.endswith("weight"):
+                assert relerr(gk, g0) < 1e-5, (k, n)
+            else:  # biases / norm affine / head: no split-K dependence
+                assert torch.equal(gk, g0), (k, n)

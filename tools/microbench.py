@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--stride", type=int, default=1)
+    ap.add_argument("--nl", type=int, default=1, help="block: 1 = the input is the previous block's raw output (normalise-on-load)")
     a = ap.parse_args()
     from mia_hip import CONV_G2S2, CONV_G3S1, CONV_G3S2, CONV_T2S2, WGRAD_3S1, WGRAD_3S2, ops
     dev = torch.device("cuda:0")
@@ -47,8 +48,23 @@ def main():
         wtb, ntb, ktb = pct.get(wt, ops._dt(dt), True)
         fine = torch.randn(a.batch, 2 * s, 2 * s, cout, device=dev).to(dt)
 
+    if a.what == "block":  # one C -> C PlainBlock forward + backward (the canonical block of the benchmark with --c 64 --size 512)
+        from mia_hip import NORM_INSTANCE
+        wpar = torch.nn.Parameter(w)
+        bpar, gam, bet = (torch.nn.Parameter(t) for t in (b, torch.ones(cout, device=dev), torch.zeros(cout, device=dev)))
+        coefs = torch.zeros(5, a.batch, a.c, device=dev)
+        coefs[2] = 1.0 + 0.1 * torch.randn(a.batch, a.c, device=dev)
+        coefs[3] = 0.1 * torch.randn(a.batch, a.c, device=dev)
+        xin = x.clone().requires_grad_(True)
+        gz = torch.randn(a.batch, so, so, cout, device=dev).to(dt)
+
     def run():
-        if a.what == "convt":
+        if a.what == "block":
+            cfg = ops.NormCfg(NORM_INSTANCE, True)
+            z = ops.PlainBlockFn.apply(xin, None, wpar, bpar, gam, bet, 1, cfg, None, ops.LRELU_SLOPE, False, False,
+                                       coefs if a.nl else None, ops.LRELU_SLOPE)
+            z.backward(gz)
+        elif a.what == "convt":
             ops.conv_mma(CONV_T2S2, x, None, wtf, ntf, ktf, False, b, cout, (2 * s, 2 * s))
         elif a.what == "convt_dgrad":
             ops.conv_mma(CONV_G2S2, fine, None, wtb, ntb, ktb, False, None, a.c, (s, s))
