@@ -134,6 +134,14 @@ int mia_stem_fwd(const void* x, int x_dtype, const float* w, const float* bias, 
                  int h, int wd, int c0, void* stream);
 int mia_stem_wgrad(const void* x, int x_dtype, const void* dy, int dtype, float* workspace, float* grad, int n, int h, int wd,
                    int c0, int accumulate, void* stream);
+/* mia_stem_wgrad with the block's norm + LeakyReLU backward folded in: dz is the gradient w.r.t. the stem block's ACTIVATED
+ * output, y its raw conv output, and the kernel forms dy = scale * (g - c1 - xhat * c2), g = dz * lrelu'(scale * y + shift), on
+ * load (rounded to `dtype` like the stored dy of mia_norm_act_bwd: same bits).  The stem has no input gradient, so this weight
+ * gradient is the only consumer of dy: pair it with mia_norm_bwd_sums and the backward apply pass (read dz + y, write dy) and the
+ * read of dy disappear.  scale / shift / xa / xb: mia_norm_finalize's rows; c1 / c2: mia_norm_bwd_sums' outputs. */
+int mia_stem_wgrad_fused(const void* x, int x_dtype, const void* dz, const void* y, int dtype, const float* scale,
+                         const float* shift, const float* xa, const float* xb, const float* c1, const float* c2, float slope,
+                         float* workspace, float* grad, int n, int h, int wd, int c0, int accumulate, void* stream);
 
 #define MIA_WGRAD_3S1 0
 #define MIA_WGRAD_3S2 1
@@ -181,6 +189,12 @@ int mia_norm_act_bwd(const void* dz, const void* dz2, const void* y, void* dy, i
                      const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
                      int fixed_stats, float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma,
                      float* dbeta, float* dbias, int accumulate, void* stream);
+/* mia_norm_act_bwd without its apply pass (no dy is written): reduction + finalize only -- c1 / c2 (group means of g and
+ * g * xhat), dgamma, dbeta, dbias.  For a block whose only consumer of dy forms it on load (mia_stem_wgrad_fused). */
+int mia_norm_bwd_sums(const void* dz, const void* dz2, const void* y, int dtype, const float* scale, const float* shift,
+                      const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
+                      int fixed_stats, float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma,
+                      float* dbeta, float* dbias, int accumulate, void* stream);
 
 /* Synchronised batch norm for data-parallel runs (build-side addition; SURVEY.md 8e: "a second, small collective"):
  * the caller moves 3*C floats (forward, all-gather) and 2*C floats (backward, all-reduce sum) per layer over RCCL and

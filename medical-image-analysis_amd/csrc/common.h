@@ -62,6 +62,15 @@ template <> struct Elem<bf16_t> {
   __device__ static __forceinline__ bf16_t cvt(float v) { return f2bf(v); }
 };
 
+// Norm + LeakyReLU backward for one element (reference autograd of blocks.py:98-102): g = dz * lrelu'(scale*y + shift),
+// dy = scale*(g - c1 - xhat*c2) = scale*g + ka*y + kb with ka = -scale*c2*xa, kb = -scale*(c1 + c2*xb).  ONE definition with explicit
+// fmas, shared by the streaming apply pass (norm.hip) and the kernels that form dy on load (stem.hip: mia_stem_wgrad_fused), so
+// both produce the same bits.
+__device__ __forceinline__ float norm_bwd_dy(float g, float yv, float sc, float sf, float ka, float kb, float slope) {
+  if (!(__builtin_fmaf(sc, yv, sf) > 0.f)) g *= slope;
+  return __builtin_fmaf(sc, g, __builtin_fmaf(ka, yv, kb));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -444,8 +444,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stream_kernel(const T* __res
       const float yv = Elem<T>::ld(yin + e);
       float g = Elem<T>::ld(gin + e);
       if (TWO) g += Elem<T>::ld(g2in + e);
-      if (!(sc[e] * yv + sf[e] > 0.f)) g *= slope;
-      out[e] = Elem<T>::cvt(sc[e] * g + ka[e] * yv + kb[e]);
+      out[e] = Elem<T>::cvt(norm_bwd_dy(g, yv, sc[e], sf[e], ka[e], kb[e], slope));
     }
     *reinterpret_cast<u32x4*>(dy + base + r * c) = *reinterpret_cast<const u32x4*>(out);
   };
@@ -759,6 +758,25 @@ extern "C" int mia_norm_act_bwd(const void* dz, const void* dz2, const void* y, 
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, mode, fixed_stats, scale, xa,
                      xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate, nullptr, inline_sums ? partials : nullptr, slabs);
   bwd_apply_launch(dz, dz2, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// mia_norm_act_bwd without its apply pass: the reduction over (dz, y) and the finalize (c1, c2 = the group means of g and
+// g*xhat; dgamma, dbeta, dbias) -- for a block whose only consumer of dy forms it on load (mia_stem_wgrad_fused).
+extern "C" int mia_norm_bwd_sums(const void* dz, const void* dz2, const void* y, int dtype, const float* scale, const float* shift,
+                                 const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
+                                 int fixed_stats, float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma,
+                                 float* dbeta, float* dbias, int accumulate, void* stream) {
+  MIA_CHECK_ARG(dz && y && scale && shift && xa && xb && partials && c1 && c2 && dgamma && dbeta, "mia_norm_bwd_sums: null pointer");
+  MIA_CHECK_ARG(n > 0 && hw > 0 && c > 0 && slabs > 0, "mia_norm_bwd_sums: bad shape");
+  if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_norm_bwd_sums: bad dtype"); return MIA_EARG; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  MIA_CHECK_ARG(two_piece_ok(dz, dz2, y, nullptr, dtype, c), "mia_norm_bwd_sums: two-piece gradient needs c %% 32 == 0 and aligned tensors");
+  const bool inline_sums = (int64_t)n * slabs <= 1024;
+  bwd_reduce_launch(dz, dz2, y, dtype, scale, shift, xa, xb, n, hw, c, slope, slabs, partials, c1, c2, st, !inline_sums);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, mode, fixed_stats, scale, xa,
+                     xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate, nullptr, inline_sums ? partials : nullptr, slabs);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

@@ -206,9 +206,16 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
 }
 
 // partial[blk][9][c0] = sum over the block's pixels of x[p + t] * dy[p][co]
-template <typename T, typename TI>
+// FUSED (mia_stem_wgrad_fused): `dy` holds dz, the gradient w.r.t. the block's ACTIVATED output, and the kernel forms the conv
+// output gradient on load from (dz, y, coefficients) with norm_bwd_dy -- rounded to T exactly as the streaming apply pass would
+// have stored it -- so that pass (read dz + y, write dy) and this kernel's read of dy collapse into one read of dz + y.
+struct StemFuse {
+  const void* y; const float* scale; const float* shift; const float* xa; const float* xb; const float* c1; const float* c2; float slope;
+};
+
+template <typename T, typename TI, bool FUSED = false>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TI* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
-                                                         int slabs, int h, int wd, int c0, int win_rows) {
+                                                         int slabs, int h, int wd, int c0, int win_rows, StemFuse fz) {
   constexpr int EPU = Elem<T>::EPU;
   extern __shared__ float red[];  // [lanes][c0 + 1], then (win_rows > 0) the slab's image window [win_rows][wd + 2]
   const int upp = c0 / EPU, lanes = 256 / upp;
@@ -220,6 +227,33 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TI* __restrict__ 
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int e = 0; e < EPU; ++e) acc[t][e] = 0.f;
+  float fsc[EPU], fsf[EPU], fka[EPU], fkb[EPU];  // FUSED: this thread's channel unit of image n
+  const T* yrow = nullptr;
+  if constexpr (FUSED) {
+    if (pl < lanes) {
+#pragma unroll
+      for (int e = 0; e < EPU; ++e) {
+        const size_t o = (size_t)n * c0 + u * EPU + e;
+        fsc[e] = fz.scale[o]; fsf[e] = fz.shift[o];
+        fka[e] = -fsc[e] * fz.c2[o] * fz.xa[o];
+        fkb[e] = -fsc[e] * (fz.c1[o] + fz.c2[o] * fz.xb[o]);
+      }
+    }
+    yrow = static_cast<const T*>(fz.y) + ((size_t)n * hw) * c0 + u * EPU;
+  }
+  // g (the block's conv-output gradient for this thread's EPU channels of one pixel) from the loaded unit(s)
+  auto grad_of = [&](const u32x4& raw, const u32x4& yraw, float* gf) {
+    alignas(16) T g[EPU]; alignas(16) T yv[EPU];
+    *reinterpret_cast<u32x4*>(g) = raw;
+    *reinterpret_cast<u32x4*>(yv) = yraw;
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) {
+      if constexpr (FUSED) {  // dy rounded to T exactly as the apply pass would have stored it
+        const T r = Elem<T>::cvt(norm_bwd_dy(Elem<T>::ld(g + e), Elem<T>::ld(yv + e), fsc[e], fsf[e], fka[e], fkb[e], fz.slope));
+        gf[e] = Elem<T>::ld(&r);
+      } else gf[e] = Elem<T>::ld(g + e);
+    }
+  };
   if (win_rows > 0 && r0 < r1) {
     // The nine image taps of a pixel come from LDS: the slab's rows (one above, one below, a zero column either side) are
     // staged once per block, so a tap is a broadcast ds_read with no bounds test.  As nine global loads per pixel group
@@ -237,12 +271,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TI* __restrict__ 
       const T* grow = dy + ((size_t)n * hw) * c0 + u * EPU;
       int p = r0 + pl;
       int py = p / wd, px = p - py * wd;
-      auto body = [&](const u32x4& raw, int wy, int wx) {  // (wy, wx): window coordinates of the pixel's top-left tap
-        alignas(16) T g[EPU];
-        *reinterpret_cast<u32x4*>(g) = raw;
+      auto body = [&](const u32x4& raw, const u32x4& yraw, int wy, int wx) {  // (wy, wx): window coordinates of the pixel's top-left tap
         float gf[EPU];
-#pragma unroll
-        for (int e = 0; e < EPU; ++e) gf[e] = Elem<T>::ld(g + e);
+        grad_of(raw, yraw, gf);
         const float* wrow = win + wy * wp + wx;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -251,17 +282,20 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TI* __restrict__ 
           for (int e = 0; e < EPU; ++e) acc[t][e] += xv * gf[e];
         }
       };
-      for (; p + lanes < r1; p += 2 * lanes) {  // two dy loads in flight
+      const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
+      auto ldy = [&](int pp) -> u32x4 { if constexpr (FUSED) return *reinterpret_cast<const u32x4*>(yrow + (size_t)pp * c0); else return zero; };
+      for (; p + lanes < r1; p += 2 * lanes) {  // two dy (FUSED: dz + y) loads in flight
         const u32x4 a0 = *reinterpret_cast<const u32x4*>(grow + (size_t)p * c0);
         const u32x4 a1 = *reinterpret_cast<const u32x4*>(grow + (size_t)(p + lanes) * c0);
-        body(a0, py - py0, px);
+        const u32x4 y0 = ldy(p), y1 = ldy(p + lanes);
+        body(a0, y0, py - py0, px);
         px += lanes;
         while (px >= wd) { px -= wd; ++py; }
-        body(a1, py - py0, px);
+        body(a1, y1, py - py0, px);
         px += lanes;
         while (px >= wd) { px -= wd; ++py; }
       }
-      if (p < r1) body(*reinterpret_cast<const u32x4*>(grow + (size_t)p * c0), py - py0, px);
+      if (p < r1) body(*reinterpret_cast<const u32x4*>(grow + (size_t)p * c0), ldy(p), py - py0, px);
     }
   } else if (pl < lanes && r0 + pl < r1) {
     const TI* img = x + (size_t)n * hw;
@@ -269,11 +303,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TI* __restrict__ 
     int p = r0 + pl;
     int py = p / wd, px = p - py * wd;  // one division per thread; the walk below is incremental
     for (; p < r1; p += lanes) {
-      alignas(16) T g[EPU];
-      *reinterpret_cast<u32x4*>(g) = *reinterpret_cast<const u32x4*>(grow + (size_t)p * c0);
       float gf[EPU];
-#pragma unroll
-      for (int e = 0; e < EPU; ++e) gf[e] = Elem<T>::ld(g + e);
+      u32x4 yraw = u32x4{0u, 0u, 0u, 0u};
+      if constexpr (FUSED) yraw = *reinterpret_cast<const u32x4*>(yrow + (size_t)p * c0);
+      grad_of(*reinterpret_cast<const u32x4*>(grow + (size_t)p * c0), yraw, gf);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
@@ -360,13 +393,9 @@ extern "C" int mia_stem_fwd(const void* x, int x_dtype, const float* w, const fl
   return MIA_OK;
 }
 
-extern "C" int mia_stem_wgrad(const void* x, int x_dtype, const void* dy, int dtype, float* workspace, float* grad, int n, int h, int wd,
-                              int c0, int accumulate, void* stream) {
-  MIA_CHECK_ARG(x && dy && workspace && grad && n > 0 && h > 0 && wd > 0, "mia_stem_wgrad: bad arguments");
-  MIA_CHECK_ARG((dtype == MIA_BF16 || dtype == MIA_F32) && (x_dtype == MIA_BF16 || x_dtype == MIA_F32), "mia_stem_wgrad: bad dtype");
-  MIA_CHECK_ARG(stem_ok(dtype, c0), "mia_stem_wgrad: c0=%d must be a multiple of the 16-byte unit and <= 256", c0);
+static int stem_wgrad_run(const void* x, int x_dtype, const void* dy, int dtype, float* workspace, float* grad, int n, int h, int wd,
+                          int c0, int accumulate, void* stream, const StemFuse* fuse) {
   const int epu = dtype == MIA_BF16 ? 8 : 4, lanes = 256 / (c0 / epu);
-  MIA_CHECK_ARG((int64_t)h * wd < ((int64_t)1 << 31) && n <= STEM_WBLOCKS, "mia_stem_wgrad: image or batch too large");
   // one block = one pixel slab of one image (n * slabs <= STEM_WBLOCKS partial rows in the workspace)
   const int64_t hw = (int64_t)h * wd;
   int slabs = STEM_WBLOCKS / n;
@@ -380,13 +409,39 @@ extern "C" int mia_stem_wgrad(const void* x, int x_dtype, const void* dy, int dt
   int win_rows = (int)((per + wd - 1) / wd) + 3;  // rows a slab can touch (it may start mid-row) + one above and below
   if ((size_t)win_rows * (wd + 2) * 4 + shb <= 60 * 1024) shb += (size_t)win_rows * (wd + 2) * 4;
   else win_rows = 0;
-#define SW(T, TI) hipLaunchKernelGGL((stem_wgrad_kernel<T, TI>), dim3(blocks), dim3(256), shb, st, static_cast<const TI*>(x), static_cast<const T*>(dy), workspace, slabs, h, wd, c0, win_rows)
-  if (dtype == MIA_BF16 && x_dtype == MIA_F32) SW(bf16_t, float);
-  else if (dtype == MIA_BF16) SW(bf16_t, bf16_t);
-  else if (x_dtype == MIA_F32) SW(float, float);
-  else SW(float, bf16_t);
+  const StemFuse fz = fuse ? *fuse : StemFuse{};
+#define SW(T, TI, F) hipLaunchKernelGGL((stem_wgrad_kernel<T, TI, F>), dim3(blocks), dim3(256), shb, st, static_cast<const TI*>(x), static_cast<const T*>(dy), workspace, slabs, h, wd, c0, win_rows, fz)
+#define SWF(T, TI) do { if (fuse) SW(T, TI, true); else SW(T, TI, false); } while (0)
+  if (dtype == MIA_BF16 && x_dtype == MIA_F32) SWF(bf16_t, float);
+  else if (dtype == MIA_BF16) SWF(bf16_t, bf16_t);
+  else if (x_dtype == MIA_F32) SWF(float, float);
+  else SWF(float, bf16_t);
+#undef SWF
 #undef SW
   hipLaunchKernelGGL(stem_wgrad_final_kernel, dim3(ceil_div(9 * c0, 16)), dim3(256), 0, st, workspace, blocks, c0, grad, accumulate);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
+}
+
+extern "C" int mia_stem_wgrad(const void* x, int x_dtype, const void* dy, int dtype, float* workspace, float* grad, int n, int h, int wd,
+                              int c0, int accumulate, void* stream) {
+  MIA_CHECK_ARG(x && dy && workspace && grad && n > 0 && h > 0 && wd > 0, "mia_stem_wgrad: bad arguments");
+  MIA_CHECK_ARG((dtype == MIA_BF16 || dtype == MIA_F32) && (x_dtype == MIA_BF16 || x_dtype == MIA_F32), "mia_stem_wgrad: bad dtype");
+  MIA_CHECK_ARG(stem_ok(dtype, c0), "mia_stem_wgrad: c0=%d must be a multiple of the 16-byte unit and <= 256", c0);
+  MIA_CHECK_ARG((int64_t)h * wd < ((int64_t)1 << 31) && n <= STEM_WBLOCKS, "mia_stem_wgrad: image or batch too large");
+  return stem_wgrad_run(x, x_dtype, dy, dtype, workspace, grad, n, h, wd, c0, accumulate, stream, nullptr);
+}
+
+// Weight gradient of the stem with the block's norm + LeakyReLU backward folded in (see stem_wgrad_kernel<.., FUSED>).
+extern "C" int mia_stem_wgrad_fused(const void* x, int x_dtype, const void* dz, const void* y, int dtype, const float* scale,
+                                    const float* shift, const float* xa, const float* xb, const float* c1, const float* c2, float slope,
+                                    float* workspace, float* grad, int n, int h, int wd, int c0, int accumulate, void* stream) {
+  MIA_CHECK_ARG(x && dz && y && scale && shift && xa && xb && c1 && c2 && workspace && grad && n > 0 && h > 0 && wd > 0,
+                "mia_stem_wgrad_fused: bad arguments");
+  MIA_CHECK_ARG((dtype == MIA_BF16 || dtype == MIA_F32) && (x_dtype == MIA_BF16 || x_dtype == MIA_F32), "mia_stem_wgrad_fused: bad dtype");
+  MIA_CHECK_ARG(stem_ok(dtype, c0), "mia_stem_wgrad_fused: c0=%d must be a multiple of the 16-byte unit and <= 256", c0);
+  MIA_CHECK_ARG((int64_t)h * wd < ((int64_t)1 << 31) && n <= STEM_WBLOCKS, "mia_stem_wgrad_fused: image or batch too large");
+  MIA_CHECK_ARG(((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "mia_stem_wgrad_fused: dz / y must be 16-byte aligned");
+  const StemFuse fz{y, scale, shift, xa, xb, c1, c2, slope};
+  return stem_wgrad_run(x, x_dtype, dz, dtype, workspace, grad, n, h, wd, c0, accumulate, stream, &fz);
 }

@@ -469,6 +469,7 @@ class LazyMaterializeFn(torch.autograd.Function):
         return dz, None, None
 
 
+FUSE_STEM_BWD = __import__('os').environ.get('MIA_FUSE_STEM_BWD', '1') != '0'  # A/B knob: the stem's backward apply pass folded into its weight gradient
 FUSE_NL = __import__('os').environ.get('MIA_FUSE_NL', '1') != '0'  # A/B knob: 0 = every block materialises its activation
 
 
@@ -601,6 +602,20 @@ class PlainBlockFn(torch.autograd.Function):
         dgamma = dgb[0] if dgamma is None else dgamma
         dbeta = dgb[1] if dbeta is None else dbeta
         dbias = dgb[2] if dbias is None else dbias
+        if ctx.stem and ctx.sync is None and FUSE_STEM_BWD:
+            # the stem has no input gradient: its weight gradient is the only consumer of dy and forms it on load -- no apply pass
+            call("mia_norm_bwd_sums", _p(dz), _p(dz2), _p(y), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
+                 _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs,
+                 _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
+            if dz2 is not None:
+                dz = dz + dz2
+            ws = torch.empty(lib().mia_stem_wgrad_workspace(cout), device=dev, dtype=torch.float32)
+            dw = grad_dest(weight)
+            if dw is None:
+                dw = torch.empty(weight.shape, device=dev, dtype=torch.float32)
+            call("mia_stem_wgrad_fused", _p(x1), _dt(x1), _p(dz), _p(y), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
+                 _p(cc[0]), _p(cc[1]), _c_float(ctx.slope), _p(ws), _p(dw), n, ho, wo, cout, 0, _stream())
+            return (None, None, dw, dbias, dgamma, dbeta) + (None,) * 8
         dy = torch.empty_like(y)
         if ctx.sync is None:
             call("mia_norm_act_bwd", _p(dz), _p(dz2), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),

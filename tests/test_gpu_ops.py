@@ -1109,3 +1109,58 @@ def test_reserve_cus_keeps_results(monkeypatch):
                 assert relerr(gk, g0) < 1e-5, (k, n)
             else:  # biases / norm affine / head: no split-K dependence
                 assert torch.equal(gk, g0), (k, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("norm,c0,hw", [("instance", 64, (48, 80)), ("batch", 16, (38, 54)), ("instance", 32, (130, 70))])
+def test_stem_backward_fused_into_weight_gradient(norm, c0, hw, dtype):
+    """The stem block has no input gradient, so its weight gradient is the only consumer of the conv-output gradient dy:
+    `mia_norm_bwd_sums` + `mia_stem_wgrad_fused` (dy formed on load from dz, y and the coefficient rows) against the path it
+    replaces (`mia_norm_act_bwd` writing dy, `mia_stem_wgrad` reading it): every gradient of the model BIT-IDENTICAL (the two
+    paths share one definition of the element-wise arithmetic, csrc/common.h::norm_bwd_dy, and round dy to the storage dtype
+    at the same point), and the stem's weight gradient against fp32-CPU autograd of the reference block."""
+    from mia_hip import ops
+    from models.unet import UNet
+    dev = _dev()
+    g = torch.Generator().manual_seed(c0 + hw[0])
+    x = torch.rand(3, 1, *hw, generator=g).to(dev)
+    gz = torch.randn(3, 3, *hw, generator=g).to(dev)
+    res = {}
+    old = ops.FUSE_STEM_BWD
+    try:
+        for fuse in (False, True):
+            ops.FUSE_STEM_BWD = fuse
+            torch.manual_seed(4)
+            m = UNet(2, 1, 3, [c0, 2 * c0], normalization=norm, dropout_prob=None).to(dev)
+            m.set_compute_dtype(dtype)
+            m.train()
+            (m(x) * gz).sum().backward()
+            res[fuse] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    finally:
+        ops.FUSE_STEM_BWD = old
+    for k in res[False]:
+        assert torch.equal(res[False][k], res[True][k]), k
+    # block-level check of the fused path against torch-CPU autograd (fp32 only: exact operands)
+    if dtype == torch.float32:
+        blk = torch.nn.Sequential(torch.nn.Conv2d(1, c0, 3, padding=1),
+                                  (torch.nn.InstanceNorm2d if norm == "instance" else torch.nn.BatchNorm2d)(c0, eps=1e-5, affine=True),
+                                  torch.nn.LeakyReLU(0.01))
+        sd = m.encoder.levels[0][0].all.state_dict()
+        blk.load_state_dict({"0.weight": sd["0.weight"].cpu(), "0.bias": sd["0.bias"].cpu(), "1.weight": sd["2.weight"].cpu(),
+                             "1.bias": sd["2.bias"].cpu(), **({"1.running_mean": torch.zeros(c0), "1.running_var": torch.ones(c0),
+                                                               "1.num_batches_tracked": torch.tensor(0)} if norm == "batch" else {})})
+        from models.unet.blocks import PlainBlock
+        pb = PlainBlock(2, 1, c0, normalization=norm).to(dev)
+        pb.all.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+        pb.train()
+        gg = torch.randn(3, c0, *hw, generator=g)
+        ops.FUSE_STEM_BWD = True
+        try:
+            (pb(x) * gg.to(dev)).sum().backward()
+        finally:
+            ops.FUSE_STEM_BWD = old
+        (blk.train()(x.cpu()) * gg).sum().backward()
+        assert relerr(pb.all[0].weight.grad, blk[0].weight.grad) < 2e-4
+        assert relerr(pb.all[2].weight.grad, blk[1].weight.grad) < 2e-4
+        assert relerr(pb.all[2].bias.grad, blk[1].bias.grad) < 2e-4

@@ -60,7 +60,9 @@ def main():
             e["valu_per_mfma"] = round(means.get("SQ_INSTS_VALU", 0) / means["SQ_INSTS_MFMA"], 3)
             e["lds_per_mfma"] = round(means.get("SQ_INSTS_LDS", 0) / means["SQ_INSTS_MFMA"], 3)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in means and means.get("SQ_BUSY_CYCLES"):
-            e["mfma_busy_frac_of_sq_busy"] = round(means["SQ_VALU_MFMA_BUSY_CYCLES"] / means["SQ_BUSY_CYCLES"], 4)
+            # SQ_VALU_MFMA_BUSY_CYCLES sums over the 1024 SIMDs, SQ_BUSY_CYCLES over the 32 shader engines: / 32 = per-SIMD busy share
+            # (the same normalisation reproduces the 0.60 of profiles/r02b_pmc_canonical_conv.csv for the plain kernel)
+            e["mfma_busy_frac"] = round(means["SQ_VALU_MFMA_BUSY_CYCLES"] / means["SQ_BUSY_CYCLES"] / 32.0, 4)
         rec["kernels"][k] = e
     dst = os.path.join(ROOT, "profiles", f"{out_tag}_pmc_canonical_block.csv")
     with open(dst, "w", newline="") as fh:
