@@ -303,6 +303,13 @@ int mia_gaussian_blur(const float* in, float* out, int nb, int c, int h, int w, 
 /* per-sample (mean, unbiased std) over C*H*W (gray=1, C=3: of the luma image): feeds contrast and z-score */
 int mia_sample_stats_workspace(int nb); /* floats */
 int mia_sample_stats(const float* in, int nb, int c, int64_t hw, int gray, float* workspace, float* mean_std, void* stream);
+/* Selected-sample forms for the batched pipeline (al_trainer.py:670-697: every stage is drawn per sample with p = 0.1 .. 0.2).
+ * In every augmentation entry point `apply[b]` > 0 transforms sample b, 0 copies it through, < 0 SKIPS it (not read, not
+ * written).  mia_sample_stats_sel: statistics of the samples with apply[b] >= 0 only.  mia_copy_selected: out[b] = in[b] for
+ * apply[b] > 0 (bytes_per_sample % 16 == 0) -- the copy-back of a neighbourhood stage run into a scratch buffer. */
+int mia_sample_stats_sel(const float* in, int nb, int c, int64_t hw, int gray, float* workspace, float* mean_std,
+                         const int* apply, void* stream);
+int mia_copy_selected(const void* in, void* out, int64_t bytes_per_sample, int nb, const int* apply, void* stream);
 #define MIA_EW_GAMMA 0    /* RandomGamma            image_transform.py:31 */
 #define MIA_EW_CONTRAST 1 /* RandomContrast / RandomBrightness (both ColorJitter(contrast=)) image_transform.py:62,:93 */
 #define MIA_EW_NOISE 2    /* RandomGaussianNoise with an explicit noise tensor image_transform.py:130-132 */

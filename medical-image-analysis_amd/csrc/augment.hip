@@ -6,11 +6,15 @@
 // :145-193, SimulateLowRes :196-236), normalization.py:9-26.  The reference runs these per sample on
 // the CPU inside DataLoader workers through torchvision; here every stage is one (or two, where a
 // per-sample statistic is needed) HBM-streaming launch over the whole batch: images [B,C,H,W] fp32,
-// labels [B,H,W] int64, parameters in small per-sample device arrays, `apply[b]==0` = pass-through.
+// labels [B,H,W] int64, parameters in small per-sample device arrays.  `apply[b]`: > 0 = transform sample b, 0 = pass it
+// through (copy in -> out), < 0 = SKIP it: nothing of sample b is read or written (round 4: the batched pipeline runs the
+// element-wise stages in place and the neighbourhood stages into a scratch buffer + mia_copy_selected, so a stage that was drawn
+// for 4 of 32 samples streams 4 samples, not 32).
 // Geometric ops move image and label in ONE launch.  All are bandwidth-bound (read once, write once).
 #include "common.h"
 
 __device__ __forceinline__ bool on(const int* apply, int b) { return apply == nullptr || apply[b] != 0; }
+__device__ __forceinline__ bool skipped(const int* apply, int b) { return apply != nullptr && apply[b] < 0; }
 
 // ---------------------------------------------------------------- inverse-affine nearest warp (image + label)
 // mats[b] = the 6 entries of torchvision's inverse affine matrix (centre frame).  The source pixel of every output pixel
@@ -53,6 +57,7 @@ __global__ void affine_nearest_kernel(const float* __restrict__ img_in, float* _
     const int b = (int)(i / groups);
     const int64_t p = (i - (int64_t)b * groups) * VEC;
     const int y = (int)(p / w), x0 = (int)(p - (int64_t)y * w);
+    if (skipped(apply, b)) continue;
     const bool act = on(apply, b);
     int src[VEC];
     bool ins[VEC];
@@ -130,6 +135,7 @@ __global__ void elastic_warp_kernel(const float* __restrict__ img_in, float* __r
     const int b = (int)(i / groups);
     const int64_t p = (i - (int64_t)b * groups) * VEC;
     const int y = (int)(p / w), x0 = (int)(p - (int64_t)y * w);
+    if (skipped(apply, b)) continue;
     const bool act = on(apply, b);
     const float* D = disp + (int64_t)b * 2 * gh * gw;
     const float v = (float)y * sv;
@@ -281,6 +287,7 @@ __global__ void gaussian_blur_kernel(const float* __restrict__ in, float* __rest
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t bc = i / hw, p = i - bc * hw;
     const int b = (int)(bc / c);
+    if (skipped(apply, b)) continue;
     if (!on(apply, b)) { out[i] = in[i]; continue; }
     const int k = ksize[b], r = k / 2;
     const float s = sigma[b];
@@ -325,9 +332,13 @@ extern "C" int mia_gaussian_blur(const float* in, float* out, int nb, int c, int
 // ---------------------------------------------------------------- per-sample statistics over C*H*W: stats[b] = (sum, sumsq) in double
 // gray=1 with c==3: statistics of 0.2989 r + 0.587 g + 0.114 b (torchvision rgb_to_grayscale) over H*W.
 __global__ void sample_stats_partial_kernel(const float* __restrict__ in, int c, int64_t hw, int gray, int slabs,
-                                            float* __restrict__ part) {
+                                            float* __restrict__ part, const int* __restrict__ apply) {
   __shared__ float red[16];
   const int b = blockIdx.x / slabs, s = blockIdx.x % slabs;
+  if (skipped(apply, b)) {  // nobody reads this sample's statistics: leave zeros (uniform per block)
+    if (threadIdx.x == 0) { part[(size_t)blockIdx.x * 2] = 0.f; part[(size_t)blockIdx.x * 2 + 1] = 0.f; }
+    return;
+  }
   const int64_t n = (gray && c == 3) ? hw : (int64_t)c * hw;
   const int64_t per = (n + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < n ? r0 + per : n;
   const float* src = in + (int64_t)b * c * hw;
@@ -356,10 +367,43 @@ __global__ void sample_stats_final_kernel(const float* __restrict__ part, int nb
 #define STAT_SLABS 64
 extern "C" int mia_sample_stats_workspace(int nb) { return nb * STAT_SLABS * 2; }
 
+static int sample_stats_run(const float* in, int nb, int c, int64_t hw, int gray, float* workspace, float* mean_std, const int* apply, void* stream);
+
 extern "C" int mia_sample_stats(const float* in, int nb, int c, int64_t hw, int gray, float* workspace, float* mean_std, void* stream) {
+  return sample_stats_run(in, nb, c, hw, gray, workspace, mean_std, nullptr, stream);
+}
+
+// statistics of the samples with apply[b] >= 0 only (the others are not read; their rows of mean_std are zero)
+extern "C" int mia_sample_stats_sel(const float* in, int nb, int c, int64_t hw, int gray, float* workspace, float* mean_std,
+                                    const int* apply, void* stream) {
+  return sample_stats_run(in, nb, c, hw, gray, workspace, mean_std, apply, stream);
+}
+
+// out[b] = in[b] for every sample with apply[b] > 0 (16-byte units; the copy-back half of a neighbourhood stage that ran into
+// a scratch buffer on the selected samples only)
+__global__ void copy_selected_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t units, int nb, const int* __restrict__ apply) {
+  const int64_t total = units * nb;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / units);
+    if (apply[b] > 0) out[i] = in[i];
+  }
+}
+
+extern "C" int mia_copy_selected(const void* in, void* out, int64_t bytes_per_sample, int nb, const int* apply, void* stream) {
+  MIA_CHECK_ARG(in && out && apply && nb > 0 && bytes_per_sample > 0 && bytes_per_sample % 16 == 0, "mia_copy_selected: bad arguments");
+  MIA_CHECK_ARG(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "mia_copy_selected: unaligned tensors");
+  const int64_t total = bytes_per_sample / 16 * nb;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(copy_selected_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const u32x4*>(in),
+                     static_cast<u32x4*>(out), bytes_per_sample / 16, nb, apply);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+static int sample_stats_run(const float* in, int nb, int c, int64_t hw, int gray, float* workspace, float* mean_std, const int* apply, void* stream) {
   MIA_CHECK_ARG(in && workspace && mean_std && nb > 0 && c > 0 && hw > 0, "mia_sample_stats: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(sample_stats_partial_kernel, dim3(nb * STAT_SLABS), dim3(256), 0, st, in, c, hw, gray, STAT_SLABS, workspace);
+  hipLaunchKernelGGL(sample_stats_partial_kernel, dim3(nb * STAT_SLABS), dim3(256), 0, st, in, c, hw, gray, STAT_SLABS, workspace, apply);
   const int64_t n = (gray && c == 3) ? hw : (int64_t)c * hw;
   hipLaunchKernelGGL(sample_stats_final_kernel, dim3(ceil_div(nb, 64)), dim3(64), 0, st, workspace, nb, STAT_SLABS, n, mean_std);
   MIA_LAUNCH_CHECK();
@@ -377,6 +421,7 @@ __global__ void elementwise_kernel(const float* __restrict__ in, float* __restri
   const int64_t total = per_sample * nb;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / per_sample);
+    if (skipped(apply, b)) continue;
     float v = in[i];
     if (on(apply, b)) {
       if (op == EW_GAMMA) v = powf(v, p0[b]);
@@ -412,6 +457,10 @@ __global__ void noise_clip_kernel(const float* __restrict__ in, float* __restric
                                   const int* __restrict__ apply) {
   const int64_t total = per_sample * nb, quads = (total + 3) / 4;
   for (int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < quads; qd += (int64_t)gridDim.x * blockDim.x) {
+    if (apply != nullptr) {  // a quad spans at most two samples: nothing to do when neither is selected for anything
+      const int64_t last = qd * 4 + 3 < total ? qd * 4 + 3 : total - 1;
+      if (apply[(int)(qd * 4 / per_sample)] < 0 && apply[(int)(last / per_sample)] < 0) continue;
+    }
     unsigned c0 = (unsigned)qd, c1 = (unsigned)(qd >> 32), c2 = (unsigned)offset, c3 = (unsigned)(offset >> 32);
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
@@ -425,6 +474,7 @@ __global__ void noise_clip_kernel(const float* __restrict__ in, float* __restric
       const int64_t i = qd * 4 + e;
       if (i >= total) break;
       const int b = (int)(i / per_sample);
+      if (skipped(apply, b)) continue;
       float v = in[i];
       if (on(apply, b)) { v += sigma[b] * z[e]; v = fminf(fmaxf(v, 0.f), 1.f); }
       out[i] = v;
@@ -459,6 +509,7 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ in, float* __re
     const int b = (int)(bc / c);
     const int y = (int)(p / ow), x = (int)(p - (int64_t)y * ow);
     const float* src = in + bc * (int64_t)h * w;
+    if (lowres != nullptr && skipped(apply, b)) continue;
     if (lowres != nullptr && !on(apply, b)) { out[i] = src[(int64_t)y * w + x]; continue; }
     const int lh = lowres ? lowres[b * 2] : h, lw = lowres ? lowres[b * 2 + 1] : w;
     const float sy = src_index((float)lh / (float)oh, y), sx = src_index((float)lw / (float)ow, x);

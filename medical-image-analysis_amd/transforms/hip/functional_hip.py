@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import threading
+import time
 from typing import Optional, Sequence
 
 import torch
@@ -39,6 +40,7 @@ class ParamArena:
         self.k = 0
         self._slots = [None] * self.RING  # (pinned host uint8, device uint8, event)
         self._turn = 0
+        self.wait_s = 0.0  # seconds the host spent blocked on a staging buffer the device had not consumed yet (GPU-bound loop)
 
     def begin_dry(self):
         self.dry, self.items, self.views, self.k = True, [], [], 0
@@ -59,7 +61,9 @@ class ParamArena:
                     torch.cuda.Event())
             self._slots[self._turn] = slot
         else:
+            t0 = time.perf_counter()
             slot[2].synchronize()  # the copy that last read this pinned buffer has completed (normally long ago)
+            self.wait_s += time.perf_counter() - t0
         host, dev, ev = slot
         hv = host.numpy()
         for a, o in zip(self.items, offs):
@@ -128,8 +132,49 @@ def _dev_i(vals, dev):
     return dev_array(np.asarray([int(v) for v in vals], dtype=np.int32), dev)
 
 
+def set_selective(flag: bool) -> None:
+    """Selected-sample mode (calling thread; set by BatchedAugment around one batch): a stage touches only the samples it was
+    drawn for -- element-wise stages run IN PLACE, neighbourhood stages write the selected samples into a scratch buffer and
+    `mia_copy_selected` puts them back, unselected samples are neither read nor written (`apply[b] = -1`, include/mia_hip.h).
+    The caller's tensors are modified in place in this mode."""
+    _TLS.selective = bool(flag)
+
+
+def _selective() -> bool:
+    return getattr(_TLS, "selective", False)
+
+
 def _apply(apply, dev):
-    return None if apply is None else _dev_i(apply, dev)
+    if apply is None:
+        return None
+    if _selective():
+        return _dev_i([1 if a else -1 for a in apply], dev)
+    return _dev_i(apply, dev)
+
+
+def _scratch(like: torch.Tensor) -> torch.Tensor:
+    """Per-thread scratch tensor of `like`'s shape / dtype / device, reused from batch to batch (selected-sample mode)."""
+    if like.is_meta:
+        return torch.empty_like(like)
+    pool = getattr(_TLS, "scratch", None)
+    if pool is None:
+        pool = _TLS.scratch = {}
+    key = (tuple(like.shape), like.dtype, like.device)
+    t = pool.get(key)
+    if t is None:
+        if len(pool) > 8:
+            pool.clear()
+        t = pool[key] = torch.empty_like(like)
+    return t
+
+
+def _sel_ok(*ts) -> bool:
+    """Selected-sample mode can serve these batch tensors: 16-byte multiples per sample (mia_copy_selected)."""
+    return _selective() and all(t is None or (t.numel() // t.shape[0] * t.element_size()) % 16 == 0 for t in ts)
+
+
+def _copy_back(src: torch.Tensor, dst: torch.Tensor, ap) -> None:
+    call("mia_copy_selected", _p(src), _p(dst), _c_i64(src.numel() // src.shape[0] * src.element_size()), src.shape[0], _p(ap), _stream())
 
 
 def affine_nearest(img: Optional[torch.Tensor], lab: Optional[torch.Tensor], mats: Sequence[Sequence[float]], apply=None):
@@ -141,17 +186,26 @@ def affine_nearest(img: Optional[torch.Tensor], lab: Optional[torch.Tensor], mat
     io = oi = lo = ol = None
     if img is not None:
         io = _f32(img)
-        oi = torch.empty_like(io)
     if lab is not None:
         if not _dry():
             _need_dev(lab)
         lo = lab.long().contiguous()
-        ol = torch.empty_like(lo)
+    sel = apply is not None and _sel_ok(io, lo)
+    if io is not None:
+        oi = _scratch(io) if sel else torch.empty_like(io)
+    if lo is not None:
+        ol = _scratch(lo) if sel else torch.empty_like(lo)
     m = dev_array(np.asarray([list(r) for r in mats], dtype=np.float32).reshape(b, 6), dev)
-    ap = _apply(apply, dev)
+    ap = _apply(apply, dev) if (sel or not _selective()) else _dev_i(apply, dev)
     if _dry():
-        return oi, ol
+        return (io, lo) if sel else (oi, ol)
     call("mia_affine_nearest", _p(io), _p(oi), _p(lo), _p(ol), b, c, h, w, _p(m), _p(ap), _stream())
+    if sel:  # selected samples only: scratch -> back into the batch tensors
+        if io is not None:
+            _copy_back(oi, io, ap)
+        if lo is not None:
+            _copy_back(ol, lo, ap)
+        return io, lo
     return oi, ol
 
 
@@ -172,16 +226,25 @@ def elastic_warp(img: Optional[torch.Tensor], lab: Optional[torch.Tensor], disp:
     io = oi = lo = ol = None
     if img is not None:
         io = _f32(img)
-        oi = torch.empty_like(io)
     if lab is not None:
         if not _dry():
             _need_dev(lab)
         lo = lab.long().contiguous()
-        ol = torch.empty_like(lo)
-    ap = _apply(apply, dev)
+    sel = apply is not None and _sel_ok(io, lo)
+    if io is not None:
+        oi = _scratch(io) if sel else torch.empty_like(io)
+    if lo is not None:
+        ol = _scratch(lo) if sel else torch.empty_like(lo)
+    ap = _apply(apply, dev) if (sel or not _selective()) else _dev_i(apply, dev)
     if _dry():
-        return oi, ol
+        return (io, lo) if sel else (oi, ol)
     call("mia_elastic_warp", _p(io), _p(oi), _p(lo), _p(ol), b, c, h, w, _p(d), d.shape[2], d.shape[3], _p(ap), _stream())
+    if sel:
+        if io is not None:
+            _copy_back(oi, io, ap)
+        if lo is not None:
+            _copy_back(ol, lo, ap)
+        return io, lo
     return oi, ol
 
 
@@ -226,23 +289,33 @@ def crop(x: torch.Tensor, top: Sequence[int], left: Sequence[int], oh: int, ow: 
 def gaussian_blur(img: torch.Tensor, sigma: Sequence[float], ksize: Sequence[int], apply=None) -> torch.Tensor:
     x = _f32(img)
     b, c, h, w = x.shape
-    out = torch.empty_like(x)
-    sg, ks, ap = _dev_f(sigma, x.device), _dev_i(ksize, x.device), _apply(apply, x.device)  # keep alive across the launch
+    sel = apply is not None and _sel_ok(x)
+    out = _scratch(x) if sel else torch.empty_like(x)
+    sg, ks = _dev_f(sigma, x.device), _dev_i(ksize, x.device)  # keep alive across the launch
+    ap = _apply(apply, x.device) if (sel or not _selective()) else _dev_i(apply, x.device)
     if _dry():
-        return out
+        return x if sel else out
     call("mia_gaussian_blur", _p(x), _p(out), b, c, h, w, _p(sg), _p(ks), int(max(ksize)), _p(ap), _stream())
+    if sel:
+        _copy_back(out, x, ap)
+        return x
     return out
 
 
-def sample_stats(img: torch.Tensor, gray: bool = False) -> torch.Tensor:
-    """[B, 2] = per-sample (mean, unbiased std) over C*H*W (luma image if gray and C == 3)."""
+def sample_stats(img: torch.Tensor, gray: bool = False, apply=None) -> torch.Tensor:
+    """[B, 2] = per-sample (mean, unbiased std) over C*H*W (luma image if gray and C == 3).  In selected-sample mode with an
+    `apply` list only the selected samples are read (the other rows are zero)."""
     x = _f32(img)
     b, c, h, w = x.shape
     ws = torch.empty(lib().mia_sample_stats_workspace(b), device=x.device, dtype=torch.float32)
     out = torch.empty((b, 2), device=x.device, dtype=torch.float32)
+    ap = _apply(apply, x.device) if (apply is not None and _selective()) else None
     if _dry():
         return out
-    call("mia_sample_stats", _p(x), b, c, _c_i64(h * w), int(gray), _p(ws), _p(out), _stream())
+    if ap is not None:
+        call("mia_sample_stats_sel", _p(x), b, c, _c_i64(h * w), int(gray), _p(ws), _p(out), _p(ap), _stream())
+    else:
+        call("mia_sample_stats", _p(x), b, c, _c_i64(h * w), int(gray), _p(ws), _p(out), _stream())
     return out
 
 
@@ -250,7 +323,7 @@ def elementwise(img: torch.Tensor, op: int, p0=None, mean_std: Optional[torch.Te
                 aux: Optional[torch.Tensor] = None, apply=None) -> torch.Tensor:
     x = _f32(img)
     b = x.shape[0]
-    out = torch.empty_like(x)
+    out = x if (_selective() and apply is not None) else torch.empty_like(x)  # selected-sample mode: in place
     pp = None if p0 is None else _dev_f(p0, x.device)
     if aux is not None:
         aux = _f32(aux)
@@ -264,7 +337,7 @@ def elementwise(img: torch.Tensor, op: int, p0=None, mean_std: Optional[torch.Te
 def noise_clip(img: torch.Tensor, sigma: Sequence[float], seed: int, offset: int = 0, apply=None) -> torch.Tensor:
     x = _f32(img)
     b = x.shape[0]
-    out = torch.empty_like(x)
+    out = x if (_selective() and apply is not None) else torch.empty_like(x)  # selected-sample mode: in place
     sg, ap = _dev_f(sigma, x.device), _apply(apply, x.device)
     if _dry():
         return out
@@ -292,12 +365,16 @@ def lowres(img: torch.Tensor, low_hw: Sequence[Sequence[int]], apply=None) -> to
     """SimulateLowRes: nearest-exact down to low_hw[b], bilinear back up, fused."""
     x = _f32(img)
     b, c, h, w = x.shape
-    out = torch.empty_like(x)
+    sel = apply is not None and _sel_ok(x)
+    out = _scratch(x) if sel else torch.empty_like(x)
     lw = dev_array(np.asarray([[int(a), int(d)] for a, d in low_hw], dtype=np.int32), x.device)
-    ap = _apply(apply, x.device)
+    ap = _apply(apply, x.device) if (sel or not _selective()) else _dev_i(apply, x.device)
     if _dry():
-        return out
+        return x if sel else out
     call("mia_resize_bilinear", _p(x), _p(out), b, c, h, w, h, w, _p(lw), _p(ap), _stream())
+    if sel:
+        _copy_back(out, x, ap)
+        return x
     return out
 
 

@@ -44,7 +44,11 @@ class BatchedAugment:
     {"image": [B,C,S,S] f32, "label": [B,S,S] int64} ready for ``train_step``."""
 
     def __init__(self, transform: Optional[ComposeTransform] = None, image_size=None, do_normalize: bool = False,
-                 antialias: bool = True):
+                 antialias: bool = True, inplace: bool = False):
+        """inplace=True: `images` / `labels` may be overwritten (a batch fresh from the loader); False (default): the stages
+        work on a copy (one device-to-device copy of the batch).  Either way every stage touches only the samples it was drawn
+        for (functional_hip.set_selective): al_train's stages fire with p = 0.1 .. 0.2 per sample (al_trainer.py:674-697)."""
+        self.inplace = inplace
         self.transform = transform
         self.final = JointResize(image_size, antialias=antialias) if image_size is not None else None
         self.normalize = ZScoreNormalize() if do_normalize else None
@@ -65,6 +69,14 @@ class BatchedAugment:
             self._arena = FH.ParamArena(images.device)
         arena = self._arena
         FH.set_arena(arena)
+        fires = params is not None and any(q is not None and any(x is not None for x in q) for q in params)
+        if fires:  # the stages modify their batch in place (selected samples only): work on a copy unless told otherwise
+            img_f, lab_l = images.float(), labels.long()  # no-ops for the usual fp32 / int64 inputs
+            if not self.inplace:
+                img_f = img_f.clone() if img_f.data_ptr() == images.data_ptr() else img_f  # (hipMemcpy D2D)
+                lab_l = lab_l.clone() if lab_l.data_ptr() == labels.data_ptr() else lab_l
+            images, labels = img_f.contiguous(), lab_l.contiguous()
+        FH.set_selective(bool(fires))
         try:
             arena.begin_dry()
             rng_before = torch.get_rng_state()
@@ -79,6 +91,7 @@ class BatchedAugment:
         finally:
             arena.dry = False
             FH.set_arena(None)
+            FH.set_selective(False)
         return {"image": images, "label": labels, "_bytes": nbytes}
 
     def _run(self, images, labels, params, b):
@@ -97,17 +110,18 @@ class BatchedAugment:
 
     def _stage_bytes(self, params, images, labels) -> int:
         """Algorithmic bytes of the stages that run on this batch (a stage reads its image (+ label) once and writes
-        it once; a stage selected for at least one sample streams the whole batch, the others are skipped)."""
+        it once), counted per SELECTED sample: a stage drawn for k of the B samples streams k samples."""
         b, c, h, w = images.shape
-        img_b, lab_b = b * c * h * w * 4, b * h * w * 8
+        img_b, lab_b = c * h * w * 4, h * w * 8  # per sample
         total = 0
         stages = getattr(self.transform, "transforms", [])
         for i, t in enumerate(stages):
-            if all(q is None or q[i] is None for q in params):
+            k = sum(1 for q in params if q is not None and q[i] is not None)
+            if k == 0:
                 continue
             inner = getattr(t, "transform", t)
             geometric = isinstance(inner, (RandomAffine, RandomElastic, RandomRotation, RandomRotation90, MirrorTransform))
-            total += 2 * img_b + (2 * lab_b if geometric else 0)
+            total += k * (2 * img_b + (2 * lab_b if geometric else 0))
             if isinstance(inner, (RandomContrast, RandomBrightness)):
-                total += img_b  # the mean pass
+                total += k * img_b  # the mean pass
         return total

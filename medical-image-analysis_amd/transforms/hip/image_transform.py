@@ -49,7 +49,7 @@ class _ContrastJitter(BaseTransform):
         return (float(torch.empty(1).uniform_(float(lo), float(hi))),)
 
     def apply_batch(self, images, labels, params):
-        ms = FH.sample_stats(images, gray=(images.shape[1] == 3))
+        ms = FH.sample_stats(images, gray=(images.shape[1] == 3), apply=_on(params))
         return FH.elementwise(images, FH.EW_CONTRAST, p0=[p[0] if p else 1.0 for p in params], mean_std=ms, apply=_on(params)), labels
 
 

@@ -347,3 +347,90 @@ def test_train_engine_matches_golden_step():
         # prediction path (valid_slices core)
         pred = eng.predict(torch.from_numpy(d["x"]))
         assert pred.shape == (2, 32, 32) and pred.dtype == torch.long
+
+
+def test_selected_sample_mode_touches_only_the_drawn_samples():
+    """Round 4: a stage drawn for k of B samples streams k samples.  Kernel level: `apply[b] < 0` leaves
+    sample b of the output untouched (not read, not written) in every stage kernel, `mia_copy_selected` copies the selected
+    samples only, `mia_sample_stats_sel` zeroes the rows it skips.  Pipeline level: BatchedAugment (selected-sample mode,
+    element-wise stages in place, neighbourhood stages through a scratch buffer) gives exactly the outputs of the
+    whole-batch path (`functional_hip.set_selective` never switched on), leaves the caller's tensors alone unless
+    `inplace=True`, and `inplace=True` gives the same outputs."""
+    import ctypes
+    from mia_hip import call
+    from mia_hip.ops import _c_float, _c_i64, _p, _stream
+    from transforms import functional_hip as FH
+    from transforms.gpu_pipeline import BatchedAugment, al_train_transforms
+    from transforms.image_transform import RandomGaussianNoise
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    b, h, w = 5, 40, 64
+    x = torch.rand(b, 1, h, w, generator=g).to(dev)
+    lab = torch.randint(0, 3, (b, h, w), generator=g).to(dev)
+    ap = torch.tensor([1, -1, 0, -1, 1], dtype=torch.int32, device=dev)
+    sentinel = -7.0
+    # blur / low-res / element-wise / noise / affine / elastic: skipped samples keep the sentinel, pass-through samples are copied
+    out = torch.full_like(x, sentinel)
+    sg = torch.full((b,), 0.8, device=dev)
+    ks = torch.full((b,), 3, dtype=torch.int32, device=dev)
+    call("mia_gaussian_blur", _p(x), _p(out), b, 1, h, w, _p(sg), _p(ks), 3, _p(ap), _stream())
+    assert (out[1] == sentinel).all() and (out[3] == sentinel).all() and torch.equal(out[2], x[2]) and not torch.equal(out[0], x[0])
+    out = torch.full_like(x, sentinel)
+    lw = torch.tensor([[20, 32]] * b, dtype=torch.int32, device=dev)
+    call("mia_resize_bilinear", _p(x), _p(out), b, 1, h, w, h, w, _p(lw), _p(ap), _stream())
+    assert (out[1] == sentinel).all() and torch.equal(out[2], x[2]) and not torch.equal(out[4], x[4])
+    out = torch.full_like(x, sentinel)
+    p0 = torch.full((b,), 1.3, device=dev)
+    call("mia_elementwise", _p(x), _p(out), _c_i64(h * w), b, 0, _p(p0), None, None, _p(ap), _stream())
+    assert (out[3] == sentinel).all() and torch.equal(out[2], x[2]) and torch.allclose(out[0], x[0] ** 1.3, atol=1e-6)
+    out = torch.full_like(x, sentinel)
+    call("mia_noise_clip", _p(x), _p(out), _c_i64(h * w), b, _p(sg), ctypes.c_uint64(5), ctypes.c_uint64(0), _p(ap), _stream())
+    assert (out[1] == sentinel).all() and (out[3] == sentinel).all() and torch.equal(out[2], x[2]) and not torch.equal(out[0], x[0])
+    oi, ol = torch.full_like(x, sentinel), torch.full_like(lab, -7)
+    mats = torch.tensor([[0.9, 0.1, 0.0, -0.1, 0.9, 0.0]] * b, device=dev)
+    call("mia_affine_nearest", _p(x), _p(oi), _p(lab), _p(ol), b, 1, h, w, _p(mats), _p(ap), _stream())
+    assert (oi[1] == sentinel).all() and (ol[3] == -7).all() and torch.equal(oi[2], x[2]) and torch.equal(ol[2], lab[2])
+    oi, ol = torch.full_like(x, sentinel), torch.full_like(lab, -7)
+    disp = torch.randn(b, 2, 3, 3, generator=g).to(dev) * 3
+    call("mia_elastic_warp", _p(x), _p(oi), _p(lab), _p(ol), b, 1, h, w, _p(disp), 3, 3, _p(ap), _stream())
+    assert (oi[3] == sentinel).all() and (ol[1] == -7).all() and torch.equal(oi[2], x[2]) and torch.equal(ol[2], lab[2])
+    # copy_selected / sample_stats_sel
+    dst = torch.full_like(x, sentinel)
+    call("mia_copy_selected", _p(x), _p(dst), _c_i64(h * w * 4), b, _p(ap), _stream())
+    assert torch.equal(dst[0], x[0]) and torch.equal(dst[4], x[4]) and (dst[1:4] == sentinel).all()
+    ws = torch.empty(FH.lib().mia_sample_stats_workspace(b), device=dev)
+    ms = torch.empty(b, 2, device=dev)
+    call("mia_sample_stats_sel", _p(x), b, 1, _c_i64(h * w), 0, _p(ws), _p(ms), _p(ap), _stream())
+    full = FH.sample_stats(x)
+    assert torch.equal(ms[[0, 2, 4]], full[[0, 2, 4]]) and (ms[[1, 3]] == 0).all()
+    # pipeline: selected-sample mode == whole-batch mode, inputs preserved, inplace identical
+    RandomGaussianNoise.exact_rng = True
+    try:
+        imgs = torch.rand(8, 1, 96, 128, generator=g).to(dev)
+        labs = torch.randint(0, 3, (8, 96, 128), generator=g).to(dev)
+        keep_i, keep_l = imgs.clone(), labs.clone()
+        pipe = al_train_transforms("busi", elastic=True)
+        seed = next(s for s in range(300, 400) if _n_stages(pipe, s, 8, (1, 96, 128)) >= 6)
+        torch.manual_seed(seed)
+        got = BatchedAugment(pipe, image_size=64)(imgs, labs)
+        assert torch.equal(imgs, keep_i) and torch.equal(labs, keep_l)
+        # whole-batch reference: the same pipeline with the selective switch held off
+        real = FH.set_selective
+        FH.set_selective = lambda flag: real(False)
+        try:
+            torch.manual_seed(seed)
+            want = BatchedAugment(pipe, image_size=64)(imgs, labs)
+        finally:
+            FH.set_selective = real
+        assert torch.equal(got["image"], want["image"]) and torch.equal(got["label"], want["label"])
+        assert 0 < got["_bytes"] < want["_bytes"] or got["_bytes"] == want["_bytes"]
+        torch.manual_seed(seed)
+        inpl = BatchedAugment(pipe, image_size=64, inplace=True)(imgs.clone(), labs.clone())
+        assert torch.equal(inpl["image"], got["image"]) and torch.equal(inpl["label"], got["label"])
+    finally:
+        RandomGaussianNoise.exact_rng = False
+
+
+def _n_stages(pipe, seed, b, shape):
+    torch.manual_seed(seed)
+    return sum(1 for _ in range(b) for q in pipe.draw(shape) if q is not None)
