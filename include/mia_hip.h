@@ -125,6 +125,18 @@ int mia_conv_mma_nl(int mode, int dtype, const void* y_in, int c1, const float* 
                     const void* wpack, int npad, int kpad, const float* bias, void* out, int nout, float* stat_partials,
                     int n, int hin, int win, int hout, int wout, void* stream);
 
+/* Fused PlainBlock, backward: the input-gradient conv of the CONSUMING block with the producing block's norm-backward reduction
+ * in its epilogue.  out = dz, the gradient w.r.t. the producing block's activated output (what mia_conv_mma computes with
+ * flip_taps = 1); y_prod / scale / shift / xa / xb = that block's raw conv output and coefficient rows (mia_norm_finalize).
+ * While a tile's accumulators are in registers the kernel adds up g = dz * lrelu'(scale * y + shift) and g * (xa * y + xb) from
+ * the bf16-rounded dz it stores, and writes partials [N][tiles][nout][2] (tiles as mia_conv_mma_tiles) -- the input of
+ * mia_norm_act_bwd_pre, which then skips its own reduction pass over dz and y (blocks.py:98-102 backward).  3x3 stride 1, bf16,
+ * 64 -> 64 channels (mia_conv_cr_supported). */
+int mia_conv_cr_supported(int mode, int dtype, int c1, int nout, int hout, int wout);
+int mia_conv_mma_cr(int mode, int dtype, const void* in1, int c1, const void* wpack, int npad, int kpad, int flip_taps,
+                    void* out, int nout, const void* y_prod, const float* scale, const float* shift, const float* xa,
+                    const float* xb, float slope, float* partials, int n, int hin, int win, int hout, int wout, void* stream);
+
 /* Stem: Conv2d(1, C0, 3, padding=1) (first encoder block, unet.py:54-66 with input_channels=1): HBM-streaming VALU
  * kernels (9 FMAs per output; MFMA would idle 31/32 of its K).  x is the [N][H][W] image in x_dtype (fp32 or bf16),
  * y / dy are NHWC in `dtype`; stat_partials [N][mia_stem_slabs()][C0][2]; grad is the [C0][1][3][3] parameter layout. */
@@ -195,6 +207,12 @@ int mia_norm_bwd_sums(const void* dz, const void* dz2, const void* y, int dtype,
                       const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
                       int fixed_stats, float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma,
                       float* dbeta, float* dbias, int accumulate, void* stream);
+/* mia_norm_act_bwd with the reduction already done: partials [n][parts][c][2] come from mia_conv_mma_cr.  Sums + finalize; the
+ * apply pass (dy = ...) runs only when dy != NULL (NULL: the consumer forms dy on load, mia_stem_wgrad_fused). */
+int mia_norm_act_bwd_pre(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
+                         const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
+                         int fixed_stats, float slope, int parts, const float* partials, float* c1, float* c2,
+                         float* dgamma, float* dbeta, float* dbias, int accumulate, void* stream);
 
 /* Synchronised batch norm for data-parallel runs (build-side addition; SURVEY.md 8e: "a second, small collective"):
  * the caller moves 3*C floats (forward, all-gather) and 2*C floats (backward, all-reduce sum) per layer over RCCL and

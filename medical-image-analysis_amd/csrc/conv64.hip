@@ -47,6 +47,7 @@ struct Tile { int img, ty, tx; };
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // two floats -> packed bf16 pair (low = a): ONE v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
@@ -95,7 +96,11 @@ extern "C" int mia_conv64_debug_read(unsigned long long* host_out) {
 // v_cvt_pk; the 16 x 2 coefficients of a thread's channels come from a 512-byte LDS table refreshed per tile by threads
 // 0..127 (one extra VGPR across the matrix phase).  Zero padding is padding of z, not of y: halo units outside the image
 // are forced back to zero (border tiles only; 6 validity bits per thread).
-template <bool NL>
+// CR = column-reduce epilogue (ConvArgs::cr_*): the launch computes an input gradient dz and, while the tile's accumulators are
+// still in registers, the per-tile sums of g = dz * lrelu'(scale*y + shift) and g * xhat for the norm backward of the block
+// that produced this activation -- from the bf16-rounded dz it is about to store and the y tile it loads here (8 bytes per lane
+// and row).  Replaces that block's stand-alone reduction pass (read dz + read y: colreduce_vec_kernel) by one read of y.
+template <bool NL, bool CR>
 __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a, int total_tiles, int tiles_per_img, int run, int n_base) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + (NL ? 2 * C * 4 : 0)];
   u32x4* ldsA = reinterpret_cast<u32x4*>(smem);
@@ -303,6 +308,52 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
     const int row_bytes = a.Wout * (C * 2);
     const bool want_stats = a.stats != nullptr;  // uniform
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    // CR: this lane's four channels of the producing block's coefficient rows, and the y tile (row m: 8 bytes per lane,
+    // fetched in two batches of eight rows so that at most 28 registers hold them)
+    f32x4 csc, csf, cxa, cxb;
+    u32x2 yv[TH];
+    const unsigned ybase = (unsigned)(((oy0 * a.Wout) + ox0 + pr) * (C * 2) + (16 * wave + 4 * q) * 2);
+    rsrc_t rsy;
+    constexpr int YB = 2;  // rows per y batch
+    auto load_y = [&](int m0, bool full_t) {
+#pragma unroll
+      for (int mm = m0; mm < m0 + YB; ++mm) {
+        const bool ok = full_t || (colok && oy0 + mm < a.Hout);
+#if defined(CR_DBG) && CR_DBG == 2
+        yv[mm] = u32x2{0x3F803F80u + (unsigned)mm, 0x3F803F80u};
+#else
+        yv[mm] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsy, (int)(ok ? ybase + (unsigned)(mm * row_bytes) : SENT), 0, 0));
+#endif
+      }
+    };
+    if constexpr (CR) {
+      const unsigned cbytes = (unsigned)(a.N * C * 4);
+      const int co = (cur.img * C + 16 * wave + 4 * q) * 4;  // scalar descriptors + one 32-bit lane offset: no 64-bit lane pointers
+      csc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.cr_scale, cbytes), co, 0, 0));
+      csf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.cr_shift, cbytes), co, 0, 0));
+      cxa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.cr_xa, cbytes), co, 0, 0));
+      cxb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(a.cr_xb, cbytes), co, 0, 0));
+      rsy = make_rsrc(static_cast<const bf16_t*>(a.cr_y) + (size_t)cur.img * ipix * C, img_bytes);
+      load_y(0, full);
+      load_y(YB, full);
+    }
+    // CR: one row of this lane (4 channels: packed bf16 pairs p01, p23 = the dz about to be stored; y pairs from yv)
+    auto cr_row = [&](unsigned p01, unsigned p23, const u32x2& yr, float wgt) {
+      const unsigned dzw[2] = {p01, p23}, yw[2] = {yr[0], yr[1]};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int r = 2 * h + e;
+          const float dzv = __builtin_bit_cast(float, e ? (dzw[h] & 0xFFFF0000u) : (dzw[h] << 16));
+          const float y = __builtin_bit_cast(float, e ? (yw[h] & 0xFFFF0000u) : (yw[h] << 16));
+          float g = dzv * wgt;
+          if (!(__builtin_fmaf(csc[r], y, csf[r]) > 0.f)) g *= a.cr_slope;
+          s1[r] += g;
+          s2[r] = __builtin_fmaf(g, __builtin_fmaf(cxa[r], y, cxb[r]), s2[r]);
+        }
+      }
+    };
     auto store_rows = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
       // the inline-asm statistics below read MFMA results; hipcc pads hazards only for instructions it emits itself, so the
@@ -310,7 +361,10 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
       if constexpr (FULL) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
 #pragma unroll
       for (int m = 0; m < TH; m += 2) {
-        if (want_stats) {
+        if constexpr (CR) {  // y rows two batches (eight rows) ahead of their use
+          if (m % YB == 0 && m + 2 * YB < TH) load_y(m + 2 * YB, FULL);
+        }
+        if (want_stats && !CR) {
 #pragma unroll
           for (int mm = m; mm < m + 2; ++mm) {
             const float w = (FULL || (colok && oy0 + mm < a.Hout)) ? 1.f : 0.f;
@@ -325,6 +379,14 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
         // packed bf16 pairs: x = row m, y = row m+1 (this lane's 4 channels each)
         const unsigned x0 = pack_bf16x2(acc[m][0], acc[m][1]), x1 = pack_bf16x2(acc[m][2], acc[m][3]);
         const unsigned y0 = pack_bf16x2(acc[m + 1][0], acc[m + 1][1]), y1 = pack_bf16x2(acc[m + 1][2], acc[m + 1][3]);
+        if constexpr (CR) {
+#if !defined(CR_DBG) || CR_DBG != 1
+          cr_row(x0, x1, yv[m], (FULL || (colok && oy0 + m < a.Hout)) ? 1.f : 0.f);
+          cr_row(y0, y1, yv[m + 1], (FULL || (colok && oy0 + m + 1 < a.Hout)) ? 1.f : 0.f);
+#else
+          s1[0] += __builtin_bit_cast(float, yv[m][0] ^ yv[m + 1][1]);
+#endif
+        }
         // vdst rows 1,3 (odd q) <-> src rows 0,2 (even q): even q gets its partner's x in y, odd q its partner's y in x
         const auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
         const auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
@@ -335,6 +397,25 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
           const bool ok = colok && (oy0 + m + qodd < a.Hout);
           const unsigned voff = ok ? obase + (unsigned)(m * row_bytes) : SENT;
           __builtin_amdgcn_raw_buffer_store_b128(d, rso, (int)voff, 0, 0);
+        }
+        if constexpr (CR) {
+          // Store-data hazard (found on hardware, tools/probe/diag_cr3.py): under the register pressure of this epilogue hipcc
+          // reuses a store's data registers three instructions after the store (a y-row offset went into dword 0), and the
+          // 16-byte store reads its data in four lane phases AFTER issue -- lanes {12-15, 28-31, 44-47, 60-63} of ~5 % of the
+          // tiles then stored the new value.  hipcc's own rule (one wait state after a >= 12-byte store) does not cover it
+          // while the vector-memory path is busy; 16 wait states do (8 stores per tile: ~130 cycles of an ~8000-cycle tile).
+          __builtin_amdgcn_sched_barrier(0);
+#if defined(CR_PAD) && CR_PAD == 0
+#elif defined(CR_PAD) && CR_PAD == 2
+          asm volatile("s_nop 1" ::: "memory");
+#elif defined(CR_PAD) && CR_PAD == 4
+          asm volatile("s_nop 3" ::: "memory");
+#elif defined(CR_PAD) && CR_PAD == 8
+          asm volatile("s_nop 7" ::: "memory");
+#else
+          asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     };
@@ -381,6 +462,7 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
 bool conv64_eligible(int mode, int dtype, const ConvArgs& a) {
   if (mode != MODE_G3S1 || dtype != MIA_BF16) return false;
   if (a.nl_scale != nullptr && (a.o2 != 0 || a.nl_shift == nullptr || !(a.nl_slope >= 0.f && a.nl_slope <= 1.f))) return false;
+  if (a.cr_y != nullptr && (a.o2 != 0 || a.nl_scale != nullptr || a.stats == nullptr || !a.cr_scale || !a.cr_shift || !a.cr_xa || !a.cr_xb)) return false;
   if (a.c1 != C || a.c2 != 0 || a.o1 != C || (a.o2 != 0 && a.o2 != C) || a.npad != a.o1 + a.o2 || a.kpad != C) return false;
   if (!a.vec_in || !a.vec_out) return false;
   if ((size_t)a.Hin * a.Win * C * 2 >= ((size_t)1 << 31)) return false;
@@ -397,11 +479,15 @@ int conv64_launch(const ConvArgs& a, int blocks_override, int reserve, hipStream
   if (blocks_override >= 8 && blocks_override % 8 == 0 && blocks_override <= nblk) nblk = blocks_override;  // option conv64_blocks (diagnostics)
   const int run = nblk / 8;
   if (a.nl_scale != nullptr) {
-    hipLaunchKernelGGL(conv64_persist_kernel<true>, dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, 0);
+    hipLaunchKernelGGL((conv64_persist_kernel<true, false>), dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, 0);
     return MIA_OK;
   }
-  hipLaunchKernelGGL(conv64_persist_kernel<false>, dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, 0);
+  if (a.cr_y != nullptr) {
+    hipLaunchKernelGGL((conv64_persist_kernel<false, true>), dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, 0);
+    return MIA_OK;
+  }
+  hipLaunchKernelGGL((conv64_persist_kernel<false, false>), dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, 0);
   if (a.o2 == C)  // second destination (e.g. the up-sampled half of a decoder block's input gradient): same input, next 64 filters
-    hipLaunchKernelGGL(conv64_persist_kernel<false>, dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, C);
+    hipLaunchKernelGGL((conv64_persist_kernel<false, false>), dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, C);
   return MIA_OK;
 }

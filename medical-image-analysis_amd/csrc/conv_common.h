@@ -18,6 +18,12 @@ struct ConvArgs {
   // normalise-on-load (mia_conv_mma_nl): in1 is the RAW conv output y of the producing PlainBlock and the kernel forms
   // lrelu(nl_scale[n][c] * y + nl_shift[n][c]) while staging it; nullptr = in1 is an ordinary activation
   const float* nl_scale = nullptr; const float* nl_shift = nullptr; float nl_slope = 0.f;
+  // column-reduce epilogue (mia_conv_mma_cr): this launch is an INPUT GRADIENT whose output dz is the gradient w.r.t. the
+  // activated output of the PRODUCING PlainBlock; cr_y is that block's raw conv output (same geometry as out1) and the
+  // epilogue adds up, per tile, sum g and sum g*xhat with g = dz * lrelu'(scale*y + shift), xhat = xa*y + xb -- the
+  // reduction pass of that block's norm backward -- into `stats` ([N][tiles][o1][2])
+  const void* cr_y = nullptr; const float* cr_scale = nullptr; const float* cr_shift = nullptr;
+  const float* cr_xa = nullptr; const float* cr_xb = nullptr; float cr_slope = 0.f;
 };
 
 __device__ __forceinline__ int pi16(int r) {

@@ -309,7 +309,8 @@ extern "C" int mia_conv_mma_tiles(int mode, int hout, int wout, int* tiles_y, in
 static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void* in2, int c2, const void* wpack,
                         int npad, int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2,
                         int o2, float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream,
-                        const float* nl_scale, const float* nl_shift, float nl_slope) {
+                        const float* nl_scale, const float* nl_shift, float nl_slope, const void* cr_y = nullptr,
+                        const float* const* cr_coef = nullptr, float cr_slope = 0.f) {
   MIA_CHECK_ARG(mode >= 0 && mode <= MODE_G1, "mia_conv_mma: bad mode %d", mode);
   MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_conv_mma: bad dtype %d", dtype);
   MIA_CHECK_ARG(in1 && wpack && out1 && c1 > 0 && o1 > 0 && c2 >= 0 && o2 >= 0, "mia_conv_mma: null/empty operand");
@@ -335,6 +336,9 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
   a.N = n; a.Hin = hin; a.Win = win; a.Hout = hout; a.Wout = wout;
   a.npad = npad; a.kpad = kpad; a.flip = flip_taps;
   a.nl_scale = nl_scale; a.nl_shift = nl_shift; a.nl_slope = nl_slope;
+  if (cr_y != nullptr) {
+    a.cr_y = cr_y; a.cr_scale = cr_coef[0]; a.cr_shift = cr_coef[1]; a.cr_xa = cr_coef[2]; a.cr_xb = cr_coef[3]; a.cr_slope = cr_slope;
+  }
   int th;
   conv_tiles(opt, mode, hout, wout, &a.tiles_y, &a.tiles_x, &th);  // same snapshot as the launch below
   int mt = th / 4;
@@ -365,7 +369,14 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
     return MIA_EUNSUPPORTED;
   }
   // conv64_dma: 1 = the one-pass two-destination input gradient only (measured faster there), 2 = every 64 -> 64 launch
-  if (nl_scale != nullptr) {  // normalise-on-load: the register-staged 64-channel kernel is the one consumer that transforms
+  if (cr_y != nullptr) {  // column-reduce epilogue: the 64-channel register kernel (its epilogue overlaps the co-resident workgroup)
+    if (!(mt == 4 && conv64_eligible(mode, dtype, a))) {
+      mia_set_error("mia_conv_mma_cr: shape outside the column-reduce kernel's contract (ask mia_conv_cr_supported first)");
+      return MIA_EUNSUPPORTED;
+    }
+    rc = conv64_launch(a, opt.conv64_blocks, opt.reserve_cus, st);
+  }
+  else if (nl_scale != nullptr) {  // normalise-on-load: the register-staged 64-channel kernel is the one consumer that transforms
     if (!(mt == 4 && conv64_eligible(mode, dtype, a))) {
       mia_set_error("mia_conv_mma_nl: shape outside the normalise-on-load kernel's contract (ask mia_conv_nl_supported first)");
       return MIA_EUNSUPPORTED;
@@ -410,4 +421,25 @@ extern "C" int mia_conv_mma_nl(int mode, int dtype, const void* y_in, int c1, co
                 mode, dtype, c1, nout);
   return conv_mma_run(mode, dtype, y_in, c1, nullptr, 0, wpack, npad, kpad, 0, bias, out, nout, nullptr, 0, stat_partials, n, hin, win,
                       hout, wout, stream, in_scale, in_shift, slope);
+}
+
+// Input gradient with the producing block's norm-backward reduction in its epilogue: see include/mia_hip.h.
+extern "C" int mia_conv_cr_supported(int mode, int dtype, int c1, int nout, int hout, int wout) {
+  (void)wout;
+  return (mode == MODE_G3S1 && dtype == MIA_BF16 && c1 == 64 && nout == 64 && hout > 8) ? 1 : 0;
+}
+
+extern "C" int mia_conv_mma_cr(int mode, int dtype, const void* in1, int c1, const void* wpack, int npad, int kpad, int flip_taps,
+                               void* out, int nout, const void* y_prod, const float* scale, const float* shift, const float* xa,
+                               const float* xb, float slope, float* partials, int n, int hin, int win, int hout, int wout,
+                               void* stream) {
+  MIA_CHECK_ARG(y_prod && scale && shift && xa && xb && partials, "mia_conv_mma_cr: null pointer");
+  MIA_CHECK_ARG(mia_conv_cr_supported(mode, dtype, c1, nout, hout, wout), "mia_conv_mma_cr: unsupported shape (mode %d dtype %d %d -> %d)",
+                mode, dtype, c1, nout);
+  MIA_CHECK_ARG((reinterpret_cast<uintptr_t>(y_prod) & 15) == 0 && (reinterpret_cast<uintptr_t>(scale) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(shift) & 15) == 0 && (reinterpret_cast<uintptr_t>(xa) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(xb) & 15) == 0, "mia_conv_mma_cr: 16-byte aligned tensors / coefficient rows required");
+  const float* coef[4] = {scale, shift, xa, xb};
+  return conv_mma_run(mode, dtype, in1, c1, nullptr, 0, wpack, npad, kpad, flip_taps, nullptr, out, nout, nullptr, 0, partials, n, hin,
+                      win, hout, wout, stream, nullptr, nullptr, 0.f, y_prod, coef, slope);
 }

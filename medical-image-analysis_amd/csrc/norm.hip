@@ -781,6 +781,25 @@ extern "C" int mia_norm_bwd_sums(const void* dz, const void* dz2, const void* y,
   return MIA_OK;
 }
 
+// mia_norm_act_bwd whose reduction pass already ran somewhere else: `partials` [n][parts][c][2] were filled by the epilogue of the
+// input-gradient conv that produced dz (mia_conv_mma_cr).  Sums + finalize here; the apply pass only when dy != nullptr.
+extern "C" int mia_norm_act_bwd_pre(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
+                                    const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
+                                    int fixed_stats, float slope, int parts, const float* partials, float* c1, float* c2,
+                                    float* dgamma, float* dbeta, float* dbias, int accumulate, void* stream) {
+  MIA_CHECK_ARG(scale && shift && xa && xb && partials && c1 && c2 && dgamma && dbeta, "mia_norm_act_bwd_pre: null pointer");
+  MIA_CHECK_ARG(n > 0 && hw > 0 && c > 0 && parts > 0, "mia_norm_act_bwd_pre: bad shape");
+  MIA_CHECK_ARG(dy == nullptr || (dz && y), "mia_norm_act_bwd_pre: the apply pass needs dz and y");
+  if (dtype != MIA_BF16 && dtype != MIA_F32) { mia_set_error("mia_norm_act_bwd_pre: bad dtype"); return MIA_EARG; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3(n, ceil_div(c, 16)), dim3(256), 0, st, partials, parts, c, c1, c2);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, mode, fixed_stats, scale, xa,
+                     xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate, nullptr, nullptr, 0);
+  if (dy != nullptr) bwd_apply_launch(dz, nullptr, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
 // local batch totals tot[3][C] = (sum g, sum g*xhat, pixel count) over this rank's images, from the per-(n,c) sums in c1 / c2
 __global__ void bn_bwd_local_tot_kernel(int n_img, int c, int64_t hw, const float* __restrict__ c1, const float* __restrict__ c2,
                                         float* __restrict__ tot) {

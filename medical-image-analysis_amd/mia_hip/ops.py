@@ -217,9 +217,11 @@ def conv_tiles(mode: int, hout: int, wout: int) -> int:
 
 def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: torch.Tensor, npad: int, kpad: int,
              flip: bool, bias: Optional[torch.Tensor], nout: int, out_hw: Tuple[int, int], want_stats: bool = False,
-             out_split: Optional[int] = None, nl=None):
+             out_split: Optional[int] = None, nl=None, cr=None):
     """nl = (coefs [5, N, C] of the producing block, slope): x1 is that block's RAW conv output and the kernel normalises on
-    load (`mia_conv_mma_nl`; the fused PlainBlock)."""
+    load (`mia_conv_mma_nl`; the fused PlainBlock).  cr = (y_prod, coefs, slope): this launch is the input gradient that
+    produces dz for the block with raw output `y_prod`, and its epilogue does that block's norm-backward reduction
+    (`mia_conv_mma_cr`); the third return value is then the partials tensor [N, tiles, nout, 2]."""
     n, hin, win, c1 = x1.shape
     c2 = 0 if x2 is None else x2.shape[3]
     hout, wout = out_hw
@@ -231,14 +233,19 @@ def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: tor
         out1 = torch.empty((n, hout, wout, o1), device=x1.device, dtype=x1.dtype)
         out2 = torch.empty((n, hout, wout, o2), device=x1.device, dtype=x1.dtype)
     stats = None
-    if want_stats:
+    if want_stats or cr is not None:
         stats = torch.empty((n, conv_tiles(mode, hout, wout), nout, 2), device=x1.device, dtype=torch.float32)
     tag = PROBE.match(mode, c1, c2, nout, hin, win, bool(flip)) if (PROBE is not None and PROBE.enabled) else None
     probe = PROBE if tag else None
     if probe is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if nl is not None:
+    if cr is not None:
+        assert x2 is None and out_split is None and nl is None and bias is None
+        yp, cf, sl = cr
+        call("mia_conv_mma_cr", mode, _dt(x1), _p(x1), c1, _p(wpack), npad, kpad, int(flip), _p(out1), o1, _p(yp), _p(cf[2]), _p(cf[3]),
+             _p(cf[0]), _p(cf[1]), _c_float(sl), _p(stats), n, hin, win, hout, wout, _stream())
+    elif nl is not None:
         assert x2 is None and out_split is None and not flip
         call("mia_conv_mma_nl", mode, _dt(x1), _p(x1), c1, _p(nl[0][2]), _p(nl[0][3]), _c_float(nl[1]), _p(wpack), npad, kpad,
              _p(bias), _p(out1), o1, _p(stats), n, hin, win, hout, wout, _stream())
@@ -354,6 +361,27 @@ def _take_colsum(t: torch.Tensor) -> Optional[torch.Tensor]:
     if hit is not None and hit[0] == tuple(t.shape) and hit[1] == t._version:
         return hit[2]
     return None
+
+
+# Norm-backward partial sums computed by the epilogue of the input-gradient conv that produced a dz tensor (mia_conv_mma_cr):
+# keyed by that tensor's storage address; the producing block's backward takes them and skips its own reduction pass.
+_CR_HINT = {}
+FUSE_CR = __import__('os').environ.get('MIA_FUSE_CR', '0') != '0'  # A/B knob; OFF by default: measured +-0 on the cfg3 step (DESIGN, round 4)
+
+
+def _hint_cr(dz: torch.Tensor, partials: torch.Tensor) -> None:
+    if len(_CR_HINT) > 64:
+        _CR_HINT.clear()
+    _CR_HINT[dz.data_ptr()] = (partials, tuple(dz.shape))
+
+
+def _take_cr(dz: torch.Tensor) -> Optional[torch.Tensor]:
+    h = _CR_HINT.pop(dz.data_ptr(), None)
+    return h[0] if (h is not None and h[1] == tuple(dz.shape)) else None
+
+
+def cr_supported(dtype, cin: int, cout: int, h: int, w: int) -> bool:
+    return FUSE_CR and dtype == torch.bfloat16 and bool(lib().mia_conv_cr_supported(CONV_G3S1, BF16, cout, cin, h, w))
 
 
 _COL_SLABS = int(__import__('os').environ.get('MIA_COL_SLABS', '64'))
@@ -602,11 +630,17 @@ class PlainBlockFn(torch.autograd.Function):
         dgamma = dgb[0] if dgamma is None else dgamma
         dbeta = dgb[1] if dbeta is None else dbeta
         dbias = dgb[2] if dbias is None else dbias
+        pre = _take_cr(dz) if (dz2 is None and ctx.sync is None) else None  # reduction already done by the conv that produced dz
         if ctx.stem and ctx.sync is None and FUSE_STEM_BWD:
             # the stem has no input gradient: its weight gradient is the only consumer of dy and forms it on load -- no apply pass
-            call("mia_norm_bwd_sums", _p(dz), _p(dz2), _p(y), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
-                 _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs,
-                 _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
+            if pre is not None:
+                call("mia_norm_act_bwd_pre", None, None, None, dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
+                     _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope),
+                     pre.shape[1], _p(pre), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
+            else:
+                call("mia_norm_bwd_sums", _p(dz), _p(dz2), _p(y), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
+                     _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs,
+                     _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
             if dz2 is not None:
                 dz = dz + dz2
             ws = torch.empty(lib().mia_stem_wgrad_workspace(cout), device=dev, dtype=torch.float32)
@@ -617,7 +651,11 @@ class PlainBlockFn(torch.autograd.Function):
                  _p(cc[0]), _p(cc[1]), _c_float(ctx.slope), _p(ws), _p(dw), n, ho, wo, cout, 0, _stream())
             return (None, None, dw, dbias, dgamma, dbeta) + (None,) * 8
         dy = torch.empty_like(y)
-        if ctx.sync is None:
+        if pre is not None:
+            call("mia_norm_act_bwd_pre", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
+                 _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope),
+                 pre.shape[1], _p(pre), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
+        elif ctx.sync is None:
             call("mia_norm_act_bwd", _p(dz), _p(dz2), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
                  _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs,
                  _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
@@ -652,6 +690,12 @@ class PlainBlockFn(torch.autograd.Function):
                 # decoder block behind a ConvTranspose2d: dx2 is that layer's output gradient and its per-channel sum is
                 # the transposed conv's bias gradient -- the epilogue statistics deliver it without another pass over dx2
                 want = x2 is not None and ctx.needs_input_grad[1]
+                if nl_coefs is not None and cr_supported(y.dtype, cin, cout, ho, wo):
+                    # x1 is the previous block's raw output: its norm-backward reduction rides in this conv's epilogue
+                    dx1, _, partials = conv_mma(CONV_G3S1, dy, None, wb, npad, kpad, True, None, cin, (ho, wo),
+                                                cr=(x1, nl_coefs, ctx.nl_slope))
+                    _hint_cr(dx1, partials)
+                    return (dx1, None, dw, dbias, dgamma, dbeta) + (None,) * 8
                 dx1, dx2, st = conv_mma(CONV_G3S1, dy, None, wb, npad, kpad, True, None, cin, (ho, wo), want_stats=want,
                                         out_split=split)
                 if want:
@@ -745,7 +789,11 @@ class PlainBlockHeadFn(torch.autograd.Function):
         dx1 = None
         if ctx.needs_input_grad[0]:
             wb, npad, kpad = pack_cache(weight).get(weight, dtype, n_from_d0=False)
-            dx1, _, _ = conv_mma(CONV_G3S1, dy, None, wb, npad, kpad, True, None, cin, (h, w))
+            if nl_coefs is not None and cr_supported(y.dtype, cin, cout, h, w):
+                dx1, _, partials = conv_mma(CONV_G3S1, dy, None, wb, npad, kpad, True, None, cin, (h, w), cr=(x1, nl_coefs, ctx.nl_slope))
+                _hint_cr(dx1, partials)
+            else:
+                dx1, _, _ = conv_mma(CONV_G3S1, dy, None, wb, npad, kpad, True, None, cin, (h, w))
         return dx1, dw, dbias, dgamma, dbeta, None, dwh.reshape(head_w.shape), dbh, None, None, None
 
 

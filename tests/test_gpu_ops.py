@@ -1029,7 +1029,8 @@ def test_fused_level_pairs_match_unfused_model(norm, drop):
     lab = torch.randint(0, 3, (3, 48, 80), generator=g).to(dev)
     loss_fn = DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss)
     res = {}
-    old = ops.FUSE_NL
+    old, old_cr = ops.FUSE_NL, ops.FUSE_CR
+    ops.FUSE_CR = False  # (the backward reduction fused into the input-gradient epilogue has its own test; it is not bit-identical)
     try:
         for fuse in (False, True):
             ops.FUSE_NL = fuse
@@ -1054,7 +1055,7 @@ def test_fused_level_pairs_match_unfused_model(norm, drop):
                 feat = m.get_pixel_feature(x)[1].clone()
             res[fuse] = (out.detach().clone(), loss.item(), grads, ev, feat)
     finally:
-        ops.FUSE_NL = old
+        ops.FUSE_NL, ops.FUSE_CR = old, old_cr
     a, b = res[False], res[True]
     assert torch.equal(a[0], b[0]) and a[1] == b[1]
     assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
@@ -1164,3 +1165,99 @@ def test_stem_backward_fused_into_weight_gradient(norm, c0, hw, dtype):
         assert relerr(pb.all[0].weight.grad, blk[0].weight.grad) < 2e-4
         assert relerr(pb.all[2].weight.grad, blk[1].weight.grad) < 2e-4
         assert relerr(pb.all[2].bias.grad, blk[1].bias.grad) < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 37, 53), (1, 16, 16), (3, 64, 48), (5, 33, 17), (32, 128, 128), (2, 512, 384)])
+def test_conv_input_gradient_with_column_reduce_epilogue(case):
+    """`mia_conv_mma_cr`: the input-gradient conv of the consuming block with the producing block's norm-backward reduction in
+    its epilogue.  dz bit-identical to `mia_conv_mma`; the per-tile partial sums, added up, equal sum g and sum g * xhat
+    (g = dz * lrelu'(scale * y + shift)) computed in fp64 from the stored bf16 dz -- ragged tiles, several images, and more tiles
+    than workgroups (the persistent walk with the next tile's prefetch live across the epilogue) included;
+    `mia_norm_act_bwd_pre` on them gives the dy / dgamma / dbeta of `mia_norm_act_bwd` within fp32 summation order."""
+    import mia_hip
+    from mia_hip import CONV_G3S1, NORM_INSTANCE, call, ops
+    from mia_hip.ops import _c_float, _c_i64, _p, _stream
+    dev = _dev()
+    n, h, w = case
+    c = 64
+    g = torch.Generator().manual_seed(7 * n + h)
+    dyb = torch.randn(n, h, w, c, generator=g).to(dev, torch.bfloat16)
+    y = (torch.randn(n, h, w, c, generator=g) * 1.5).to(dev, torch.bfloat16)
+    coefs = torch.zeros(5, n, c)
+    coefs[0] = torch.rand(n, c, generator=g) + 0.5     # xa
+    coefs[1] = torch.randn(n, c, generator=g) * 0.3    # xb
+    coefs[2] = torch.randn(n, c, generator=g)          # scale
+    coefs[3] = torch.randn(n, c, generator=g) * 0.7    # shift
+    coefs = coefs.to(dev)
+    wt = (torch.randn(c, c, 3, 3, generator=g) / 24).to(dev)
+    pc = ops.PackCache()
+    wb, npad, kpad = pc.get(wt, mia_hip.BF16, False)
+    ref, _, _ = ops.conv_mma(CONV_G3S1, dyb, None, wb, npad, kpad, True, None, c, (h, w))
+    got, _, part = ops.conv_mma(CONV_G3S1, dyb, None, wb, npad, kpad, True, None, c, (h, w), cr=(y, coefs, 0.01))
+    assert torch.equal(got, ref)
+    dz, yf = got.double().cpu(), y.double().cpu()
+    cf = coefs.double().cpu()
+    u = cf[2][:, None, None, :] * yf + cf[3][:, None, None, :]
+    gg = torch.where(u > 0, dz, dz * 0.01)
+    xhat = cf[0][:, None, None, :] * yf + cf[1][:, None, None, :]
+    want1, want2 = gg.sum((1, 2)), (gg * xhat).sum((1, 2))
+    p = part.double().cpu().sum(1)
+    scale_ref = max(float(want1.abs().max()), float(want2.abs().max()))
+    assert float((p[..., 0] - want1).abs().max()) < 2e-5 * scale_ref + 1e-3
+    assert float((p[..., 1] - want2).abs().max()) < 2e-5 * scale_ref + 1e-3
+    # the block's norm backward from the partials vs its own reduction pass
+    gam = torch.ones(c, device=dev)
+    outs = []
+    for use_pre in (False, True):
+        dy = torch.empty_like(y)
+        cc = torch.empty(2, n, c, device=dev)
+        dgb = torch.empty(3, c, device=dev)
+        slabs = max(1, min(64, h * w // 1024))
+        pt = torch.empty(n, slabs, c, 2, device=dev)
+        if use_pre:
+            call("mia_norm_act_bwd_pre", _p(got), _p(y), _p(dy), mia_hip.BF16, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
+                 _p(coefs[4]), n, _c_i64(h * w), c, NORM_INSTANCE, 0, _c_float(0.01), part.shape[1], _p(part), _p(cc[0]), _p(cc[1]),
+                 _p(dgb[0]), _p(dgb[1]), _p(dgb[2]), 0, _stream())
+        else:
+            call("mia_norm_act_bwd", _p(got), None, _p(y), _p(dy), mia_hip.BF16, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
+                 _p(coefs[4]), n, _c_i64(h * w), c, NORM_INSTANCE, 0, _c_float(0.01), slabs, _p(pt), _p(cc[0]), _p(cc[1]),
+                 _p(dgb[0]), _p(dgb[1]), _p(dgb[2]), 0, _stream())
+        outs.append((dy.float().cpu(), dgb[:2].cpu().clone(), cc.cpu().clone()))
+    assert relerr(outs[1][2], outs[0][2]) < 1e-5       # c1, c2
+    assert relerr(outs[1][1], outs[0][1]) < 1e-5       # dgamma, dbeta
+    assert relerr(outs[1][0], outs[0][0]) < 8e-3       # dy (bf16: a handful of values may round the other way)
+
+
+@pytest.mark.gpu
+def test_fused_backward_reduction_matches_unfused_model():
+    """Model level: ops.FUSE_CR on / off on a bf16 UNet with 64-channel level-0 blocks -- logits identical, every parameter
+    gradient within the bf16 rounding band of the unfused path (the reduction partials are summed in a different order, which
+    can move single dy values by one bf16 ulp)."""
+    from losses.compound_losses import DiceAndCELoss
+    from mia_hip import ops
+    from models.unet import UNet
+    dev = _dev()
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(3, 1, 80, 112, generator=g).to(dev)
+    lab = torch.randint(0, 3, (3, 80, 112), generator=g).to(dev)
+    loss_fn = DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss)
+    res = {}
+    old = ops.FUSE_CR
+    try:
+        for fuse in (False, True):
+            ops.FUSE_CR = fuse
+            ops._CR_HINT.clear()
+            torch.manual_seed(11)
+            m = UNet(2, 1, 3, [64, 128], normalization="instance", dropout_prob=None).to(dev)
+            m.set_compute_dtype(torch.bfloat16)
+            m.train()
+            out = m(x)
+            loss_fn(out, lab).backward()
+            res[fuse] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+            assert not ops._CR_HINT  # every hint was consumed
+    finally:
+        ops.FUSE_CR = old
+    assert torch.equal(res[False][0], res[True][0])
+    for k, gk in res[True][1].items():
+        assert relerr(gk, res[False][1][k]) < 2e-2, k
