@@ -364,6 +364,13 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
     a.tiles_y = ceil_div(hout, 16);
     a.nblk_n = nout / 128;
   }
+  // the same 512-thread shape for the strided conv's INPUT GRADIENT (transposed mode, four output-parity classes per tile):
+  // a 128-channel block shares one staged dy tile (option conv_t3_wide; measured per level in tools/s2_levels.py)
+  bool t3_wide = false;
+  if (opt.conv_t3_wide && fast && mode == MODE_T3S2 && dtype == MIA_BF16 && nout % 128 == 0 && a.o2 == 0 && mt == 4) {
+    t3_wide = true;
+    a.nblk_n = nout / 128;
+  }
   if (mt == 8 && !(fast && dtype == MIA_BF16 && nt == 4 && mode == MODE_G3S1)) {
     mia_set_error("mia_conv_mma: MIA_CONV_MT8 tiles need the bf16 fast path with >= 64 output channels");
     return MIA_EUNSUPPORTED;
@@ -391,7 +398,7 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
   // conv_pw_s2 = 1 stops at 256 input channels, = 2 always)
   else if (opt.conv_pw && (mode != MODE_G3S2 || opt.conv_pw_s2 >= 2 || (opt.conv_pw_s2 == 1 && c1 <= 256)) && conv_pw_eligible(mode, dtype, a))
     rc = conv_pw_launch(mode, a, opt.reserve_cus, st);
-  else if (fast) rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
+  else if (fast) rc = conv_mma_fast_launch(mode, dtype, a, t3_wide ? 16 : mt, nt, grid_y, st);
   else rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);
   if (rc != MIA_OK) return rc;
   MIA_LAUNCH_CHECK();

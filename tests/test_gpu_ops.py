@@ -1261,3 +1261,33 @@ def test_fused_backward_reduction_matches_unfused_model():
     assert torch.equal(res[False][0], res[True][0])
     for k, gk in res[True][1].items():
         assert relerr(gk, res[False][1][k]) < 2e-2, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 256, 128, 24, 40), (1, 512, 256, 17, 23), (3, 256, 128, 9, 8), (1, 1024, 512, 16, 16)])
+def test_conv_t3_wide_matches_tile_kernel(case):
+    """Option conv_t3_wide: the stride-2 3x3 conv's input gradient (transposed mode) on 512-thread workgroups with 128-channel
+    blocks -- bit-identical to the 256-thread tile kernel (same per-element summation order), odd fine sizes included."""
+    import mia_hip
+    from mia_hip import CONV_T3S2, ops
+    dev = _dev()
+    n, cout, cin, hc, wc = case          # dy: [n, hc, wc, cout] -> dx: [n, 2hc(-1), 2wc(-1), cin]
+    g = torch.Generator().manual_seed(cout + hc)
+    dy = torch.randn(n, hc, wc, cout, generator=g).to(dev, torch.bfloat16)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / 30).to(dev)
+    pc = ops.PackCache()
+    wb, npad, kpad = pc.get(wt, mia_hip.BF16, False)
+    old = mia_hip.get_option("conv_t3_wide")
+    try:
+        for fine in ((2 * hc, 2 * wc), (2 * hc - 1, 2 * wc - 1)):
+            outs = []
+            for v in (0, 1):
+                mia_hip.set_option("conv_t3_wide", v)
+                o, _, _ = ops.conv_mma(CONV_T3S2, dy, None, wb, npad, kpad, False, None, cin, fine)
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1]), fine
+            want = F.conv_transpose2d(dy.float().cpu().permute(0, 3, 1, 2), wt.cpu().to(torch.bfloat16).float(), stride=2, padding=1,
+                                      output_padding=(fine[0] - (2 * hc - 1), fine[1] - (2 * wc - 1)))
+            assert relerr(nchw(outs[1]), want) < 1e-2
+    finally:
+        mia_hip.set_option("conv_t3_wide", old)
