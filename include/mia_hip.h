@@ -92,6 +92,8 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
  *   stem_mfma (MIA_STEM_MFMA, 1)   matrix-core stem kernel for fp32 images
  *   conv_t3_wide (MIA_CONV_T3_WIDE, 0)   input gradient of the stride-2 3x3 conv (bf16, output channels % 128 == 0) on 512-thread
  *                                  workgroups with 128-channel blocks (the conv_s2_wide shape); bit-identical results
+ *   wgrad_narrow (MIA_WGRAD_NARROW, 0)   3x3 stride-1 bf16 weight gradient with channel counts that are not multiples of 64: blocks
+ *                                  with <= 32 valid channels skip their empty 16-channel tiles and re-deal the waves (same sums)
  *   reserve_cus (MIA_RESERVE_CUS, 0)   CUs the persistent kernels leave free (0..64, rounded so that the grids stay
  *                                  multiples of 8): the grids of conv_bt / conv_pw / conv64 / conv64_dma shrink to CUs - k
  *                                  workgroups (same work items: bit-identical results) and mia_wgrad_target_blocks follows

@@ -654,6 +654,10 @@ __device__ __forceinline__ void lds_dma16(wi32x4 rsrc, unsigned voff, unsigned l
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" : : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory", "m0");
 }
 
+// NARROW = the launch has blocks with fewer than 64 valid channels (c or cdy not a multiple of 64: cfg5's 96-channel level): those
+// blocks skip their empty 16-channel tiles and re-deal the waves (below); full blocks of such a launch run their four n tiles as two
+// passes of two over the staged tile.  NARROW = false is the unchanged round-2 body.
+template <bool NARROW>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) {
   constexpr int KS = 3, TAPS = 9, TH = 4;
   constexpr int XH = TH + 2, XROW = 3072;  // 24 pixels x 128 B per image row of the x tile
@@ -691,6 +695,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) 
   const bool xok0 = kloc + ch8_0 * 8 < cs, xok1 = kloc + ch8_1 * 8 < cs;
   const bool dok0 = n0 + ch8_0 * 8 < a.cdy, dok1 = n0 + ch8_1 * 8 < a.cdy;
   const unsigned lds0 = (unsigned)(size_t)(lds_u8*)smem;
+
+  // Narrow blocks (round 4; cfg5's 96-channel level: 96 = 64 + 32 in both dimensions): a block with <= 32 valid input channels
+  // has only two 16-channel k tiles, so instead of leaving waves 2, 3 idle the four waves are (k tile = wave & 1) x (half of the
+  // n tiles = wave >> 1); a block with <= 32 valid output channels simply skips its empty n tiles.  Uniform per workgroup:
+  // this wave computes k tile `ktile` against the n tiles cbeg .. cbeg + ccnt - 1 (ccnt in 0..4).
+  const int ntl = ((a.cdy - n0 < 64 ? a.cdy - n0 : 64) + 15) >> 4, ktl = ((cs - kloc < 64 ? cs - kloc : 64) + 15) >> 4;
+  int ktile = wave, cbeg = 0, ccnt = 4;
+  if constexpr (NARROW) {
+    if (ktl > 2) { ktile = wave; cbeg = 0; ccnt = ntl; }
+    else if (ntl > 2) { ktile = wave & 1; cbeg = 2 * (wave >> 1); ccnt = ntl - cbeg < 2 ? ntl - cbeg : 2; }
+    else { ktile = wave & 1; cbeg = wave >> 1; ccnt = cbeg < ntl ? 1 : 0; }
+    if (ktile >= ktl) ccnt = 0;
+    if (ccnt < 0) ccnt = 0;
+  }
 
   auto issue = [&](int img, int ty, int tx, unsigned stage_base) {
     const int oy0 = ty * TH, ox0 = tx * 16;
@@ -774,16 +792,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) 
 
   // lane-constant fragment bases (absolute LDS bytes of the CURRENT stage; stepped by one stage per tile)
   const int g1 = grp >> 1, xb0 = 8 * (grp & 1) + qp, sub = 8 * (pp & 1);
-  unsigned dbase[2][2], xbase[KS][2];
+  unsigned dbase[4][2], xbase[KS][2];  // dbase[c]: LOCAL n tile c of this wave = n tile (cbeg + c) & 3 of the block
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {  // channel tiles c and c + 2 differ by +512 bytes
-    dbase[c][0] = lds0 + X_BYTES + swz_off(g1 * 16 + xb0, 2 * c + (pp >> 1)) + sub;
-    dbase[c][1] = lds0 + X_BYTES + swz_off(g1 * 16 + xb0 + 4, 2 * c + (pp >> 1)) + sub;
+  for (int c = 0; c < 4; ++c) {
+    const int cg = (cbeg + c) & 3;
+    dbase[c][0] = lds0 + X_BYTES + swz_off(g1 * 16 + xb0, 2 * cg + (pp >> 1)) + sub;
+    dbase[c][1] = lds0 + X_BYTES + swz_off(g1 * 16 + xb0 + 4, 2 * cg + (pp >> 1)) + sub;
   }
 #pragma unroll
   for (int kw = 0; kw < KS; ++kw) {
-    xbase[kw][0] = lds0 + g1 * XROW + swz_off(xb0 + kw, 2 * wave + (pp >> 1)) + sub;
-    xbase[kw][1] = lds0 + g1 * XROW + swz_off(xb0 + kw + 4, 2 * wave + (pp >> 1)) + sub;
+    xbase[kw][0] = lds0 + g1 * XROW + swz_off(xb0 + kw, 2 * ktile + (pp >> 1)) + sub;
+    xbase[kw][1] = lds0 + g1 * XROW + swz_off(xb0 + kw + 4, 2 * ktile + (pp >> 1)) + sub;
   }
 
   const int ntiles = a.N * a.tiles_x * a.tiles_y;
@@ -823,39 +842,50 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) 
     issue_stage = issue_stage == NSTAGE - 1 ? 0 : issue_stage + 1;
 
     WSTAMP(w1);
-    u32x4 af[2][4], bf[3];
-    auto load_a = [&](int kb, int c) -> u32x4 {
-      const s16x4 lo = tr_read_at(dbase[c & 1][0] + 512 * (c >> 1) + 4096 * kb);
-      const s16x4 hi = tr_read_at(dbase[c & 1][1] + 512 * (c >> 1) + 4096 * kb);
-      return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    auto mma_tile = [&](auto cc_tag, auto c0_tag) __attribute__((always_inline)) {
+      constexpr int CC = decltype(cc_tag)::value, C0 = decltype(c0_tag)::value;  // local n tiles C0 .. C0 + CC - 1 of this wave
+      u32x4 af[2][CC], bf[3];
+      auto load_a = [&](int kb, int c) -> u32x4 {
+        const s16x4 lo = tr_read_at(dbase[C0 + c][0] + 4096 * kb);
+        const s16x4 hi = tr_read_at(dbase[C0 + c][1] + 4096 * kb);
+        return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      };
+      auto load_b = [&](int step) -> u32x4 {  // step = kb * 9 + tap
+        const int kb = step / TAPS, t = step % TAPS, kh = t / KS, kw = t % KS;
+        const s16x4 lo = tr_read_at(xbase[kw][0] + XROW * (2 * kb + kh));
+        const s16x4 hi = tr_read_at(xbase[kw][1] + XROW * (2 * kb + kh));
+        return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      };
+#pragma unroll
+      for (int c = 0; c < CC; ++c) af[0][c] = load_a(0, c);
+      bf[0] = load_b(0);
+      bf[1] = load_b(1);
+#pragma unroll
+      for (int step = 0; step < 2 * TAPS; ++step) {
+        const int kb = step / TAPS, t = step % TAPS;
+        if (step + 2 < 2 * TAPS) bf[(step + 2) % 3] = load_b(step + 2);
+        if (kb == 0 && t >= 5 && t - 5 < CC) af[1][t - 5] = load_a(1, t - 5);  // second row block's dy fragments behind the first's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+          acc[t][C0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kb][c]), __builtin_bit_cast(bf16x8, bf[step % 3]),
+                                                                   acc[t][C0 + c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     };
-    auto load_b = [&](int step) -> u32x4 {  // step = kb * 9 + tap
-      const int kb = step / TAPS, t = step % TAPS, kh = t / KS, kw = t % KS;
-      const s16x4 lo = tr_read_at(xbase[kw][0] + XROW * (2 * kb + kh));
-      const s16x4 hi = tr_read_at(xbase[kw][1] + XROW * (2 * kb + kh));
-      return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-    };
-#pragma unroll
-    for (int c = 0; c < 4; ++c) af[0][c] = load_a(0, c);
-    bf[0] = load_b(0);
-    bf[1] = load_b(1);
-#pragma unroll
-    for (int step = 0; step < 2 * TAPS; ++step) {
-      const int kb = step / TAPS, t = step % TAPS;
-      if (step + 2 < 2 * TAPS) bf[(step + 2) % 3] = load_b(step + 2);
-      if (kb == 0 && t >= 5 && t <= 8) af[1][t - 5] = load_a(1, t - 5);  // second row block's dy fragments behind the first's MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kb][c]), __builtin_bit_cast(bf16x8, bf[step % 3]),
-                                                            acc[t][c], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+    if constexpr (!NARROW) {
+      mma_tile(I4{}, I0{});
+    } else {
+      if (ccnt >= 2) mma_tile(I2{}, I0{}); else if (ccnt == 1) mma_tile(I1{}, I0{});
+      if (ccnt >= 4) mma_tile(I2{}, I2{}); else if (ccnt == 3) mma_tile(I1{}, I2{});
     }
     // next stage's fragment bases
     const int delta = stage == NSTAGE - 1 ? -(NSTAGE - 1) * STAGE : STAGE;
     stage = stage == NSTAGE - 1 ? 0 : stage + 1;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) { dbase[c][0] += delta; dbase[c][1] += delta; }
+    for (int c = 0; c < 4; ++c) { dbase[c][0] += delta; dbase[c][1] += delta; }
 #pragma unroll
     for (int kw = 0; kw < KS; ++kw) { xbase[kw][0] += delta; xbase[kw][1] += delta; }
     WSTAMP(w2);
@@ -883,9 +913,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) 
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + c * 16 + 4 * grp + r, k = k0 + wave * 16 + i16;
-        if (kloc + wave * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+        const int n = n0 + (cbeg + c) * 16 + 4 * grp + r, k = k0 + ktile * 16 + i16;
+        if (c < ccnt && kloc + ktile * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
       }
+  // (slab entries this block does not compute -- padded n / k tiles -- are never read: mia_wgrad_reduce sums n < nn, k < kk only)
 }
 
 // ---------------------------------------------------------------- bf16, 512-thread big block (stride-1 3x3, cdy % 128 == 0)
@@ -1865,7 +1896,7 @@ extern "C" int mia_wgrad_target_blocks(int mode, int dtype) {
 extern "C" int mia_wgrad_debug_occupancy(int which) {
   int n = -1;
   hipError_t e = hipErrorInvalidValue;
-  if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_bf16_dma_kernel, 256, 0);
+  if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_bf16_dma_kernel<false>, 256, 0);
   else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_bf16_bt_kernel, 512, 0);
   else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_bf16_bt_s2_kernel, 512, 0);
   else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_bf16_2wg_kernel<8>, 256, 0);
@@ -1939,7 +1970,12 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
     dim3 bgrid(fgrid.x / 2, fgrid.y);
     hipLaunchKernelGGL(wgrad_bf16_bt_t2_kernel, bgrid, dim3(512), 0, st, a);
   } else if (fast && th == 4 && mode == MODE_W3S1) {
-    hipLaunchKernelGGL(wgrad_bf16_dma_kernel, fgrid, dim3(256), 0, st, a);
+    {
+      // narrow blocks (channels not a multiple of 64 on either side): the kernel that skips empty 16-channel tiles
+      const bool narrow = o.wgrad_narrow && ((c1 % 64 != 0) || (c2 % 64 != 0) || (cdy % 64 != 0));
+      if (narrow) hipLaunchKernelGGL(wgrad_bf16_dma_kernel<true>, fgrid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(wgrad_bf16_dma_kernel<false>, fgrid, dim3(256), 0, st, a);
+    }
   } else if (fast && wgrad_two_wg(o, mode, dtype)) {  // stride-2 / transposed shapes stay on the one-workgroup-per-CU kernel
     hipLaunchKernelGGL(wgrad_bf16_2wg_kernel<8>, fgrid, dim3(256), 0, st, a);
   } else if (fast) {

@@ -1291,3 +1291,33 @@ def test_conv_t3_wide_matches_tile_kernel(case):
             assert relerr(nchw(outs[1]), want) < 1e-2
     finally:
         mia_hip.set_option("conv_t3_wide", old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 96, 0, 96, 40, 56), (1, 192, 0, 96, 24, 40), (1, 96, 96, 192, 17, 33), (2, 48, 0, 80, 20, 36),
+                                  (1, 32, 0, 32, 64, 64), (1, 160, 0, 224, 16, 48)])
+def test_wgrad_narrow_blocks_match_full_blocks(case):
+    """Option wgrad_narrow (cfg5's 96-channel level): the LDS-DMA weight gradient skips the empty 16-channel tiles of blocks with fewer
+    than 64 valid channels and re-deals the waves -- every computed entry is the same sum in the same order, so the gradient is
+    BIT-IDENTICAL to the full-block kernel, and it matches fp32-CPU math on the same bf16 operands."""
+    import mia_hip
+    from mia_hip import WGRAD_3S1, ops
+    dev = _dev()
+    n, c1, c2, cout, h, w = case
+    g = torch.Generator().manual_seed(c1 + cout + h)
+    x1 = torch.randn(n, h, w, c1, generator=g).to(dev, torch.bfloat16)
+    x2 = torch.randn(n, h, w, c2, generator=g).to(dev, torch.bfloat16) if c2 else None
+    dy = torch.randn(n, h, w, cout, generator=g).to(dev, torch.bfloat16)
+    shape = (cout, c1 + c2, 3, 3)
+    old = mia_hip.get_option("wgrad_narrow")
+    try:
+        outs = []
+        for v in (0, 1):
+            mia_hip.set_option("wgrad_narrow", v)
+            outs.append(ops.conv_wgrad(WGRAD_3S1, x1, x2, dy, shape, cout, c1 + c2))
+    finally:
+        mia_hip.set_option("wgrad_narrow", old)
+    assert torch.equal(outs[0], outs[1])
+    xc = torch.cat([t.float().cpu().permute(0, 3, 1, 2) for t in (x1, x2) if t is not None], 1)
+    want = torch.nn.grad.conv2d_weight(xc, shape, dy.float().cpu().permute(0, 3, 1, 2), padding=1)
+    assert relerr(outs[1], want) < 2e-4
