@@ -122,6 +122,15 @@ class FlatOptimizer:
             ops.release_grad_dest(p)
 
     def step(self, max_grad_norm: float = 0.0, grad_scale: float = 1.0):
+        """Clip-by-global-norm + Adam / AdamW / SGD over the flat buffers (al_trainer.py:1376-1379, :744-761).
+
+        LIMITATION (documented): ONE step counter serves every parameter's Adam bias correction
+        (`1 - beta^t`).  torch.optim keeps a counter per parameter, so a parameter that receives its FIRST gradient late -- one
+        that was skipped (`.grad is None`) for its first k steps, e.g. a deep-supervision head switched on mid-run -- is
+        bias-corrected here as if it were k steps old: its first updates are up to 1 / (1 - beta1^1) : 1 / (1 - beta1^(k+1))
+        smaller than torch's.  `al_train` never does this (every parameter it owns gets a gradient from step 1; parameters that
+        NEVER get one are never updated, as in torch), and `checkpoint.py` writes the shared counter into every per-parameter
+        `step` entry of the torch-format optimizer state."""
         g = self.param_groups[0]
         self.step_count += 1
         clip = None
