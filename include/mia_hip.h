@@ -136,6 +136,14 @@ int mia_conv_mma_nl(int mode, int dtype, const void* y_in, int c1, const float* 
  * the bf16-rounded dz it stores, and writes partials [N][tiles][nout][2] (tiles as mia_conv_mma_tiles) -- the input of
  * mia_norm_act_bwd_pre, which then skips its own reduction pass over dz and y (blocks.py:98-102 backward).  3x3 stride 1, bf16,
  * 64 -> 64 channels (mia_conv_cr_supported). */
+/* mia_conv_mma with out += result (no bias, one source, one destination; the tile kernel: returns MIA_EUNSUPPORTED outside its
+ * contract).  Use: a skip tensor has two consumers (unet.py:213 and the next encoder level), so its gradient arrives in two pieces;
+ * the piece computed second -- the stride-2 conv's input gradient, mode CONV_T3S2 -- is added into the first in this launch's
+ * epilogue (read-modify-write), and the skip block's norm backward reads one gradient tensor instead of two. */
+int mia_conv_acc_supported(int mode, int dtype, int c1, int nout);
+int mia_conv_mma_acc(int mode, int dtype, const void* in1, int c1, const void* wpack, int npad, int kpad, int flip_taps,
+                     void* out_inout, int nout, int n, int hin, int win, int hout, int wout, void* stream);
+
 int mia_conv_cr_supported(int mode, int dtype, int c1, int nout, int hout, int wout);
 int mia_conv_mma_cr(int mode, int dtype, const void* in1, int c1, const void* wpack, int npad, int kpad, int flip_taps,
                     void* out, int nout, const void* y_prod, const float* scale, const float* shift, const float* xa,

@@ -319,11 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
 #pragma unroll
       for (int mm = m0; mm < m0 + YB; ++mm) {
         const bool ok = full_t || (colok && oy0 + mm < a.Hout);
-#if defined(CR_DBG) && CR_DBG == 2
-        yv[mm] = u32x2{0x3F803F80u + (unsigned)mm, 0x3F803F80u};
-#else
         yv[mm] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsy, (int)(ok ? ybase + (unsigned)(mm * row_bytes) : SENT), 0, 0));
-#endif
       }
     };
     if constexpr (CR) {
@@ -380,12 +376,8 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
         const unsigned x0 = pack_bf16x2(acc[m][0], acc[m][1]), x1 = pack_bf16x2(acc[m][2], acc[m][3]);
         const unsigned y0 = pack_bf16x2(acc[m + 1][0], acc[m + 1][1]), y1 = pack_bf16x2(acc[m + 1][2], acc[m + 1][3]);
         if constexpr (CR) {
-#if !defined(CR_DBG) || CR_DBG != 1
           cr_row(x0, x1, yv[m], (FULL || (colok && oy0 + m < a.Hout)) ? 1.f : 0.f);
           cr_row(y0, y1, yv[m + 1], (FULL || (colok && oy0 + m + 1 < a.Hout)) ? 1.f : 0.f);
-#else
-          s1[0] += __builtin_bit_cast(float, yv[m][0] ^ yv[m + 1][1]);
-#endif
         }
         // vdst rows 1,3 (odd q) <-> src rows 0,2 (even q): even q gets its partner's x in y, odd q its partner's y in x
         const auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
@@ -405,16 +397,7 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
           // tiles then stored the new value.  hipcc's own rule (one wait state after a >= 12-byte store) does not cover it
           // while the vector-memory path is busy; 16 wait states do (8 stores per tile: ~130 cycles of an ~8000-cycle tile).
           __builtin_amdgcn_sched_barrier(0);
-#if defined(CR_PAD) && CR_PAD == 0
-#elif defined(CR_PAD) && CR_PAD == 2
-          asm volatile("s_nop 1" ::: "memory");
-#elif defined(CR_PAD) && CR_PAD == 4
-          asm volatile("s_nop 3" ::: "memory");
-#elif defined(CR_PAD) && CR_PAD == 8
-          asm volatile("s_nop 7" ::: "memory");
-#else
-          asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-#endif
+          asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // (-DCR_PAD builds of this line measured 0 / 2 / 4 / 8 wait states: tools/probe/diag_cr4.py)
           __builtin_amdgcn_sched_barrier(0);
         }
       }

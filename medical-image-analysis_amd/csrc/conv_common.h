@@ -22,6 +22,9 @@ struct ConvArgs {
   // activated output of the PRODUCING PlainBlock; cr_y is that block's raw conv output (same geometry as out1) and the
   // epilogue adds up, per tile, sum g and sum g*xhat with g = dz * lrelu'(scale*y + shift), xhat = xa*y + xb -- the
   // reduction pass of that block's norm backward -- into `stats` ([N][tiles][o1][2])
+  // accumulate mode (mia_conv_mma_acc): out1 += result instead of out1 = result (the second gradient piece of a skip tensor is
+  // added into the first in the epilogue of the kernel that produces it: one read-modify-write instead of a second tensor)
+  int acc_out = 0;
   const void* cr_y = nullptr; const float* cr_scale = nullptr; const float* cr_shift = nullptr;
   const float* cr_xa = nullptr; const float* cr_xb = nullptr; float cr_slope = 0.f;
 };

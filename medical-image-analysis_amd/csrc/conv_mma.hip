@@ -310,7 +310,7 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
                         int npad, int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2,
                         int o2, float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream,
                         const float* nl_scale, const float* nl_shift, float nl_slope, const void* cr_y = nullptr,
-                        const float* const* cr_coef = nullptr, float cr_slope = 0.f) {
+                        const float* const* cr_coef = nullptr, float cr_slope = 0.f, int acc_out = 0) {
   MIA_CHECK_ARG(mode >= 0 && mode <= MODE_G1, "mia_conv_mma: bad mode %d", mode);
   MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_conv_mma: bad dtype %d", dtype);
   MIA_CHECK_ARG(in1 && wpack && out1 && c1 > 0 && o1 > 0 && c2 >= 0 && o2 >= 0, "mia_conv_mma: null/empty operand");
@@ -336,6 +336,7 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
   a.N = n; a.Hin = hin; a.Win = win; a.Hout = hout; a.Wout = wout;
   a.npad = npad; a.kpad = kpad; a.flip = flip_taps;
   a.nl_scale = nl_scale; a.nl_shift = nl_shift; a.nl_slope = nl_slope;
+  a.acc_out = acc_out;
   if (cr_y != nullptr) {
     a.cr_y = cr_y; a.cr_scale = cr_coef[0]; a.cr_shift = cr_coef[1]; a.cr_xa = cr_coef[2]; a.cr_xb = cr_coef[3]; a.cr_slope = cr_slope;
   }
@@ -367,7 +368,7 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
   // the same 512-thread shape for the strided conv's INPUT GRADIENT (transposed mode, four output-parity classes per tile):
   // a 128-channel block shares one staged dy tile (option conv_t3_wide; measured per level in tools/s2_levels.py)
   bool t3_wide = false;
-  if (opt.conv_t3_wide && fast && mode == MODE_T3S2 && dtype == MIA_BF16 && nout % 128 == 0 && a.o2 == 0 && mt == 4) {
+  if (opt.conv_t3_wide && !acc_out && fast && mode == MODE_T3S2 && dtype == MIA_BF16 && nout % 128 == 0 && a.o2 == 0 && mt == 4) {
     t3_wide = true;
     a.nblk_n = nout / 128;
   }
@@ -376,7 +377,11 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
     return MIA_EUNSUPPORTED;
   }
   // conv64_dma: 1 = the one-pass two-destination input gradient only (measured faster there), 2 = every 64 -> 64 launch
-  if (cr_y != nullptr) {  // column-reduce epilogue: the 64-channel register kernel (its epilogue overlaps the co-resident workgroup)
+  if (acc_out) {  // out += result: the tile kernel's epilogue is the one that reads the previous values
+    if (!fast || t3_wide) { mia_set_error("mia_conv_mma_acc: shape outside the accumulating kernel's contract"); return MIA_EUNSUPPORTED; }
+    rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
+  }
+  else if (cr_y != nullptr) {  // column-reduce epilogue: the 64-channel register kernel (its epilogue overlaps the co-resident workgroup)
     if (!(mt == 4 && conv64_eligible(mode, dtype, a))) {
       mia_set_error("mia_conv_mma_cr: shape outside the column-reduce kernel's contract (ask mia_conv_cr_supported first)");
       return MIA_EUNSUPPORTED;
@@ -449,4 +454,17 @@ extern "C" int mia_conv_mma_cr(int mode, int dtype, const void* in1, int c1, con
   const float* coef[4] = {scale, shift, xa, xb};
   return conv_mma_run(mode, dtype, in1, c1, nullptr, 0, wpack, npad, kpad, flip_taps, nullptr, out, nout, nullptr, 0, partials, n, hin,
                       win, hout, wout, stream, nullptr, nullptr, 0.f, y_prod, coef, slope);
+}
+
+// out += conv(in): see include/mia_hip.h.
+extern "C" int mia_conv_acc_supported(int mode, int dtype, int c1, int nout) {
+  const int epu = dtype == MIA_BF16 ? 8 : 4;
+  return ((mode == MODE_T3S2 || mode == MODE_G3S1) && (dtype == MIA_BF16 || dtype == MIA_F32) && c1 % (4 * epu) == 0 && nout % epu == 0) ? 1 : 0;
+}
+
+extern "C" int mia_conv_mma_acc(int mode, int dtype, const void* in1, int c1, const void* wpack, int npad, int kpad, int flip_taps,
+                                void* out_inout, int nout, int n, int hin, int win, int hout, int wout, void* stream) {
+  MIA_CHECK_ARG(mode == MODE_T3S2 || mode == MODE_G3S1, "mia_conv_mma_acc: mode %d not served", mode);
+  return conv_mma_run(mode, dtype, in1, c1, nullptr, 0, wpack, npad, kpad, flip_taps, nullptr, out_inout, nout, nullptr, 0, nullptr, n, hin,
+                      win, hout, wout, stream, nullptr, nullptr, 0.f, nullptr, nullptr, 0.f, 1);
 }

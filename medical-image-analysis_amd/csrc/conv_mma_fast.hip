@@ -331,13 +331,32 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
     const rsrc_t rso = make_rsrc(obase + (size_t)img * opix * cn, (unsigned)(opix * cn * ES));
     const int nloc = second ? ch - a.o1 : ch;
     const bool colok = pixok && ((ch >= a.o1) == second);
+    unsigned voffs[O_IT];
 #pragma unroll
     for (int i = 0; i < O_IT; ++i) {
       const int y = y0 + i * (PPI / 16);
       const int oy = TMODE ? 2 * (oy0 + y) + ph : oy0 + y;
-      const unsigned voff = (colok && oy0 + y < hd) ? (unsigned)((((size_t)oy * a.Wout + ox) * cn + nloc) * ES) : SENT;
+      voffs[i] = (colok && oy0 + y < hd) ? (unsigned)((((size_t)oy * a.Wout + ox) * cn + nloc) * ES) : SENT;
+    }
+    if (a.acc_out) {  // out += result: every previous value is loaded before the first store (the compiler cannot reorder them itself)
+      u32x4 prev[O_IT];
+#pragma unroll
+      for (int i = 0; i < O_IT; ++i) prev[i] = __builtin_amdgcn_raw_buffer_load_b128(rso, (int)voffs[i], 0, 0);
+#pragma unroll
+      for (int i = 0; i < O_IT; ++i) {
+        alignas(16) T dv[EPU]; alignas(16) T pv[EPU];
+        *reinterpret_cast<u32x4*>(dv) = *reinterpret_cast<const u32x4*>(ldsO + (pl0 + i * PPI) * OSTR + cu * EPU);
+        *reinterpret_cast<u32x4*>(pv) = prev[i];
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) dv[e] = Elem<T>::cvt(Elem<T>::ld(pv + e) + Elem<T>::ld(dv + e));
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(dv), rso, (int)voffs[i], 0, 0);
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < O_IT; ++i) {
       const u32x4 d = *reinterpret_cast<const u32x4*>(ldsO + (pl0 + i * PPI) * OSTR + cu * EPU);
-      __builtin_amdgcn_raw_buffer_store_b128(d, rso, (int)voff, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(d, rso, (int)voffs[i], 0, 0);
     }
   };
   const bool first_part = n0 < a.o1, second_part = a.o2 > 0 && n0 + BN > a.o1;  // uniform

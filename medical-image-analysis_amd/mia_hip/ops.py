@@ -380,6 +380,24 @@ def _take_cr(dz: torch.Tensor) -> Optional[torch.Tensor]:
     return h[0] if (h is not None and h[1] == tuple(dz.shape)) else None
 
 
+# Skip tensors have two consumers, so their gradient arrives in two pieces.  The decoder block (which runs first in backward) leaves
+# its piece here, keyed by the skip tensor's storage address; the stride-2 block of the next encoder level then ADDS its piece into
+# that tensor inside its input-gradient kernel (mia_conv_mma_acc) and returns no gradient of its own, so the skip block's norm
+# backward reads one gradient tensor instead of two.
+_ACC_HINT = {}
+FUSE_ACC = __import__('os').environ.get('MIA_FUSE_ACC', '1') != '0'  # A/B knob
+
+
+def _hint_acc(x: torch.Tensor, dx: torch.Tensor) -> None:
+    if FUSE_ACC and dx is not None:
+        _ACC_HINT[x.data_ptr()] = (dx, tuple(x.shape))
+
+
+def _take_acc(x: torch.Tensor) -> Optional[torch.Tensor]:
+    h = _ACC_HINT.pop(x.data_ptr(), None)
+    return h[0] if (h is not None and h[1] == tuple(x.shape) and h[0].dtype == x.dtype) else None
+
+
 def cr_supported(dtype, cin: int, cout: int, h: int, w: int) -> bool:
     return FUSE_CR and dtype == torch.bfloat16 and bool(lib().mia_conv_cr_supported(CONV_G3S1, BF16, cout, cin, h, w))
 
@@ -684,6 +702,12 @@ class PlainBlockFn(torch.autograd.Function):
             c1 = x1.shape[3]
             split = c1 if x2 is not None else None
             if ctx.stride == 2:
+                other = _take_acc(x1) if x2 is None else None
+                if other is not None and lib().mia_conv_acc_supported(CONV_T3S2, dtype, cout, cin):
+                    # the other consumer of x1 (a skip tensor) has already written its gradient piece: add ours into it
+                    call("mia_conv_mma_acc", CONV_T3S2, dtype, _p(dy), cout, _p(wb), npad, kpad, 0, _p(other), cin, n, ho, wo,
+                         x1.shape[1], x1.shape[2], _stream())
+                    return (None, None, dw, dbias, dgamma, dbeta) + (None,) * 8
                 dx1, dx2, _ = conv_mma(CONV_T3S2, dy, None, wb, npad, kpad, False, None, cin, (x1.shape[1], x1.shape[2]),
                                        out_split=split)
             else:
@@ -701,6 +725,8 @@ class PlainBlockFn(torch.autograd.Function):
                 if want:
                     sums = colsum(st.view(-1, 2 * cin)).view(cin, 2)[c1:, 0]
                     _hint_colsum(dx2, sums)
+                if x2 is not None and ctx.needs_input_grad[0]:
+                    _hint_acc(x1, dx1)  # x1 is the skip tensor: its other consumer may add its gradient piece into dx1
         return (dx1, dx2, dw, dbias, dgamma, dbeta) + (None,) * 8
 
 

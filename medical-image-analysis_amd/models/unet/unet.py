@@ -216,6 +216,8 @@ class UNet(nn.Module):
 
     def forward(self, x, return_ds=False):
         ops._COLSUM_HINT.clear()  # hints are only valid inside the backward pass of the forward that produced them
+        ops._ACC_HINT.clear()
+        ops._CR_HINT.clear()
         self._draw_dropout(x.shape[0], x.device)
         return self.decoder.forward_nhwc(self._skips(x), return_ds=return_ds)
 

@@ -1321,3 +1321,53 @@ def test_wgrad_narrow_blocks_match_full_blocks(case):
     xc = torch.cat([t.float().cpu().permute(0, 3, 1, 2) for t in (x1, x2) if t is not None], 1)
     want = torch.nn.grad.conv2d_weight(xc, shape, dy.float().cpu().permute(0, 3, 1, 2), padding=1)
     assert relerr(outs[1], want) < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("norm,ch,hw", [("instance", [32, 64, 128], (64, 96)), ("batch", [64, 128], (48, 80)), ("instance", [16, 32, 64, 128], (80, 48))])
+def test_skip_gradient_accumulated_in_the_stride2_input_gradient(norm, ch, hw, dtype):
+    """A skip tensor's gradient arrives in two pieces (decoder block, next encoder level).  ops.FUSE_ACC: the stride-2 block adds
+    its piece into the decoder's tensor inside its input-gradient kernel (`mia_conv_mma_acc`) and the skip block's norm backward
+    reads ONE tensor.  fp32: the stored sum is the same fp32 number the two-piece kernels formed on load -> every gradient
+    bit-identical; bf16: the sum is rounded to bf16 once more -> within the bf16 rounding band.  Kernel level: out += conv."""
+    import mia_hip
+    from mia_hip import CONV_T3S2, call, ops
+    from mia_hip.ops import _p, _stream
+    from models.unet import UNet
+    dev = _dev()
+    g = torch.Generator().manual_seed(ch[0] + hw[0])
+    x = torch.rand(2, 1, *hw, generator=g).to(dev)
+    gz = torch.randn(2, 3, *hw, generator=g).to(dev)
+    res = {}
+    old = ops.FUSE_ACC
+    try:
+        for fuse in (False, True):
+            ops.FUSE_ACC = fuse
+            torch.manual_seed(4)
+            m = UNet(2, 1, 3, ch, normalization=norm, dropout_prob=None).to(dev)
+            m.set_compute_dtype(dtype)
+            m.train()
+            (m(x) * gz).sum().backward()
+            res[fuse] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+            assert not ops._ACC_HINT or not fuse  # every piece left by a decoder block was taken
+    finally:
+        ops.FUSE_ACC = old
+    for k in res[False]:
+        if dtype == torch.float32:
+            assert torch.equal(res[False][k], res[True][k]), k
+        else:
+            assert relerr(res[True][k], res[False][k]) < 3e-2, k
+    # kernel level
+    n, cout, cin, hc, wc = 2, 64, 32, 12, 20
+    dt = mia_hip.BF16 if dtype == torch.bfloat16 else mia_hip.F32
+    dy = torch.randn(n, hc, wc, cout, generator=g).to(dev, dtype)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / 30).to(dev)
+    wb, npad, kpad = ops.PackCache().get(wt, dt, False)
+    for fine in ((2 * hc, 2 * wc), (2 * hc - 1, 2 * wc - 1)):
+        base = torch.randn(n, fine[0], fine[1], cin, generator=g).to(dev, dtype)
+        plain, _, _ = ops.conv_mma(CONV_T3S2, dy, None, wb, npad, kpad, False, None, cin, fine)
+        acc = base.clone()
+        call("mia_conv_mma_acc", CONV_T3S2, dt, _p(dy), cout, _p(wb), npad, kpad, 0, _p(acc), cin, n, hc, wc, fine[0], fine[1], _stream())
+        want = (base.float() + plain.float()).to(dtype)
+        assert torch.equal(acc, want), fine
