@@ -294,6 +294,16 @@ int mia_norm_act_bwd_head(const float* dlogits, const float* w, int k1, int64_t 
                           const float* ysum, int n, int64_t hw, int c, int mode, int fixed_stats, float slope, int slabs,
                           float* partials, float* c1, float* c2, float* dgamma, float* dbeta, float* dbias, int accumulate,
                           void* stream);
+/* mia_norm_act_bwd_head + mia_head_norm_wgrad in ONE reduction pass (both read exactly dlogits and y): the kernel that adds up the
+ * block's norm-backward sums also accumulates the head's dW[k][c] = sum_p dl[p][k] * lrelu(scale * y + shift) and db[k] (unet.py:176
+ * backward).  c == 64 (mia_head_w_supported); head_workspace: n * slabs * k1 * (c + 1) floats. */
+int mia_head_w_supported(int dtype, int c, int k1);
+int mia_norm_act_bwd_head_w(const float* dlogits, const float* w, int k1, int64_t gsn, int64_t gsk, int64_t gsp,
+                            const void* y, void* dy, int dtype, const float* scale, const float* shift, const float* xa,
+                            const float* xb, const float* ysum, int n, int64_t hw, int c, int mode, int fixed_stats,
+                            float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta,
+                            float* dbias, int accumulate, float* head_workspace, float* dw_head, float* db_head,
+                            int accumulate_head, void* stream);
 
 /* ------------------------------------------------------------------ optimizer (al_trainer.py:1374-1379) */
 #define MIA_OPT_ADAM 0

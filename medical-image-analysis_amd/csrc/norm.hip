@@ -853,12 +853,15 @@ extern "C" int mia_norm_act_bwd_apply_sync(const void* dz, const void* dz2, cons
 // When the block's only consumer is the segmentation head, its output gradient is dz[p][c] = sum_k dl[p][k] * w[k][c]:
 // three FMAs per value from 12 bytes per pixel.  Recomputing it here (weights in registers) removes the head's
 // input-gradient kernel and both reads of dz: nothing activation-sized flows between the head and this block.
-template <typename T, int K1, int CG>
+// HWG (round 4): the same pass also accumulates the head's weight / bias gradient dW[k][c] = sum_p dl[p][k] * lrelu(scale*y + shift),
+// db[k] = sum_p dl[p][k] -- both kernels read exactly (dl, y), so mia_head_norm_wgrad's pass over them disappears.  Needs c == CG
+// (one channel group per block row); wpart: [gridDim.x][K1][c + 1].
+template <typename T, int K1, int CG, bool HWG = false>
 __global__ __launch_bounds__(256) void colreduce_head_kernel(const float* __restrict__ dl, const float* __restrict__ w,
                                                              const T* __restrict__ y, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* __restrict__ xa,
                                                              const float* __restrict__ xb, int hw, int c, int slabs, float slope,
-                                                             int64_t gsn, int64_t gsp, int64_t gsk, float* __restrict__ part) {
+                                                             int64_t gsn, int64_t gsp, int64_t gsk, float* __restrict__ part, float* __restrict__ wpart) {
   constexpr int EPU = Elem<T>::EPU, UPB = CG / EPU, LANES = 256 / UPB;
   __shared__ float sh[2][LANES][CG + 1];
   const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
@@ -866,6 +869,13 @@ __global__ __launch_bounds__(256) void colreduce_head_kernel(const float* __rest
   const int ch0 = blockIdx.y * CG + u * EPU;
   const int per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
   float s1[EPU], s2[EPU], sc[EPU], sf[EPU], ka[EPU], kb[EPU], wr[K1][EPU];
+  float wacc[HWG ? K1 : 1][EPU], bacc[HWG ? K1 : 1];
+#pragma unroll
+  for (int k = 0; k < (HWG ? K1 : 1); ++k) {
+    bacc[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) wacc[k][e] = 0.f;
+  }
 #pragma unroll
   for (int e = 0; e < EPU; ++e) {
     s1[e] = 0.f; s2[e] = 0.f;
@@ -879,14 +889,24 @@ __global__ __launch_bounds__(256) void colreduce_head_kernel(const float* __rest
   auto body = [&](const u32x4& raw, const float (&gv)[K1]) {
     alignas(16) T v[EPU];
     *reinterpret_cast<u32x4*>(v) = raw;
+    if constexpr (HWG) {
+#pragma unroll
+      for (int k = 0; k < K1; ++k) bacc[k] += gv[k];
+    }
 #pragma unroll
     for (int e = 0; e < EPU; ++e) {
       const float yv = Elem<T>::ld(v + e);
       float g = 0.f;
 #pragma unroll
       for (int k = 0; k < K1; ++k) g += gv[k] * wr[k][e];
-      if (!(sc[e] * yv + sf[e] > 0.f)) g *= slope;
+      const float uv = sc[e] * yv + sf[e];
+      if (!(uv > 0.f)) g *= slope;
       s1[e] += g; s2[e] += g * (ka[e] * yv + kb[e]);
+      if constexpr (HWG) {  // the head's input x = lrelu(u), as mia_head_norm_wgrad forms it
+        const float xv = uv > 0.f ? uv : uv * slope;
+#pragma unroll
+        for (int k = 0; k < K1; ++k) wacc[k][e] += gv[k] * xv;
+      }
     }
   };
   int r = r0 + pl;
@@ -918,7 +938,45 @@ __global__ __launch_bounds__(256) void colreduce_head_kernel(const float* __rest
     for (int j = 0; j < LANES; ++j) t += sh[k][j][chl];
     part[(((size_t)n * slabs + s) * c + blockIdx.y * CG + chl) * 2 + k] = t;
   }
+  if constexpr (HWG) {  // per-block head gradient partials: [K1][c + 1] (the bias column last), lanes combined through the same LDS rows
+#pragma unroll
+    for (int k = 0; k < K1; ++k) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < EPU; ++e) sh[0][pl][u * EPU + e] = wacc[k][e];
+      if (u == 0) sh[0][pl][CG] = bacc[k];
+      __syncthreads();
+      if (threadIdx.x <= CG) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < LANES; ++j) t += sh[0][j][threadIdx.x];
+        wpart[((size_t)blockIdx.x * K1 + k) * (CG + 1) + threadIdx.x] = t;
+      }
+    }
+  }
 }
+
+// dw[k][c] / db[k] (+)= sum over blocks of the partials above (fixed order)
+__global__ void head_w_final_kernel(const float* __restrict__ part, int nblk, int k1, int c0, float* __restrict__ dw, float* __restrict__ db,
+                                    int accumulate) {
+  __shared__ float sh[16][17];
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + cl, tot = k1 * (c0 + 1);
+  float sm = 0.f;
+  if (i < tot)
+    for (int b = tl; b < nblk; b += 16) sm += part[(size_t)b * tot + i];
+  sh[tl][cl] = sm;
+  __syncthreads();
+  if (tl == 0 && i < tot) {
+    float t = 0.f;
+    for (int j = 0; j < 16; ++j) t += sh[j][cl];
+    const int kk = i / (c0 + 1), ch = i % (c0 + 1);
+    if (ch < c0) dw[kk * c0 + ch] = accumulate ? dw[kk * c0 + ch] + t : t;
+    else db[kk] = accumulate ? db[kk] + t : t;
+  }
+}
+
+
 
 template <typename T, int K1>
 __global__ __launch_bounds__(256) void norm_act_bwd_stream_head_kernel(const float* __restrict__ dl, const float* __restrict__ w,
@@ -983,11 +1041,11 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stream_head_kernel(const flo
 
 // mia_norm_act_bwd with dz = W^T dl recomputed on the fly (w: [k1][c] fp32, dl: fp32 logits gradient with element strides
 // gsn / gsk / gsp, pixel-linear).  Contract: c % 32 == 0, 2 <= k1 <= 4, 16-byte aligned y / dy, hw < 2^31.
-extern "C" int mia_norm_act_bwd_head(const float* dlogits, const float* w, int k1, int64_t gsn, int64_t gsk, int64_t gsp,
-                                     const void* y, void* dy, int dtype, const float* scale, const float* shift, const float* xa,
-                                     const float* xb, const float* ysum, int n, int64_t hw, int c, int mode, int fixed_stats,
-                                     float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta,
-                                     float* dbias, int accumulate, void* stream) {
+static int norm_act_bwd_head_run(const float* dlogits, const float* w, int k1, int64_t gsn, int64_t gsk, int64_t gsp,
+                                 const void* y, void* dy, int dtype, const float* scale, const float* shift, const float* xa,
+                                 const float* xb, const float* ysum, int n, int64_t hw, int c, int mode, int fixed_stats,
+                                 float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta,
+                                 float* dbias, int accumulate, void* stream, float* wpart, float* dwh, float* dbh, int acc_head) {
   MIA_CHECK_ARG(dlogits && w && y && dy && scale && shift && xa && xb && partials && c1 && c2 && dgamma && dbeta,
                 "mia_norm_act_bwd_head: null pointer");
   MIA_CHECK_ARG(n > 0 && hw > 0 && hw < ((int64_t)1 << 31) && c > 0 && slabs > 0 && k1 >= 2 && k1 <= 4 && c % 32 == 0,
@@ -996,11 +1054,15 @@ extern "C" int mia_norm_act_bwd_head(const float* dlogits, const float* w, int k
   MIA_CHECK_ARG(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0, "mia_norm_act_bwd_head: unaligned");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int epu = dtype == MIA_BF16 ? 8 : 4;
-#define CRH(T, K, CGW) hipLaunchKernelGGL((colreduce_head_kernel<T, K, CGW>), dim3(n * slabs, c / CGW), dim3(256), 0, st, dlogits, w, \
-                                          static_cast<const T*>(y), scale, shift, xa, xb, (int)hw, c, slabs, slope, gsn, gsp, gsk, partials)
-#define CRHK(T, CGW) do { if (k1 == 2) CRH(T, 2, CGW); else if (k1 == 3) CRH(T, 3, CGW); else CRH(T, 4, CGW); } while (0)
-  if (c % 64 == 0) { if (dtype == MIA_BF16) CRHK(bf16_t, 64); else CRHK(float, 64); }
-  else { if (dtype == MIA_BF16) CRHK(bf16_t, 32); else CRHK(float, 32); }
+#define CRH(T, K, CGW, HG) hipLaunchKernelGGL((colreduce_head_kernel<T, K, CGW, HG>), dim3(n * slabs, c / CGW), dim3(256), 0, st, dlogits, w, \
+                                              static_cast<const T*>(y), scale, shift, xa, xb, (int)hw, c, slabs, slope, gsn, gsp, gsk, partials, wpart)
+#define CRHK(T, CGW, HG) do { if (k1 == 2) CRH(T, 2, CGW, HG); else if (k1 == 3) CRH(T, 3, CGW, HG); else CRH(T, 4, CGW, HG); } while (0)
+  if (wpart != nullptr) {  // c == 64 (checked by the caller): the head's weight gradient rides in the same pass
+    if (dtype == MIA_BF16) CRHK(bf16_t, 64, true); else CRHK(float, 64, true);
+    hipLaunchKernelGGL(head_w_final_kernel, dim3(ceil_div(k1 * (c + 1), 16)), dim3(256), 0, st, wpart, n * slabs, k1, c, dwh, dbh, acc_head);
+  }
+  else if (c % 64 == 0) { if (dtype == MIA_BF16) CRHK(bf16_t, 64, false); else CRHK(float, 64, false); }
+  else { if (dtype == MIA_BF16) CRHK(bf16_t, 32, false); else CRHK(float, 32, false); }
 #undef CRHK
 #undef CRH
   const bool inline_sums = (int64_t)n * slabs <= 1024;
@@ -1018,4 +1080,31 @@ extern "C" int mia_norm_act_bwd_head(const float* dlogits, const float* w, int k
 #undef BSH
   MIA_LAUNCH_CHECK();
   return MIA_OK;
+}
+
+extern "C" int mia_norm_act_bwd_head(const float* dlogits, const float* w, int k1, int64_t gsn, int64_t gsk, int64_t gsp,
+                                     const void* y, void* dy, int dtype, const float* scale, const float* shift, const float* xa,
+                                     const float* xb, const float* ysum, int n, int64_t hw, int c, int mode, int fixed_stats,
+                                     float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta,
+                                     float* dbias, int accumulate, void* stream) {
+  return norm_act_bwd_head_run(dlogits, w, k1, gsn, gsk, gsp, y, dy, dtype, scale, shift, xa, xb, ysum, n, hw, c, mode, fixed_stats, slope,
+                               slabs, partials, c1, c2, dgamma, dbeta, dbias, accumulate, stream, nullptr, nullptr, nullptr, 0);
+}
+
+// mia_norm_act_bwd_head + mia_head_norm_wgrad in one reduction pass: the head's dW / db are accumulated by the kernel that computes the
+// block's norm-backward sums (both read exactly dl and y).  c == 64; head_workspace: n * slabs * k1 * (c + 1) floats.
+extern "C" int mia_head_w_supported(int dtype, int c, int k1) {
+  return ((dtype == MIA_BF16 || dtype == MIA_F32) && c == 64 && k1 >= 2 && k1 <= 4) ? 1 : 0;
+}
+extern "C" int mia_norm_act_bwd_head_w(const float* dlogits, const float* w, int k1, int64_t gsn, int64_t gsk, int64_t gsp,
+                                       const void* y, void* dy, int dtype, const float* scale, const float* shift, const float* xa,
+                                       const float* xb, const float* ysum, int n, int64_t hw, int c, int mode, int fixed_stats,
+                                       float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta,
+                                       float* dbias, int accumulate, float* head_workspace, float* dw_head, float* db_head,
+                                       int accumulate_head, void* stream) {
+  MIA_CHECK_ARG(head_workspace && dw_head && db_head, "mia_norm_act_bwd_head_w: null head-gradient pointer");
+  MIA_CHECK_ARG(mia_head_w_supported(dtype, c, k1), "mia_norm_act_bwd_head_w: unsupported shape (c=%d k1=%d)", c, k1);
+  return norm_act_bwd_head_run(dlogits, w, k1, gsn, gsk, gsp, y, dy, dtype, scale, shift, xa, xb, ysum, n, hw, c, mode, fixed_stats, slope,
+                               slabs, partials, c1, c2, dgamma, dbeta, dbias, accumulate, stream, head_workspace, dw_head, db_head,
+                               accumulate_head);
 }

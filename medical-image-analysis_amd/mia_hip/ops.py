@@ -515,6 +515,7 @@ class LazyMaterializeFn(torch.autograd.Function):
         return dz, None, None
 
 
+FUSE_HEAD_W = __import__('os').environ.get('MIA_FUSE_HEAD_W', '1') != '0'  # A/B knob: head dW / db in the norm-backward reduction pass
 FUSE_STEM_BWD = __import__('os').environ.get('MIA_FUSE_STEM_BWD', '1') != '0'  # A/B knob: the stem's backward apply pass folded into its weight gradient
 FUSE_NL = __import__('os').environ.get('MIA_FUSE_NL', '1') != '0'  # A/B knob: 0 = every block materialises its activation
 
@@ -793,10 +794,6 @@ class PlainBlockHeadFn(torch.autograd.Function):
         dwh, dbh = grad_dest(head_w), grad_dest(head_b)
         dwh = torch.empty((k1, cout), device=dev, dtype=torch.float32) if dwh is None else dwh
         dbh = torch.empty(k1, device=dev, dtype=torch.float32) if dbh is None else dbh
-        ws = torch.empty(lib().mia_head_bwd_workspace(cout, k1), device=dev, dtype=torch.float32)
-        call("mia_head_norm_wgrad", _p(dl), _p(y), dtype, _p(coefs[2]), _p(coefs[3]), _c_float(ctx.slope), _p(dwh), _p(dbh),
-             _p(ws), n, _c_i64(hw), cout, k1, _c_i64(st[0]), _c_i64(st[1]), _c_i64(st[2]), 0, _stream())
-        # norm backward with dz = W^T dl recomputed
         slabs = _slabs_for(hw)
         part = torch.empty((n, slabs, cout, 2), device=dev, dtype=torch.float32)
         cc = torch.empty((2, n, cout), device=dev, dtype=torch.float32)
@@ -806,10 +803,22 @@ class PlainBlockHeadFn(torch.autograd.Function):
         dbeta = dgb[1] if dbeta is None else dbeta
         dbias = dgb[2] if dbias is None else dbias
         dy = torch.empty_like(y)
-        call("mia_norm_act_bwd_head", _p(dl), _p(w2), k1, _c_i64(st[0]), _c_i64(st[1]), _c_i64(st[2]), _p(y), _p(dy), dtype,
-             _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]), _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout,
-             ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs, _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta),
-             _p(dbias), 0, _stream())
+        if FUSE_HEAD_W and lib().mia_head_w_supported(dtype, cout, k1):
+            # head dW / db and the block's norm-backward sums in ONE pass over (dl, y); then the apply pass with dz = W^T dl recomputed
+            ws = torch.empty(n * slabs * k1 * (cout + 1), device=dev, dtype=torch.float32)
+            call("mia_norm_act_bwd_head_w", _p(dl), _p(w2), k1, _c_i64(st[0]), _c_i64(st[1]), _c_i64(st[2]), _p(y), _p(dy), dtype,
+                 _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]), _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout,
+                 ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs, _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta),
+                 _p(dbias), 0, _p(ws), _p(dwh), _p(dbh), 0, _stream())
+        else:
+            ws = torch.empty(lib().mia_head_bwd_workspace(cout, k1), device=dev, dtype=torch.float32)
+            call("mia_head_norm_wgrad", _p(dl), _p(y), dtype, _p(coefs[2]), _p(coefs[3]), _c_float(ctx.slope), _p(dwh), _p(dbh),
+                 _p(ws), n, _c_i64(hw), cout, k1, _c_i64(st[0]), _c_i64(st[1]), _c_i64(st[2]), 0, _stream())
+            # norm backward with dz = W^T dl recomputed
+            call("mia_norm_act_bwd_head", _p(dl), _p(w2), k1, _c_i64(st[0]), _c_i64(st[1]), _c_i64(st[2]), _p(y), _p(dy), dtype,
+                 _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]), _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout,
+                 ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs, _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta),
+                 _p(dbias), 0, _stream())
         dw = conv_wgrad(WGRAD_3S1, x1, None, dy, weight.shape, cout, cin, out=grad_dest(weight),
                         nl=None if nl_coefs is None else (nl_coefs, ctx.nl_slope))
         dx1 = None

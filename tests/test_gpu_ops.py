@@ -1371,3 +1371,37 @@ def test_skip_gradient_accumulated_in_the_stride2_input_gradient(norm, ch, hw, d
         call("mia_conv_mma_acc", CONV_T3S2, dt, _p(dy), cout, _p(wb), npad, kpad, 0, _p(acc), cin, n, hc, wc, fine[0], fine[1], _stream())
         want = (base.float() + plain.float()).to(dtype)
         assert torch.equal(acc, want), fine
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,k1", [(torch.float32, 3), (torch.bfloat16, 3), (torch.bfloat16, 4), (torch.float32, 2)])
+def test_head_weight_gradient_in_the_norm_backward_reduction_pass(dtype, k1):
+    """ops.FUSE_HEAD_W: `mia_norm_act_bwd_head_w` accumulates the 1x1 head's dW / db in the kernel that adds up the last block's
+    norm-backward sums (both read exactly dlogits and y) -- `mia_head_norm_wgrad`'s pass over them disappears.  Every other
+    gradient bit-identical to the two-pass path; the head's dW / db equal within fp32 summation order (another slab partition)."""
+    from losses.compound_losses import DiceAndCELoss
+    from mia_hip import ops
+    from models.unet import UNet
+    dev = _dev()
+    g = torch.Generator().manual_seed(k1)
+    x = torch.rand(3, 1, 96, 80, generator=g).to(dev)
+    lab = torch.randint(0, k1, (3, 96, 80), generator=g).to(dev)
+    loss_fn = DiceAndCELoss(dice_kwargs=dict(num_classes=k1 - 1, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss)
+    res = {}
+    old = ops.FUSE_HEAD_W
+    try:
+        for fuse in (False, True):
+            ops.FUSE_HEAD_W = fuse
+            torch.manual_seed(2)
+            m = UNet(2, 1, k1, [64, 128], normalization="instance", dropout_prob=None).to(dev)
+            m.set_compute_dtype(dtype)
+            m.train()
+            loss_fn(m(x), lab).backward()
+            res[fuse] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    finally:
+        ops.FUSE_HEAD_W = old
+    for k in res[False]:
+        if k.startswith("decoder.seg_output"):
+            assert relerr(res[True][k], res[False][k]) < 2e-5, k
+        else:
+            assert torch.equal(res[False][k], res[True][k]), k
