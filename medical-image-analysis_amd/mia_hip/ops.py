@@ -543,6 +543,10 @@ class PlainBlockFn(torch.autograd.Function):
         each its own output makes autograd deliver their gradients separately to backward, which sums them on load inside
         the norm kernels instead of autograd launching an `add` over the full activation."""
         ctx.dup = dup
+        # x1 is one of the two views a `dup=True` block handed out (tagged by the model): exactly one gradient will ever arrive
+        # for it, so the two consumers may share one gradient tensor (see _ACC_HINT).  Untagged tensors (e.g. a ResidualBlock's
+        # output, whose several gradient pieces autograd itself adds up) never take that path.
+        ctx.dup_in = bool(getattr(x1, "_mia_dup", False))
         ctx.set_materialize_grads(False)
         _need_dev(x1, x2, weight)
         x1 = x1.contiguous()
@@ -703,7 +707,7 @@ class PlainBlockFn(torch.autograd.Function):
             c1 = x1.shape[3]
             split = c1 if x2 is not None else None
             if ctx.stride == 2:
-                other = _take_acc(x1) if x2 is None else None
+                other = _take_acc(x1) if (x2 is None and ctx.dup_in) else None
                 if other is not None and lib().mia_conv_acc_supported(CONV_T3S2, dtype, cout, cin):
                     # the other consumer of x1 (a skip tensor) has already written its gradient piece: add ours into it
                     call("mia_conv_mma_acc", CONV_T3S2, dtype, _p(dy), cout, _p(wb), npad, kpad, 0, _p(other), cin, n, ho, wo,
@@ -726,7 +730,7 @@ class PlainBlockFn(torch.autograd.Function):
                 if want:
                     sums = colsum(st.view(-1, 2 * cin)).view(cin, 2)[c1:, 0]
                     _hint_colsum(dx2, sums)
-                if x2 is not None and ctx.needs_input_grad[0]:
+                if x2 is not None and ctx.needs_input_grad[0] and ctx.dup_in:
                     _hint_acc(x1, dx1)  # x1 is the skip tensor: its other consumer may add its gradient piece into dx1
         return (dx1, dx2, dw, dbias, dgamma, dbeta) + (None,) * 8
 

@@ -48,6 +48,7 @@ class UNetEncoder(nn.Module):
                 # a level's output feeds the next level AND the decoder: two outputs on one storage, so each consumer's
                 # gradient reaches the block separately and is summed on load in its norm backward (no `add` pass)
                 x, skip = s[1].forward_nhwc(x, dup=True)
+                x._mia_dup = skip._mia_dup = True  # each view has exactly one consumer (ops.PlainBlockFn: ctx.dup_in)
                 skips.append(skip)
             else:
                 x = s[1].forward_nhwc(x)

@@ -1340,10 +1340,17 @@ def test_skip_gradient_accumulated_in_the_stride2_input_gradient(norm, ch, hw, d
     x = torch.rand(2, 1, *hw, generator=g).to(dev)
     gz = torch.randn(2, 3, *hw, generator=g).to(dev)
     res = {}
-    old = ops.FUSE_ACC
+    old, raw_call, calls = ops.FUSE_ACC, ops.call, []
+
+    def counting_call(name, *a):
+        calls.append(name)
+        return raw_call(name, *a)
+
+    ops.call = counting_call
     try:
         for fuse in (False, True):
             ops.FUSE_ACC = fuse
+            del calls[:]
             torch.manual_seed(4)
             m = UNet(2, 1, 3, ch, normalization=norm, dropout_prob=None).to(dev)
             m.set_compute_dtype(dtype)
@@ -1351,8 +1358,9 @@ def test_skip_gradient_accumulated_in_the_stride2_input_gradient(norm, ch, hw, d
             (m(x) * gz).sum().backward()
             res[fuse] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
             assert not ops._ACC_HINT or not fuse  # every piece left by a decoder block was taken
+            assert calls.count("mia_conv_mma_acc") == (len(ch) - 1 if fuse else 0)  # one accumulating launch per skip level
     finally:
-        ops.FUSE_ACC = old
+        ops.FUSE_ACC, ops.call = old, raw_call
     for k in res[False]:
         if dtype == torch.float32:
             assert torch.equal(res[False][k], res[True][k]), k
