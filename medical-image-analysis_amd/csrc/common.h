@@ -62,6 +62,50 @@ template <> struct Elem<bf16_t> {
   __device__ static __forceinline__ bf16_t cvt(float v) { return f2bf(v); }
 };
 
+// fp32 tensors on the bf16 matrix cores ("split" mode of the fp32 tile kernels, option f32_split).  Every fp32 operand element
+// becomes ONE 32-bit word (hi | lo << 16): hi = bf16_rne(x), lo = bf16_rne(x - hi), i.e. x to 16-17 significant bits; a 16-byte
+// unit still holds four channels, so LDS layout, staging and fragment reads are those of the exact fp32 kernel.  An A fragment
+// (8 bf16 per lane) is then (h0, l0, h1, l1, h2, l2, h3, l3) and two MFMAs against the B fragment's (H0, H0, H1, H1, ..) and
+// (L0, L0, L1, L1, ..) forms add all four products (h + l)(H + L) of 16 channels: 2 x 16 cycles instead of 4 x 32 for the four
+// v_mfma_f32_16x16x4_f32, fp32 accumulation.  bf16 x bf16 products are exact in fp32, so the only error is the 2^-17 operand
+// representation (measured on the full-width nets: logits within 3e-5 of the exact fp32 path).
+struct SplitBf16 {
+  static __device__ __forceinline__ u32x4 unit(const u32x4& raw) {  // 4 fp32 -> 4 words (hi | lo << 16)
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    const f32x4 x = __builtin_bit_cast(f32x4, raw);
+    u32x4 o;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f2 v = {x[2 * p], x[2 * p + 1]};
+      const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));  // h0 | h1 << 16
+      const f2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xFFFF0000u)};
+      const unsigned lp = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, b2));  // l0 | l1 << 16
+      o[2 * p] = __builtin_amdgcn_perm(lp, hp, 0x05040100u);      // h0 | l0 << 16
+      o[2 * p + 1] = __builtin_amdgcn_perm(lp, hp, 0x07060302u);  // h1 | l1 << 16
+    }
+    return o;
+  }
+  static __device__ __forceinline__ u32x4 dup_hi(const u32x4& w) {  // (h, l) words -> (h, h)
+    u32x4 o;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_perm(w[d], w[d], 0x01000100u);
+    return o;
+  }
+  static __device__ __forceinline__ u32x4 dup_lo(const u32x4& w) {  // (h, l) words -> (l, l)
+    u32x4 o;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_perm(w[d], w[d], 0x03020302u);
+    return o;
+  }
+  static __device__ __forceinline__ f32x4 mfma(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  // (h, l) A fragment x expanded B fragment, and expanded A fragment x (h, l) B fragment
+  static __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& bh, const u32x4& bl, f32x4 c) { return mfma(a, bl, mfma(a, bh, c)); }
+  static __device__ __forceinline__ f32x4 mma_a(const u32x4& ah, const u32x4& al, const u32x4& b, f32x4 c) { return mfma(al, b, mfma(ah, b, c)); }
+};
+
 // Norm + LeakyReLU backward for one element (reference autograd of blocks.py:98-102): g = dz * lrelu'(scale*y + shift),
 // dy = scale*(g - c1 - xhat*c2) = scale*g + ka*y + kb with ka = -scale*c2*xa, kb = -scale*(c1 + c2*xb).  ONE definition with explicit
 // fmas, shared by the streaming apply pass (norm.hip) and the kernels that form dy on load (stem.hip: mia_stem_wgrad_fused), so

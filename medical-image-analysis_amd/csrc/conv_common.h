@@ -27,6 +27,7 @@ struct ConvArgs {
   int acc_out = 0;
   const void* cr_y = nullptr; const float* cr_scale = nullptr; const float* cr_shift = nullptr;
   const float* cr_xa = nullptr; const float* cr_xb = nullptr; float cr_slope = 0.f;
+  int split = 0;  // fp32 tensors, products on the bf16 matrix cores from two-way split operands (option f32_split; common.h SplitBf16)
 };
 
 __device__ __forceinline__ int pi16(int r) {
@@ -62,7 +63,6 @@ template <> struct Mma<float> {
     return c;
   }
 };
-
 
 // `reserve_cus` (option of the same name): the persistent kernels below size their grids to the CU count; under data parallelism
 // RCCL's ring kernels need somewhere to run WHILE a persistent kernel owns the chip, and because the work lists are static

@@ -8,6 +8,8 @@
 // compile-time immediate"; the epilogue writes LDS at immediate offsets.  Contract (checked on the host,
 // otherwise the generic kernel runs): c1 % KB == 0, c2 % KB == 0, o1 % EPU == 0, o2 % EPU == 0, 16-byte aligned
 // pointers, per-image tensors < 2 GiB.
+#include <type_traits>
+
 #include "conv_common.h"
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -20,8 +22,11 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 // WC = 2 (stride-2 3x3 forward, bf16): 512 threads, the eight waves are 4 row groups x 2 halves of a 128-channel block on a
 // 16-row tile -- each wave owns 4 x 4 accumulators (8 fragment reads per 16 MFMAs instead of 6 per 8: the 256-thread
 // 8-row shape saturates the LDS pipe), one workgroup per CU.  The statistics stay in the host's 8-row tile layout.
-template <typename T, int MODE, int MT, int NT, int WC = 1>
+// SPLIT (T = float only): fp32 tensors, products on the bf16 matrix cores from two-way split operands (SplitBf16 in
+// common.h): commit() turns every staged fp32 unit into (hi | lo) words, an MFMA step is two 16x16x32 bf16 instructions.
+template <typename T, int MODE, int MT, int NT, int WC = 1, bool SPLIT = false>
 __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_mma_fast_kernel(const ConvArgs a) {
+  static_assert(!SPLIT || sizeof(T) == 4, "split mode is a mode of the fp32 kernel");
   using G = Geo<MODE, MT>;
   constexpr int NTHR = 256 * WC, PL = 64 * WC;  // threads; pixel lanes (x 4 channel groups) of a staging iteration
   constexpr int TH = G::TH, BN = 16 * NT * WC, EPU = Elem<T>::EPU, KB = 4 * EPU, ES = (int)sizeof(T);
@@ -168,9 +173,27 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) ldsA[g * NPA + (S == 2 ? a_lds[i] : p4 + PL * i)] = pa[i];
+    for (int i = 0; i < A_IT; ++i) ldsA[g * NPA + (S == 2 ? a_lds[i] : p4 + PL * i)] = SPLIT ? SplitBf16::unit(pa[i]) : pa[i];
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) ldsB[((i * TPI + tsub) * 4 + g) * NPB + bn_] = pb[i];
+    for (int i = 0; i < B_IT; ++i) ldsB[((i * TPI + tsub) * 4 + g) * NPB + bn_] = SPLIT ? SplitBf16::unit(pb[i]) : pb[i];
+  };
+  // one step of the matrix loop: acc[m][n] += A(m) x B(n) for the wave's MT x NT accumulators.  Split mode forms the (H, H) /
+  // (L, L) forms of a B fragment right before its MT MFMA pairs (8 v_perm per 2 * MT MFMAs; kept out of the double buffer:
+  // 32 more live registers would spill the 4 x 4 shape)
+  auto mma_step = [&](auto&& a_of, const u32x4* bfr) {
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const u32x4 bh = SplitBf16::dup_hi(bfr[n]), bl = SplitBf16::dup_lo(bfr[n]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][n] = SplitBf16::mma(a_of(m), bh, bl, acc[m][n]);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = Mma<T>::run(a_of(m), bfr[n], acc[m][n]);
+    }
   };
 
   fetch(0);
@@ -188,10 +211,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
           for (int n = 0; n < NT; ++n) bf[n] = ldsB[(tl * 4 + q) * NPB + (wc * NT + n) * 16 + pr];
 #pragma unroll
           for (int m = 0; m < MT; ++m) af[m] = ldsA[q * NPA + S * (wave * MT + m) * PITCH + toff + pr];
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = Mma<T>::run(af[m], bf[n], acc[m][n]);
+          mma_step([&](int m) -> const u32x4& { return af[m]; }, bf);
         }
       }
     } else if constexpr (MODE == MODE_G3S1) {
@@ -220,10 +240,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
           for (int j = ta * RPS; j < (ta + 1) * RPS && j < ROWS; ++j) load_row(j, tb + 1, fr[cf ^ 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) acc[m][n] = Mma<T>::run(fr[cf][m + ta], bf[cb][n], acc[m][n]);
+        mma_step([&](int m) -> const u32x4& { return fr[cf][m + ta]; }, bf[cb]);
       }
     } else {
       // compile-time taps: fragments are double buffered in registers -- tap t+1's ds_read_b128s are issued before
@@ -244,10 +261,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
         const int cur = tl & 1;
         if (tl + 1 < NTAPS) load_tap(tl + 1, bf[cur ^ 1], af[cur ^ 1]);
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tap's MFMAs (the scheduler would sink it)
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) acc[m][n] = Mma<T>::run(af[cur][m], bf[cur][n], acc[m][n]);
+        mma_step([&](int m) -> const u32x4& { return af[cur][m]; }, bf[cur]);
       }
     }
     __syncthreads();
@@ -364,17 +378,25 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   if (second_part) store_to(true);
 }
 
-template <typename T, int MODE, int MT, int NT, int WC = 1>
+template <typename T, int MODE, int MT, int NT, int WC = 1, bool SPLIT = false>
 static void flaunch(const ConvArgs& a, int grid_y, hipStream_t st) {
   int grid_x = a.N * a.tiles_x * a.tiles_y * a.nblk_n;
   if (a.xcd) {  // groups of (channel blocks x parity classes) per tile, tiles rounded up to a multiple of 8
     grid_x = ((a.N * a.tiles_x * a.tiles_y + 7) / 8) * 8 * a.nblk_n * grid_y;
     grid_y = 1;
   }
-  hipLaunchKernelGGL((conv_mma_fast_kernel<T, MODE, MT, NT, WC>), dim3(grid_x, grid_y), dim3(256 * WC), 0, st, a);
+  hipLaunchKernelGGL((conv_mma_fast_kernel<T, MODE, MT, NT, WC, SPLIT>), dim3(grid_x, grid_y), dim3(256 * WC), 0, st, a);
 }
 template <typename T, int MODE, int MT>
 static void flaunch_nt(const ConvArgs& a, int nt, int grid_y, hipStream_t st) {
+  if constexpr (sizeof(T) == 4) {
+    if (a.split) {  // fp32 tensors, split-bf16 products
+      if (nt == 4) flaunch<T, MODE, MT, 4, 1, true>(a, grid_y, st);
+      else if (nt == 2) flaunch<T, MODE, MT, 2, 1, true>(a, grid_y, st);
+      else flaunch<T, MODE, MT, 1, 1, true>(a, grid_y, st);
+      return;
+    }
+  }
   if (nt == 4) flaunch<T, MODE, MT, 4>(a, grid_y, st);
   else if (nt == 2) flaunch<T, MODE, MT, 2>(a, grid_y, st);
   else flaunch<T, MODE, MT, 1>(a, grid_y, st);

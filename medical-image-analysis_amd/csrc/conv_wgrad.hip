@@ -1627,7 +1627,11 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgArgs a) {
 // NARROW (32-channel layers: cdy <= 32 and every source <= 32 channels, e.g. al_train's first level): the 64 x 64 block would
 // multiply 75 % zeros (1.22 ms vs 0.41 ms for the forward conv of the same layer).  The four waves become 2 input-channel tiles x 2
 // halves of the tile's pixel rows with 2 output-channel tiles each; the two pixel halves are summed through LDS at the end.
-template <int MODE, bool NARROW = false>
+// SPLIT (option f32_split): the products run on the bf16 matrix cores from two-way split operands (SplitBf16, common.h).
+// LDS holds one (hi | lo << 16) word per element in the exact kernel's layout; the reduction dimension of an MFMA is 16 pixels
+// (one tile row) x 2 parts: lane group q takes pixels q, q + 4, q + 8, q + 12 (the exact kernel's conflict-free bank pattern),
+// the dy fragment is expanded to its (H, H) and (L, L) forms once per row and meets every tap's (h, l) x fragment in two MFMAs.
+template <int MODE, bool NARROW = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
   using G = WGeo<MODE>;
   constexpr int KS = G::KS, S = G::S, PAD = G::PAD, TAPS = G::TAPS;
@@ -1702,12 +1706,39 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
   for (; tile < ntiles; tile += a.ksplit) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < X_IT; ++i) *reinterpret_cast<u32x4*>(xs + (p16 + 16 * i) * PS + ch4 * 4) = px[i];
+    for (int i = 0; i < X_IT; ++i) *reinterpret_cast<u32x4*>(xs + (p16 + 16 * i) * PS + ch4 * 4) = SPLIT ? SplitBf16::unit(px[i]) : px[i];
 #pragma unroll
-    for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(ds + (p16 + 16 * i) * PS + ch4 * 4) = pd[i];
+    for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(ds + (p16 + 16 * i) * PS + ch4 * 4) = SPLIT ? SplitBf16::unit(pd[i]) : pd[i];
     __syncthreads();
     if (tile + a.ksplit < ntiles) fetch(tile + a.ksplit);
     constexpr int YR = NARROW ? TH / 2 : TH;
+    if constexpr (SPLIT) {
+      const unsigned* xw = reinterpret_cast<const unsigned*>(xs);
+      const unsigned* dw = reinterpret_cast<const unsigned*>(ds);
+#pragma unroll
+      for (int yy = 0; yy < YR; ++yy) {
+        const int y = ph * YR + yy;
+        u32x4 ah[NC], al[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          u32x4 w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = dw[(y * 16 + 4 * j + q) * PS + c * 16 + i16];
+          ah[c] = SplitBf16::dup_hi(w); al[c] = SplitBf16::dup_lo(w);
+        }
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) {
+            u32x4 b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = xw[((y * S + kh) * XW + (4 * j + q) * S + kw) * PS + kq * 16 + i16];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[kh * KS + kw][c] = SplitBf16::mma_a(ah[c], al[c], b, acc[kh * KS + kw][c]);
+          }
+      }
+      continue;
+    }
 #pragma unroll
     for (int yy = 0; yy < YR; ++yy) {
       const int y = ph * YR + yy;
@@ -1986,7 +2017,15 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
   } else if (dtype == MIA_F32 && chan_ok && (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 4 < lim &&
              (size_t)hy * wy * cdy * 4 < lim) {
     const bool narrow = cdy <= 32 && c1 <= 32 && c2 <= 32;  // 32-channel layers: half-width blocks, all four waves busy
-    if (narrow) {
+    if (o.f32_split) {  // fp32 tensors, split-bf16 products
+      if (narrow) {
+        if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, true, true>), fgrid, dim3(256), 0, st, a);
+        else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S2, true, true>), fgrid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W2S2, true, true>), fgrid, dim3(256), 0, st, a);
+      } else if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, false, true>), fgrid, dim3(256), 0, st, a);
+      else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S2, false, true>), fgrid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W2S2, false, true>), fgrid, dim3(256), 0, st, a);
+    } else if (narrow) {
       if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, true>), fgrid, dim3(256), 0, st, a);
       else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S2, true>), fgrid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W2S2, true>), fgrid, dim3(256), 0, st, a);

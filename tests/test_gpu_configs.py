@@ -209,6 +209,20 @@ def test_cfg1_tiny_fp32_engine_step_vs_oracle():
     assert (got.argmax(1)[safe] == want.argmax(1)[safe]).all()
 
 
+@pytest.mark.parametrize("channels,size,n", [([16, 32, 64], 128, 4), ([32, 64, 128, 256, 512], 128, 2), ([64, 128, 256, 512, 1024], 128, 2)])
+def test_f32_split_train_step_meets_the_fp32_gates(channels, size, n):
+    """Option f32_split (fp32 tensors, split-bf16 products on the matrix cores: csrc/common.h SplitBf16) under the SAME gates as
+    the exact fp32 path: cfg1's, cfg4's and cfg2's networks, one train step against oracle/train_ref -- logits / loss 1e-4, label
+    maps exact off ties, gradients by `_check_grads_vs_exact`, clip norm, post-AdamW state."""
+    import mia_hip
+    old = mia_hip.get_option("f32_split")
+    mia_hip.set_option("f32_split", 1)
+    try:
+        _fp32_step_vs_oracle(channels, "instance", size, n, seed=5)
+    finally:
+        mia_hip.set_option("f32_split", old)
+
+
 def test_full_width_bf16_train_step_vs_fp32_oracle():
     """The benchmark's dtype at the benchmark's widths vs the fp32 CPU oracle: logits, loss, label maps, every weight
     gradient (tolerances and their derivation: BF16_* above)."""

@@ -1413,3 +1413,102 @@ def test_head_weight_gradient_in_the_norm_backward_reduction_pass(dtype, k1):
             assert relerr(res[True][k], res[False][k]) < 2e-5, k
         else:
             assert torch.equal(res[False][k], res[True][k]), k
+
+
+# fp32 tensors, products on the bf16 matrix cores from two-way split operands (option f32_split, csrc/common.h SplitBf16): every
+# operand element enters as hi + lo with 16-17 significant bits, products are exact, accumulation is fp32 -- so a result differs
+# from the exact fp32 kernel by at most ~2^-16 of sum |x||w| per element (measured: 1e-5 of the output range).
+SPLIT_TOL = 6e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 0, 64, 40, 56), (1, 128, 0, 256, 24, 40), (1, 64, 64, 64, 33, 47), (2, 32, 0, 32, 36, 52),
+                                  (1, 256, 0, 128, 17, 33), (2, 16, 0, 48, 20, 28), (1, 96, 96, 96, 24, 40)])
+def test_f32_split_conv_and_weight_gradient_close_to_exact(case):
+    """Option f32_split: 3x3 forward (stride 1 and 2), both input gradients and both weight gradients in fp32 on split-bf16
+    products -- within SPLIT_TOL (max-norm, relative) of fp32-CPU math AND of the exact fp32 kernels, and not bit-equal to
+    them (the split kernels are the ones that ran)."""
+    import mia_hip
+    from mia_hip import ops, CONV_G3S1, CONV_G3S2, CONV_T3S2, WGRAD_3S1, WGRAD_3S2
+    dev = _dev()
+    n, c1, c2, cout, h, w = case
+    cin = c1 + c2
+    g = torch.Generator().manual_seed(cin + cout + h)
+    old = mia_hip.get_option("f32_split")
+    try:
+        for stride in (1, 2):
+            x = torch.randn(n, cin, h, w, generator=g)
+            wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+            b = torch.randn(cout, generator=g)
+            ho, wo = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
+            dy = torch.randn(n, cout, ho, wo, generator=g)
+            xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+            yr = F.conv2d(xr.double(), wr.double(), b.double(), stride=stride, padding=1)
+            yr.backward(dy.double())
+            x1 = nhwc(x[:, :c1], torch.float32, dev)
+            x2 = nhwc(x[:, c1:], torch.float32, dev) if c2 else None
+            dyd = nhwc(dy, torch.float32, dev)
+            wd = wt.to(dev)
+            res = {}
+            for flag in (0, 1):
+                mia_hip.set_option("f32_split", flag)
+                pc = ops.PackCache()
+                wp, npad, kpad = pc.get(wd, mia_hip.F32, True)
+                wb, npb, kpb = pc.get(wd, mia_hip.F32, False)
+                y, _, stats = ops.conv_mma(CONV_G3S2 if stride == 2 else CONV_G3S1, x1, x2, wp, npad, kpad, False, b.to(dev), cout, (ho, wo),
+                                           want_stats=True)
+                split = c1 if c2 else None
+                if stride == 2:
+                    dx1, dx2, _ = ops.conv_mma(CONV_T3S2, dyd, None, wb, npb, kpb, False, None, cin, (h, w), out_split=split)
+                else:
+                    dx1, dx2, _ = ops.conv_mma(CONV_G3S1, dyd, None, wb, npb, kpb, True, None, cin, (h, w), out_split=split)
+                dx = nchw(dx1) if dx2 is None else torch.cat([nchw(dx1), nchw(dx2)], 1)
+                dw = ops.conv_wgrad(WGRAD_3S2 if stride == 2 else WGRAD_3S1, x1, x2, dyd, wt.shape, cout, cin).cpu()
+                res[flag] = (nchw(y), stats.sum(1).cpu(), dx, dw)
+            (y0, s0, dx0, dw0), (y1, s1, dx1_, dw1) = res[0], res[1]
+            for name, exact, got, want in (("y", y0, y1, yr), ("dx", dx0, dx1_, xr.grad), ("dw", dw0, dw1, wr.grad)):
+                assert relerr(exact, want) < TOL[torch.float32], (name, stride)
+                assert relerr(got, want) < SPLIT_TOL, (name, stride, relerr(got, want))
+                assert relerr(got, exact) < SPLIT_TOL, (name, stride)
+                assert not torch.equal(got, exact), (name, stride, "the split kernel did not run")
+            assert relerr(s1[..., 0], yr.detach().sum((2, 3))) < 1e-3
+            assert relerr(s1[..., 1], (yr.detach() ** 2).sum((2, 3))) < 1e-3
+    finally:
+        mia_hip.set_option("f32_split", old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 128, 64, 20, 28), (1, 64, 32, 33, 17), (1, 512, 256, 8, 12)])
+def test_f32_split_transposed_conv_close_to_exact(case):
+    """Option f32_split on the ConvTranspose 2x2 / stride 2 trio (forward, input gradient, weight gradient) in fp32."""
+    import mia_hip
+    from mia_hip import ops, CONV_G2S2, CONV_T2S2, WGRAD_2S2
+    dev = _dev()
+    n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(cin + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, 2, 2, generator=g) / math.sqrt(cin)
+    b = torch.randn(cout, generator=g)
+    dy = torch.randn(n, cout, 2 * h, 2 * w, generator=g)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr.double(), wr.double(), b.double(), stride=2)
+    yr.backward(dy.double())
+    xd, dyd, wd = nhwc(x, torch.float32, dev), nhwc(dy, torch.float32, dev), wt.to(dev)
+    old = mia_hip.get_option("f32_split")
+    res = {}
+    try:
+        for flag in (0, 1):
+            mia_hip.set_option("f32_split", flag)
+            pc = ops.PackCache()
+            wf, nf, kf = pc.get(wd, mia_hip.F32, False)
+            wb, nb, kb = pc.get(wd, mia_hip.F32, True)
+            y, _, _ = ops.conv_mma(CONV_T2S2, xd, None, wf, nf, kf, False, b.to(dev), cout, (2 * h, 2 * w))
+            dx, _, _ = ops.conv_mma(CONV_G2S2, dyd, None, wb, nb, kb, False, None, cin, (h, w))
+            dw = ops.conv_wgrad(WGRAD_2S2, dyd, None, xd, wt.shape, cin, cout).cpu()
+            res[flag] = (nchw(y), nchw(dx), dw)
+    finally:
+        mia_hip.set_option("f32_split", old)
+    for name, exact, got, want in zip(("y", "dx", "dw"), res[0], res[1], (yr, xr.grad, wr.grad)):
+        assert relerr(exact, want) < TOL[torch.float32], name
+        assert relerr(got, want) < SPLIT_TOL, (name, relerr(got, want))
+        assert not torch.equal(got, exact), (name, "the split kernel did not run")
