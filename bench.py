@@ -522,6 +522,9 @@ def main():
                                       f"dropout {drop}, Dice+CE, Adam(wd 5e-4), clip 10 ({args.config})",
                           "global_batch": world * batch, "parallelism": f"dp{world}"},
                "final_loss": round(loss_v, 6), "roofline": roof}
+        if dt == "f32":  # fp32 tensors either way; 1 = conv / weight-gradient products from split-bf16 operands (DESIGN: fp32 on the bf16 matrix cores)
+            import mia_hip
+            out["config"]["f32_split"] = int(mia_hip.get_option("f32_split"))
         if elapsed_noaug is not None:
             out["value_without_augmentation"] = round(world * batch * args.steps / elapsed_noaug, 2)
             out["ms_per_step_without_augmentation"] = round(1e3 * elapsed_noaug / args.steps, 3)
