@@ -250,6 +250,9 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1,
                     help="Dropout2d probability of every PlainBlock (al_train default 0.1, al_trainer.py:109); 0 = None")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the train step from a captured hipGraph (TrainEngine(graph=True); single GPU; for the launch-bound small "
+                         "configs: the per-launch roofline probes cannot see into a replay, so `roofline` is omitted)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -296,7 +299,8 @@ def main():
     loss_fn = DiceAndCELoss(dice_loss=DiceLoss, dice_kwargs=dict(num_classes=2, smooth=1e-5, do_bg=True, softmax=True,
                                                                  batch=False, squared=False),
                             ce_loss=torch.nn.CrossEntropyLoss, ce_kwargs={})
-    eng = TrainEngine(model, loss_fn, "adam", {"weight_decay": 5e-4}, start_lr=1e-3, num_iters=4000, lr_warmup_iter=250)
+    eng = TrainEngine(model, loss_fn, "adam", {"weight_decay": 5e-4}, start_lr=1e-3, num_iters=4000, lr_warmup_iter=250,
+                      graph=bool(args.graph))
     img, lab = synth_batch(batch, size, 1337 + rank)
     batch_d = {"image": img.to(dev), "label": lab.to(dev)}  # resident in HBM before timing
     aug = aug_in = None
@@ -384,11 +388,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, TrainEngine.GRAPH_WARMUP + 1) if args.graph else args.warmup):  # graph mode: past the capture
         loss = one_step()
     sync()
-    probe.enabled = True
-    stream_on[0] = True
+    probe.enabled = not args.graph
+    stream_on[0] = not args.graph
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
@@ -529,6 +533,8 @@ def main():
                                       f"dropout {drop}, Dice+CE, Adam(wd 5e-4), clip 10 ({args.config})",
                           "global_batch": world * batch, "parallelism": f"dp{world}"},
                "final_loss": round(loss_v, 6), "roofline": roof}
+        if args.graph:
+            out["config"]["graph"] = "train step replayed from one captured hipGraph"
         if dt == "f32":  # fp32 tensors either way; 1 = conv / weight-gradient products from split-bf16 operands (DESIGN: fp32 on the bf16 matrix cores)
             import mia_hip
             out["config"]["f32_split"] = int(mia_hip.get_option("f32_split"))

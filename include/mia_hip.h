@@ -50,6 +50,9 @@ int mia_add(const void* a, const void* b, void* out, int dtype, int64_t n, void*
 /* out[c] (+)= sum over p rows of x[p][c]: bias gradients of Conv2d / ConvTranspose2d. */
 /* Dropout2d channel masks (blocks.py:92-96): out[i] = 1/keep with probability keep, else 0 (Philox4x32-10 keyed by seed, offset) */
 int mia_dropout_mask(float* out, int64_t n, float keep, uint64_t seed, uint64_t offset, void* stream);
+/* the same with seed and base offset read from device memory (seed_base[0], seed_base[1]; the launch uses offset seed_base[1] +
+ * rel_offset): for a train step replayed from a captured hipGraph, whose kernel arguments are frozen (training/engine.py graph mode) */
+int mia_dropout_mask_dyn(float* out, int64_t n, float keep, const uint64_t* seed_base, uint64_t rel_offset, void* stream);
 /* optimizer.zero_grad() (al_trainer.py:1375) on a flat buffer: bytes % 16 == 0, 16-byte aligned */
 int mia_zero(void* p, int64_t bytes, void* stream);
 /* dst[i] = src[i * stride], fp32 (per-channel sums out of interleaved statistics) */
@@ -321,6 +324,13 @@ int mia_scale_by_clip(float* x, int64_t n, const float* clip, void* stream);
 int mia_optim_step(float* param, const float* grad, float* m, float* v, int64_t n, int kind, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, int first_step,
                    const float* clip, float grad_scale, void* stream);
+/* mia_optim_step with the per-step scalars read from device memory: dyn = {lr, bias_corr1, bias_corr2, first_step != 0} (fp32[4]),
+ * rewritten by the host before every replay of a captured step (PolyLRScheduler, al_trainer.py:1366-1379) */
+/* writes dyn (32 bytes, 16-byte aligned: fp32 {lr, bias_corr1, bias_corr2, first_step}, u64 {Philox seed, base offset}) from kernel
+ * ARGUMENTS -- safe however far the host runs ahead of the device; the u64 half is what mia_dropout_mask_dyn reads */
+int mia_step_dyn_set(void* dyn32, float lr, float bias_corr1, float bias_corr2, int first_step, uint64_t seed, uint64_t offset, void* stream);
+int mia_optim_step_dyn(float* param, const float* grad, float* m, float* v, int64_t n, int kind, float beta1, float beta2, float eps,
+                       float weight_decay, const float* dyn, const float* clip, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------ augmentation / resize / normalisation (src/transforms) */
 /* images [B][C][H][W] fp32, labels [B][H][W] int64, per-sample parameter arrays on the device;

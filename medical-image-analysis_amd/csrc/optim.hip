@@ -60,10 +60,13 @@ extern "C" int mia_grad_norm(const float* grad, int64_t n, float max_norm, float
 #define OPT_SGD 2
 
 // hp (device, fp32): [0]=lr [1]=bias_correction1 [2]=bias_correction2 (host computes 1-beta^t in double)
+// dyn (device, fp32[4]; nullptr = use the arguments): lr, bias_correction1, bias_correction2, first_step != 0 -- the per-step
+// scalars of a step that is replayed from a captured hipGraph (mia_optim_step_dyn), where kernel arguments are frozen
 __global__ void optim_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                   float* __restrict__ v, int64_t n, int kind, float lr, float beta1, float beta2, float eps,
                                   float wd, float bc1, float bc2, int first_step, const float* __restrict__ clip,
-                                  float grad_scale) {
+                                  float grad_scale, const float* __restrict__ dyn) {
+  if (dyn != nullptr) { lr = dyn[0]; bc1 = dyn[1]; bc2 = dyn[2]; first_step = dyn[3] != 0.f; }
   const float cs = (clip ? clip[1] : 1.f) * grad_scale;
   const float sq_bc2 = sqrtf(bc2);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -93,7 +96,37 @@ extern "C" int mia_optim_step(float* param, const float* grad, float* m, float* 
   MIA_CHECK_ARG(kind >= OPT_ADAM && kind <= OPT_SGD, "mia_optim_step: unknown optimizer %d", kind);
   const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
   hipLaunchKernelGGL(optim_step_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad, m, v, n, kind,
-                     lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, first_step, clip, grad_scale);
+                     lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, first_step, clip, grad_scale, (const float*)nullptr);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// The 32 bytes a captured step reads its per-iteration scalars from (fp32 {lr, bc1, bc2, first}, u64 {seed, base offset}), written
+// by a one-thread kernel whose ARGUMENTS carry the values: they are copied when the launch is enqueued, so a host that runs many
+// replays ahead of the device cannot overwrite a staging buffer the device has not read yet (a pinned async copy could).
+__global__ void step_dyn_set_kernel(float* __restrict__ f, float lr, float bc1, float bc2, float first, unsigned long long seed,
+                                    unsigned long long offset) {
+  f[0] = lr; f[1] = bc1; f[2] = bc2; f[3] = first;
+  unsigned long long* u = reinterpret_cast<unsigned long long*>(f + 4);
+  u[0] = seed; u[1] = offset;
+}
+extern "C" int mia_step_dyn_set(void* dyn32, float lr, float bias_corr1, float bias_corr2, int first_step, uint64_t seed, uint64_t offset,
+                                void* stream) {
+  MIA_CHECK_ARG(dyn32 && (reinterpret_cast<uintptr_t>(dyn32) & 15) == 0, "mia_step_dyn_set: needs a 16-byte aligned 32-byte device buffer");
+  hipLaunchKernelGGL(step_dyn_set_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), static_cast<float*>(dyn32), lr, bias_corr1,
+                     bias_corr2, first_step ? 1.f : 0.f, (unsigned long long)seed, (unsigned long long)offset);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+extern "C" int mia_optim_step_dyn(float* param, const float* grad, float* m, float* v, int64_t n, int kind, float beta1, float beta2,
+                                  float eps, float weight_decay, const float* dyn, const float* clip, float grad_scale, void* stream) {
+  MIA_CHECK_ARG(param && grad && m && n > 0 && dyn, "mia_optim_step_dyn: bad arguments");
+  MIA_CHECK_ARG(kind == OPT_SGD || v != nullptr, "mia_optim_step_dyn: Adam needs second-moment buffer");
+  MIA_CHECK_ARG(kind >= OPT_ADAM && kind <= OPT_SGD, "mia_optim_step_dyn: unknown optimizer %d", kind);
+  const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(optim_step_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad, m, v, n, kind,
+                     0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, 0, clip, grad_scale, dyn);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

@@ -322,7 +322,11 @@ __device__ __forceinline__ void philox_round_u(unsigned& c0, unsigned& c1, unsig
   const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
   c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
-__global__ void dropout_mask_kernel(float* __restrict__ out, int64_t n, float keep, unsigned long long seed, unsigned long long offset) {
+// dyn (device, u64[2]; nullptr = use the arguments): seed and BASE offset of a step replayed from a captured hipGraph; `offset` is
+// then the launch's fixed distance from that base (mia_dropout_mask_dyn)
+__global__ void dropout_mask_kernel(float* __restrict__ out, int64_t n, float keep, unsigned long long seed, unsigned long long offset,
+                                    const unsigned long long* __restrict__ dyn) {
+  if (dyn != nullptr) { seed = dyn[0]; offset += dyn[1]; }
   const int64_t quads = (n + 3) / 4;
   const float scale = 1.f / keep;
   for (int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; qd < quads; qd += (int64_t)gridDim.x * blockDim.x) {
@@ -343,7 +347,16 @@ extern "C" int mia_dropout_mask(float* out, int64_t n, float keep, uint64_t seed
   const int64_t quads = (n + 3) / 4;
   const int blocks = (int)((quads + 255) / 256 < 1024 ? (quads + 255) / 256 : 1024);
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), out, n, keep,
-                     (unsigned long long)seed, (unsigned long long)offset);
+                     (unsigned long long)seed, (unsigned long long)offset, (const unsigned long long*)nullptr);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+extern "C" int mia_dropout_mask_dyn(float* out, int64_t n, float keep, const uint64_t* seed_base, uint64_t rel_offset, void* stream) {
+  MIA_CHECK_ARG(out && n > 0 && keep > 0.f && keep <= 1.f && seed_base, "mia_dropout_mask_dyn: bad arguments (keep=%f)", (double)keep);
+  const int64_t quads = (n + 3) / 4;
+  const int blocks = (int)((quads + 255) / 256 < 1024 ? (quads + 255) / 256 : 1024);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), out, n, keep, 0ull,
+                     (unsigned long long)rel_offset, reinterpret_cast<const unsigned long long*>(seed_base));
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }

@@ -410,12 +410,46 @@ def _slabs_for(hw: int) -> int:
 
 
 # ------------------------------------------------------------------ Dropout2d masks
+class StepDyn:
+    """Per-step scalars of a train step that is replayed from a captured hipGraph (training/engine.py graph mode).  Kernel
+    arguments are frozen at capture, so what changes every iteration lives in 32 bytes of device memory that the host rewrites
+    (one one-thread launch, `mia_step_dyn_set`) before each replay: fp32 {lr, 1 - beta1^t, 1 - beta2^t, first step} for `mia_optim_step_dyn`
+    and u64 {Philox seed, base offset} for `mia_dropout_mask_dyn` (each mask launch adds its fixed distance from the base).
+    While `ops._STEP_DYN` is set, `optim_step` and `dropout_mask` take these variants."""
+
+    def __init__(self, device):
+        self.dev = torch.zeros(32, dtype=torch.uint8, device=device)
+        self.rng_span = 0   # Philox offsets one step consumes (counted while capturing)
+
+    def set(self, lr: float, bc1: float, bc2: float, first: bool, seed: int, base_offset: int) -> None:
+        """One one-thread launch whose arguments carry the values (copied at enqueue time: the host may run any number of
+        replays ahead of the device, which a pinned staging buffer + async copy would not survive)."""
+        call("mia_step_dyn_set", _p(self.dev), _c_float(lr), _c_float(bc1), _c_float(bc2), int(bool(first)),
+             ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(base_offset), _stream())
+
+    @property
+    def f32_ptr(self):
+        return ctypes.c_void_p(self.dev.data_ptr())
+
+    @property
+    def u64_ptr(self):
+        return ctypes.c_void_p(self.dev.data_ptr() + 16)
+
+
+_STEP_DYN: Optional[StepDyn] = None
+
+
 def dropout_mask(numel: int, keep: float, device) -> torch.Tensor:
     """`numel` Dropout2d channel multipliers in {0, 1/keep} (reference blocks.py:92-96) from the library's Philox kernel.
     Keyed by the device generator's (seed, offset) -- the pair torch.manual_seed / set_rng_state control, so runs are
     reproducible and per-rank seeds give per-rank masks (al_trainer.py:282-288) -- and the offset is advanced on the host
     like a PyTorch CUDA RNG consumer would: no host random numbers are drawn and no PyTorch kernel runs."""
     dev = torch.device(device)
+    if _STEP_DYN is not None:  # captured step: seed / base offset come from device memory, this launch sits `rng_span` past the base
+        out = torch.empty(numel, device=dev, dtype=torch.float32)
+        call("mia_dropout_mask_dyn", _p(out), _c_i64(numel), _c_float(keep), _STEP_DYN.u64_ptr, ctypes.c_uint64(_STEP_DYN.rng_span), _stream())
+        _STEP_DYN.rng_span += 4 * ((numel + 3) // 4)
+        return out
     gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
     seed, off = int(gen.initial_seed()), int(gen.get_offset())
     gen.set_offset(off + 4 * ((numel + 3) // 4))
@@ -1030,6 +1064,10 @@ def grad_norm(flat_grad: torch.Tensor, max_norm: float, grad_scale: float = 1.0)
 
 def optim_step(kind: int, param, grad, m, v, lr, beta1, beta2, eps, wd, step: int, clip: Optional[torch.Tensor],
                grad_scale: float = 1.0):
+    if _STEP_DYN is not None:  # captured step: lr / bias corrections / first-step flag are read from device memory
+        call("mia_optim_step_dyn", _p(param), _p(grad), _p(m), _p(v), _c_i64(param.numel()), kind, _c_float(beta1), _c_float(beta2),
+             _c_float(eps), _c_float(wd), _STEP_DYN.f32_ptr, _p(clip), _c_float(grad_scale), _stream())
+        return
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
     call("mia_optim_step", _p(param), _p(grad), _p(m), _p(v), _c_i64(param.numel()), kind, _c_float(lr), _c_float(beta1),

@@ -256,6 +256,11 @@ class GradBucketReducer:
         return 1.0 / self.world
 
 
+class _CapturedStep:
+    """A captured train step: static inputs, the device-resident per-step scalars, the graph, the static loss."""
+    __slots__ = ("img", "lab", "dyn", "graph", "loss")
+
+
 class TrainEngine:
     """One object = model + loss + flat optimizer + poly LR (+ DP reducer).  ``train_step`` returns the loss
     TENSOR (no host sync); call ``.item()`` only when you log."""
@@ -263,8 +268,14 @@ class TrainEngine:
     def __init__(self, model, loss_fn, optimizer_name: str = "adam", optimizer_kwargs: Optional[dict] = None,
                  start_lr: float = 1e-3, num_iters: int = 4000, lr_warmup_iter: int = 250, lr_interval: int = 1,
                  lr_scheduler_name: str = "poly", grad_norm: float = 10.0, process_group=None, bucket_bytes: int = 16 << 20,
-                 sync_batchnorm: Optional[bool] = None, force_reducer: bool = False, dp_reserve_cus: Optional[int] = None):
+                 sync_batchnorm: Optional[bool] = None, force_reducer: bool = False, dp_reserve_cus: Optional[int] = None,
+                 graph: Optional[bool] = None):
         """force_reducer: see GradBucketReducer(force=...).
+        graph: replay the whole step (forward, loss, backward, clip, optimizer, weight re-pack) from ONE captured hipGraph
+        (`torch.cuda.CUDAGraph`) after `GRAPH_WARMUP` eager steps -- for small models whose step is launch-bound (cfg1: ~117
+        launches for 1.1 ms of kernels).  Same kernels, same order, same arithmetic as the eager step: the values that change per
+        iteration (poly LR, Adam bias corrections, Dropout2d Philox offsets) are read from device memory (`ops.StepDyn`).
+        Single-rank only (the RCCL reducer is not captured); one graph per input shape; None = env MIA_ENGINE_GRAPH (default 0).
         dp_reserve_cus: CUs the persistent conv / weight-gradient kernels leave free for RCCL's ring kernels (library option
         `reserve_cus`, include/mia_hip.h).  None (default) = DP_RESERVE_CUS (8: one CU per XCD) when the group has more than
         one rank, else untouched; 0 = never reserve.  Why: the persistent kernels take one 512-thread workgroup per CU on a
@@ -308,6 +319,61 @@ class TrainEngine:
         self.reducer = GradBucketReducer(self.optimizer, process_group, force=force_reducer)
         self.current_iter = 0
         self._one = None
+        if graph is None:
+            graph = os.environ.get("MIA_ENGINE_GRAPH", "0") != "0"
+        if graph and (self.reducer.world > 1 or self.reducer.force or not next(model.parameters()).is_cuda):
+            raise ValueError("TrainEngine(graph=True) captures a single-rank step on a HIP device (the RCCL reducer is not captured)")
+        self.graph_mode = bool(graph)
+        self._graphs: Dict[tuple, "_CapturedStep"] = {}
+        self._eager_steps = 0
+
+    GRAPH_WARMUP = 3  # eager steps before capture: lazy module loads, PackPlan creation (step 2), allocator warm-up
+
+    def _capture(self, image: torch.Tensor, label: torch.Tensor) -> "_CapturedStep":
+        """Record one train step on static input buffers.  Nothing executes while capturing: the optimizer's step counter and
+        the device generator are left where they were, and the first replay performs the step."""
+        opt = self.optimizer
+        g = _CapturedStep()
+        g.img, g.lab = torch.empty_like(image), torch.empty_like(label)
+        g.dyn = ops.StepDyn(image.device)
+        if self._one is None:
+            self._one = torch.ones((), device=image.device, dtype=torch.float32)
+        saved = (opt.step_count, set(opt.stepped))
+        torch.cuda.synchronize()
+        g.graph = torch.cuda.CUDAGraph()
+        ops._STEP_DYN = g.dyn
+        try:
+            with torch.cuda.graph(g.graph, capture_error_mode="thread_local"):
+                output = self.model(g.img)
+                loss = self.loss_fn(output, g.lab)
+                opt.zero_grad()
+                loss.backward(self._one if self._one.shape == loss.shape else torch.ones_like(loss))
+                opt.step(max_grad_norm=self.grad_norm, grad_scale=self.reducer.grad_scale)
+                g.loss = loss.detach()
+        finally:
+            ops._STEP_DYN = None
+            opt.step_count, opt.stepped = saved
+        return g
+
+    def _train_step_graph(self, image: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+        key = (tuple(image.shape), tuple(label.shape))
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = self._capture(image, label)
+        opt = self.optimizer
+        pg = opt.param_groups[0]
+        opt.step_count += 1
+        b1, b2 = (pg["momentum"], 0.0) if opt.kind == OPT_SGD else pg["betas"]
+        dev = image.device
+        gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+        seed, off = int(gen.initial_seed()), int(gen.get_offset())
+        gen.set_offset(off + g.dyn.rng_span)  # what the eager step's mask launches would have consumed
+        g.dyn.set(float(pg["lr"]), 1.0 - b1 ** opt.step_count, 1.0 - b2 ** opt.step_count, opt.step_count == 1, seed, off)
+        g.img.copy_(image, non_blocking=True)
+        g.lab.copy_(label, non_blocking=True)
+        g.graph.replay()
+        opt.stepped.update(id(p) for p in opt.params if p.grad is not None)
+        return g.loss.clone()
 
     def train_step(self, sampled_batch) -> torch.Tensor:
         self.model.train()
@@ -316,6 +382,11 @@ class TrainEngine:
         dev = self.optimizer.flat_param.device
         image = sampled_batch["image"].to(dev, dtype=torch.float32, non_blocking=True)
         label = sampled_batch["label"].to(dev, dtype=torch.long, non_blocking=True)
+        if self.graph_mode and self._eager_steps >= self.GRAPH_WARMUP:
+            loss = self._train_step_graph(image.contiguous(), label.contiguous())
+            self.current_iter += 1
+            return loss
+        self._eager_steps += 1
         output = self.model(image)
         loss = self.loss_fn(output, label)
         self.optimizer.zero_grad()
