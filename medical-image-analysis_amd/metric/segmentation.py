@@ -72,12 +72,10 @@ def valid_slices(model, processor, image_batch: torch.Tensor, label_batch: torch
     `metric_all[b]` = Dice(pred > 0, label > 0), `metric_per_cls[b, c-1]` = Dice(pred == c, label == c), c = 1..num_classes,
     0 for an empty prediction (:1463-1472, :1539-1556).  Hausdorff / ASD / Jaccard columns of the reference's [B,4] arrays are
     CPU medpy / SimpleITK work and are not produced.  Returns (metric_all [B], metric_per_cls [B, num_classes], loss, pred)
-    -- device tensors, no host sync.  `do_denoise` is the reference's `config.postprocess_mask` (al_trainer.py:1445): the cv2
-    connected-component filter (unet_processor.py:72-135) is not built (cv2 is not importable), so True raises.  The model's
-    train / eval mode is restored on every exit path."""
+    -- device tensors, no host sync.  `do_denoise` is the reference's `config.postprocess_mask` (al_trainer.py:1445): the
+    morphology of unet_processor.py:72-160 as batched tensor ops on the device (`UnetProcessor.denoise_masks`; parity with cv2 itself is
+    unpinned -- cv2 is not importable here).  The model's train / eval mode is restored on every exit path."""
     from transforms.hip import functional_hip as FH
-    if do_denoise:
-        raise NotImplementedError("valid_slices(do_denoise=True): the cv2 mask denoise (unet_processor.py:72-135) is not built")
     dev = next(model.parameters()).device
     image = image_batch.to(dev, dtype=torch.float32)
     label = label_batch.to(dev).long()
@@ -93,7 +91,7 @@ def valid_slices(model, processor, image_batch: torch.Tensor, label_batch: torch
             if pred.shape[-2:] != label.shape[-2:]:
                 ll = FH.resize_nearest(label.unsqueeze(1), int(output.shape[-2]), int(output.shape[-1])).squeeze(1)
             loss = loss_fn(output, ll)
-        pred = processor.postprocess(pred, label.shape[-2:], do_denoise=False)
+        pred = processor.postprocess(pred, label.shape[-2:], do_denoise=do_denoise)
     finally:
         model.train(was_training)
     k1 = num_classes + 1

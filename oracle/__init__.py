@@ -26,4 +26,9 @@ Pinning status
   absent from /root/reference and not installed here.  They are restated from
   torchvision's published algorithm and pinned by analytic known-answer tests
   only (see `tests/test_oracle_transforms.py`).
+* `UnetProcessor.denoise_one_mask` (`oracle/processor_ref.py`, scipy.ndimage): PARITY
+  UNPINNED.  The reference calls cv2 (not importable here, no fixture held); the
+  restatement follows OpenCV's documented uint8 arithmetic (rectangular dilate /
+  erode ignoring outside pixels, the fixed small-kernel Gaussian table in 8.8
+  fixed point with REFLECT_101, threshold > 127) and has known-answer tests.
 """
