@@ -105,39 +105,56 @@ struct MiaPackDesc {
   int brick_begin, bricks_x;  // first brick of this tensor in the launch; bricks along D1
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const MiaPackDesc* __restrict__ descs, int count) {
-  extern __shared__ float tile[];
-  __shared__ int which;
-  if (threadIdx.x == 0) {  // bisection over the running brick counts (a linear scan cost ~50 dependent loads per block: round 4)
-    int lo = 0, hi = count;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if ((int)blockIdx.x >= descs[mid].brick_begin) lo = mid; else hi = mid;
-    }
-    which = lo;
-  }
-  __syncthreads();
-  const MiaPackDesc d = descs[which];
-  const int brick = blockIdx.x - d.brick_begin;
+// One brick with a compile-time tap count (TAPS = 0: run-time) so the index arithmetic divides by constants.  Measured (round 4): neither
+// this nor the one-latency descriptor lookup below moved the launch (0.21 ms per cfg3 step = 1.75 TB/s for 372 MB): what bounds it is
+// the 128-byte destination segments scattered over the tap planes, i.e. the brick shape -- a 32 n x 128 k brick staged as bf16 is the
+// next thing to try (0.3 % of the step).
+template <typename T, int TAPS>
+__device__ __forceinline__ void pack_brick(const MiaPackDesc& d, int brick, float* tile) {
+  const int taps = TAPS ? TAPS : d.taps;
   const int TA = d.n_from_d0 ? 16 : 64, TB = d.n_from_d0 ? 64 : 16;
-  const int taps = d.taps, pitch = TB * taps + 1, run = TB * taps;
+  const int pitch = TB * taps + 1, run = TB * taps;
   const int a0 = (brick / d.bricks_x) * TA, b0 = (brick % d.bricks_x) * TB;
-  for (int i = threadIdx.x; i < TA * run; i += 256) {
-    const int a = i / run, r = i - a * run;
+  // source rows: TB * taps contiguous floats each; a thread walks one row position across the TA rows
+  for (int r = threadIdx.x; r < run; r += 256) {
     const int b = r / taps;
-    float v = 0.f;
-    if (a0 + a < d.d0 && b0 + b < d.d1) v = d.src[((size_t)(a0 + a) * d.d1 + b0) * taps + r];
-    tile[a * pitch + r] = v;
+    const bool bok = b0 + b < d.d1;
+    const float* src = d.src + ((size_t)a0 * d.d1 + b0) * taps + r;
+    for (int a = 0; a < TA; ++a) tile[a * pitch + r] = (bok && a0 + a < d.d0) ? src[(size_t)a * d.d1 * taps] : 0.f;
   }
   __syncthreads();
   T* dst = static_cast<T*>(d.dst);
-  for (int i = threadIdx.x; i < taps * 16 * 64; i += 256) {
-    const int k = i % 64, n = (i / 64) % 16, t = i / (64 * 16);
+  const int k = threadIdx.x & 63, n_lo = threadIdx.x >> 6;  // 64 consecutive k per (tap, n) row: 128-byte (bf16) segments
+  for (int tn = n_lo; tn < taps * 16; tn += 4) {
+    const int n = tn & 15, t = tn >> 4;
     const int a = d.n_from_d0 ? n : k, b = d.n_from_d0 ? k : n;
     const int gn = (d.n_from_d0 ? a0 : b0) + n, gk = (d.n_from_d0 ? b0 : a0) + k;
     if (gn < d.npad && gk < d.kpad) dst[((size_t)t * d.npad + gn) * d.kpad + gk] = Elem<T>::cvt(tile[a * pitch + b * taps + t]);
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const MiaPackDesc* __restrict__ descs, int count) {
+  extern __shared__ float tile[];
+  __shared__ int which;
+  if (threadIdx.x < 64) {
+    // descriptor of this block's brick: the brick_begin values ascend, so it is the last one <= blockIdx.x.  Wave 0 loads 64 of
+    // them per step IN PARALLEL and counts with a ballot -- one memory latency instead of a bisection's ~6 dependent loads
+    int below = 0;
+    for (int base = 0; base < count; base += 64) {
+      const int i = base + (int)threadIdx.x;
+      const bool le = i < count && descs[i].brick_begin <= (int)blockIdx.x;
+      below += __popcll(__ballot(le));
+    }
+    if (threadIdx.x == 0) which = below - 1;
+  }
+  __syncthreads();
+  const MiaPackDesc d = descs[which];
+  const int brick = blockIdx.x - d.brick_begin;
+  if (d.taps == 9) pack_brick<T, 9>(d, brick, tile);
+  else if (d.taps == 4) pack_brick<T, 4>(d, brick, tile);
+  else if (d.taps == 1) pack_brick<T, 1>(d, brick, tile);
+  else pack_brick<T, 0>(d, brick, tile);
 }
 
 extern "C" int mia_pack_desc_bytes(void) { return (int)sizeof(MiaPackDesc); }
