@@ -486,8 +486,10 @@ def main():
                     # context, not a peak: what a synthetic loop with this block's mix (256 flop per HBM byte, 3-4 LDS reads per 8 MFMAs
                     # = the kernel's PMC 0.42-0.45 LDS instructions per MFMA, random bf16 operands) sustains under the board's power
                     # limit -- profiles/r04_mfma_power_frontier.txt (hbm = 2 rows, between ldsr 2 and 4)
-                    roof["power_frontier"] = {"hbm_GBps_at_this_mix": 4190.0, "mfma_TFLOPs_at_this_mix": 1071.0,
-                                              "frac_of_frontier": round(roof["achieved"] / 4190.0, 3),
+                    # (fused launch: + the transform's ~2 packed-fp32 VALU per MFMA -> 3.42 TB/s / 0.88 PF, the "+16pk" row)
+                    fr_gbs, fr_tf = (3420.0, 876.0) if fused else (4190.0, 1071.0)
+                    roof["power_frontier"] = {"hbm_GBps_at_this_mix": fr_gbs, "mfma_TFLOPs_at_this_mix": fr_tf,
+                                              "frac_of_frontier": round(roof["achieved"] / fr_gbs, 3),
                                               "hbm_GBps_with_no_lds_traffic": 4790.0, "mfma_only_TFLOPs": 2062.2,
                                               "source": "profiles/r04_mfma_power_frontier.txt (tools/probe/mfma_power.py)"}
             else:

@@ -12,7 +12,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-template <int SHAPE, int LDSR, int HBM>
+template <int SHAPE, int LDSR, int HBM, int VALU = 0>
 __global__ __launch_bounds__(256, 2) void mfma_loop(const u32x4* __restrict__ src, float* __restrict__ out, int iters, size_t src_units,
                                                     unsigned long long* __restrict__ clocks) {
   __shared__ u32x4 lds[4096];  // 64 KB
@@ -38,6 +38,9 @@ __global__ __launch_bounds__(256, 2) void mfma_loop(const u32x4* __restrict__ sr
   u32x4 gacc = {0, 0, 0, 0};
   const unsigned long long t0 = __builtin_readcyclecounter();
   const unsigned long long r0 = wall_clock64();
+  typedef float vf2 __attribute__((ext_vector_type(2)));
+  vf2 vacc[4] = {{1.f, 2.f}, {3.f, 4.f}, {5.f, 6.f}, {7.f, 8.f}};
+  const vf2 vk = {0.999f, 1.001f};
   u32x4 n[8], ring[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { n[i] = a[i]; ring[i] = a[i]; }
@@ -52,6 +55,10 @@ __global__ __launch_bounds__(256, 2) void mfma_loop(const u32x4* __restrict__ sr
 #pragma unroll
     for (int r = 0; r < LDSR; ++r) nxt[r & 7] = lds[(off + 64 * r) & 4095];
     off += 37;
+    if constexpr (VALU > 0) {  // VALU packed-fp32 FMAs per group on their own registers (the normalise-on-load transform: ~2 per MFMA)
+#pragma unroll
+      for (int i = 0; i < VALU; ++i) vacc[i & 3] = __builtin_elementwise_fma(vacc[i & 3], vk, vacc[(i + 1) & 3]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SHAPE == 0) {
 #pragma unroll
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void mfma_loop(const u32x4* __restrict__ sr
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
   const unsigned long long r1 = wall_clock64();
-  float s = (float)(gacc[0] ^ gacc[1] ^ gacc[2] ^ gacc[3]);
+  float s = (float)(gacc[0] ^ gacc[1] ^ gacc[2] ^ gacc[3]) + vacc[0][0] + vacc[1][1] + vacc[2][0] + vacc[3][1];
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += c4[i][0] + c4[i][3];
 #pragma unroll
@@ -79,16 +86,20 @@ __global__ __launch_bounds__(256, 2) void mfma_loop(const u32x4* __restrict__ sr
   if (tid == 0 && blockIdx.x < 64) { clocks[2 * blockIdx.x] = t1 - t0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
-template <int SHAPE, int LDSR, int HBM>
+template <int SHAPE, int LDSR, int HBM, int VALU = 0>
 static int run(const void* src, void* out, int iters, size_t units, void* clocks, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL((mfma_loop<SHAPE, LDSR, HBM>), dim3(blocks), dim3(256), 0, st, (const u32x4*)src, (float*)out, iters, units, (unsigned long long*)clocks);
+  hipLaunchKernelGGL((mfma_loop<SHAPE, LDSR, HBM, VALU>), dim3(blocks), dim3(256), 0, st, (const u32x4*)src, (float*)out, iters, units, (unsigned long long*)clocks);
   return (int)hipGetLastError();
 }
 
-extern "C" int mfma_power_run(int shape, int ldsr, int hbm, const void* src, void* out, int iters, size_t units, void* clocks, int blocks, void* stream) {
+extern "C" int mfma_power_run(int shape, int ldsr, int hbm, int valu, const void* src, void* out, int iters, size_t units, void* clocks, int blocks, void* stream) {
   hipStream_t st = (hipStream_t)stream;
 #define CASE(S, L, H) if (shape == S && ldsr == L && hbm == H) return run<S, L, H>(src, out, iters, units, clocks, blocks, st);
 #define CASES(S, H) CASE(S, 0, H) CASE(S, 2, H) CASE(S, 4, H) CASE(S, 6, H) CASE(S, 8, H)
+  if (shape == 0 && ldsr == 4 && hbm == 2 && valu == 8) return run<0, 4, 2, 8>(src, out, iters, units, clocks, blocks, st);
+  if (shape == 0 && ldsr == 4 && hbm == 2 && valu == 16) return run<0, 4, 2, 16>(src, out, iters, units, clocks, blocks, st);
+  if (shape == 0 && ldsr == 4 && hbm == 2 && valu == 24) return run<0, 4, 2, 24>(src, out, iters, units, clocks, blocks, st);
+  if (valu != 0) return -2;
   CASES(0, 0) CASES(1, 0) CASES(0, 1) CASES(1, 1) CASES(0, 2) CASES(0, 4) CASES(0, 8)
   return -1;
 }
