@@ -49,7 +49,8 @@ def main():
         return x1, x0
 
     for case in range(a.cases):
-        kind = rng.choice(["conv_bt", "conv_pw", "conv_s2_wide", "conv64_dma", "wgrad_bt", "wgrad_bt_s2", "conv_pw_s2", "wgrad_t2"])
+        kind = rng.choice(["conv_bt", "conv_pw", "conv_s2_wide", "conv64_dma", "wgrad_bt", "wgrad_bt_s2", "conv_pw_s2", "wgrad_t2", "f32_split",
+                           "f32_split"])
         n = rng.choice([1, 2, 3])
         h, w = rng.randint(3, 70), rng.randint(3, 90)
         msg, ok = "", True
@@ -110,6 +111,47 @@ def main():
             r1, r0 = ab("conv64_dma", 2, fn)
             ok = relerr(r1[0], r0[0]) < 1e-2 and (r1[1] is None or relerr(r1[1], r0[1]) < 1e-2)
             msg = f"two-destination={two} flip={flip}"
+        elif kind == "f32_split":
+            # fp32 tensors, split-bf16 products (csrc/common.h SplitBf16) against the exact fp32 kernels: every mode of the tile kernel
+            # and every weight-gradient mode, channel counts on and off the 16-channel fast-path contract, one or two sources
+            F32 = mia_hip.F32
+            mode = rng.choice(["s1", "s1_dgrad", "s2", "s2_dgrad", "t2", "t2_dgrad", "wg_s1", "wg_s2", "wg_t2"])
+            cin = rng.choice([16, 32, 48, 64, 96, 128, 160, 256])
+            cout = rng.choice([16, 32, 48, 64, 96, 128, 192])
+            two = mode in ("s1", "wg_s1") and rng.random() < 0.4
+            f = lambda *shape: torch.randn(*shape, device=dev)  # noqa: E731
+            hh, ww = (2 * h - rng.randint(0, 1), 2 * w - rng.randint(0, 1)) if mode in ("s2", "s2_dgrad", "wg_s2") else (h, w)
+            ho, wo = ((hh + 1) // 2, (ww + 1) // 2) if mode in ("s2", "s2_dgrad", "wg_s2") else (hh, ww)
+            wt = torch.randn(cout, cin * (2 if two else 1), 3, 3, device=dev) / (3 * (cin * (2 if two else 1)) ** 0.5)
+            wtt = torch.randn(cin, cout, 2, 2, device=dev) / (2 * cin ** 0.5)  # ConvTranspose2d(cin -> cout)
+            b = torch.randn(cout, device=dev)
+            x1, x2 = f(n, hh, ww, cin), (f(n, hh, ww, cin) if two else None)
+            dy = f(n, ho, wo, cout)
+            if mode == "s1":
+                fn = lambda: ops.conv_mma(CONV_G3S1, x1, x2, *ops.PackCache().get(wt, F32, True), False, b, cout, (hh, ww), want_stats=True)[0]  # noqa: E731
+            elif mode == "s1_dgrad":
+                fn = lambda: ops.conv_mma(CONV_G3S1, dy, None, *ops.PackCache().get(wt, F32, False), True, None, cin, (hh, ww))[0]  # noqa: E731
+            elif mode == "s2":
+                fn = lambda: ops.conv_mma(CONV_G3S2, x1, None, *ops.PackCache().get(wt, F32, True), False, b, cout, (ho, wo), want_stats=True)[0]  # noqa: E731
+            elif mode == "s2_dgrad":
+                from mia_hip import CONV_T3S2
+                fn = lambda: ops.conv_mma(CONV_T3S2, dy, None, *ops.PackCache().get(wt, F32, False), False, None, cin, (hh, ww))[0]  # noqa: E731
+            elif mode == "t2":
+                fn = lambda: ops.conv_mma(CONV_T2S2, x1, None, *ops.PackCache().get(wtt, F32, False), False, b, cout, (2 * hh, 2 * ww))[0]  # noqa: E731
+            elif mode == "t2_dgrad":
+                fine = f(n, 2 * hh, 2 * ww, cout)
+                fn = lambda: ops.conv_mma(CONV_G2S2, fine, None, *ops.PackCache().get(wtt, F32, True), False, None, cin, (hh, ww))[0]  # noqa: E731
+            elif mode == "wg_s1":
+                fn = lambda: ops.conv_wgrad(WGRAD_3S1, x1, x2, dy, tuple(wt.shape), cout, cin * (2 if two else 1))  # noqa: E731
+            elif mode == "wg_s2":
+                fn = lambda: ops.conv_wgrad(WGRAD_3S2, x1, None, dy, tuple(wt.shape), cout, cin)  # noqa: E731
+            else:
+                fine = f(n, 2 * hh, 2 * ww, cout)
+                fn = lambda: ops.conv_wgrad(WGRAD_2S2, fine, None, x1, tuple(wtt.shape), cin, cout)  # noqa: E731
+            r1, r0 = ab("f32_split", 1, fn)
+            e = relerr(r1, r0)
+            ok = e < 6e-5 and bool(torch.isfinite(r1).all())
+            msg = f"{mode} cin={cin}{'x2' if two else ''} cout={cout} in {hh}x{ww} relerr {e:.1e}{' (identical: exact kernel ran)' if e == 0 else ''}"
         elif kind == "wgrad_t2":
             cin, cout = rng.choice([(128, 64), (256, 128), (384, 192), (512, 256)])
             x, dout = t(n, h, w, cin), t(n, 2 * h, 2 * w, cout)
