@@ -274,9 +274,15 @@ def conv_wgrad(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], dy: torc
     ty, tx = _c_int(), _c_int()
     call("mia_wgrad_geometry", mode, dtype, hy, wy, ctypes.byref(ty), ctypes.byref(tx))
     ntiles = n * ty.value * tx.value
-    base = (npad // 64) * (kpad // 64)
+    # column blocks of one split-K slice: the kernels cut the input channels per SOURCE (ceil(c1 / 64) + ceil(c2 / 64) blocks, which
+    # is more than kpad / 64 when neither source is a multiple of 64: cfg5's 96 + 96), and the XCD-aware launch order needs a split
+    # count that is a multiple of 8 (86, 57 or 29 slices dropped those launches to the plain 2-D order and overfilled the chip:
+    # 688 workgroups for 512 slots on cfg5's 192 -> 96 gradient)
+    base = (npad // 64) * (-(-c1 // 64) + -(-c2 // 64))
     target = WGRAD_TARGET_BLOCKS or lib().mia_wgrad_target_blocks(mode, dtype)
     ksplit = max(1, min(ntiles, -(-target // base), 1024))
+    if 8 <= ksplit < ntiles:  # (one tile per slice already: a small problem, leave it)
+        ksplit -= ksplit % 8
     slabs = torch.empty((ksplit, taps, npad, kpad), device=x1.device, dtype=torch.float32)
     if nl is not None:
         assert x2 is None
