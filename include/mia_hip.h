@@ -82,7 +82,7 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
  *                                  workgroups / 16-row tiles: 1 = from 128 input channels on, 2 = always, 0 = never
  *   conv_pw (MIA_CONV_PW, 1)       ConvTranspose 2x2 / stride 2 forward and input gradient (bf16) as one pointwise GEMM on the
  *                                  512-thread LDS-DMA ring (0: the tile kernel, one parity class per workgroup)
- *   conv_pw_s2 (MIA_CONV_PW_S2, 0) stride-2 3x3 bf16 forward as a tap-gathered GEMM on the same ring (needs conv_pw; 1: up to 256
+ *   conv_pw_s2 (MIA_CONV_PW_S2, 1) stride-2 3x3 bf16 forward as a tap-gathered GEMM on the same ring (needs conv_pw; 1: up to 256
  *                                  input channels, 2: always, 0: tile kernels -- default: -0.16 ms per step in isolation, none inside the step)
  *   conv_xcd / wgrad_xcd (MIA_CONV_XCD / MIA_WGRAD_XCD, 1)   blocks sharing an input tile run on one XCD (0: plain grid order)
  *   conv_mt8 (MIA_CONV_MT8, 0)     32-row tiles of the tile kernel (experiment)

@@ -400,7 +400,8 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
   else if (opt.conv64 && mt == 4 && conv64_eligible(mode, dtype, a)) rc = conv64_launch(a, opt.conv64_blocks, opt.reserve_cus, st);
   else if (opt.conv_bt && mt == 4 && conv_bt_eligible(mode, dtype, a)) rc = conv_bt_launch(a, opt.conv_bt_order, opt.reserve_cus, st);
   // (strided 3x3 forward as a tap-gathered GEMM: measured 0.62 -> 0.51, 0.44 -> 0.40, 0.37 -> 0.35 ms at 64 / 128 / 256 input channels,
-  // 0.30 -> 0.30 at 512 in isolation (tools/s2_levels.py), but 43.99 vs 43.94 ms inside the cfg3 step on one box: default off;
+  // 0.30 -> 0.30 at 512 in isolation (tools/s2_levels.py); step-time A/Bs could not resolve it (+-0.1 ms box noise), the per-kernel sums of
+  // two interleaved rocprofv3 pairs inside the cfg3 step can: 36.90 / 36.91 -> 36.77 / 36.77 ms of kernels, so it is on;
   // conv_pw_s2 = 1 stops at 256 input channels, = 2 always)
   else if (opt.conv_pw && (mode != MODE_G3S2 || opt.conv_pw_s2 >= 2 || (opt.conv_pw_s2 == 1 && c1 <= 256)) && conv_pw_eligible(mode, dtype, a))
     rc = conv_pw_launch(mode, a, opt.reserve_cus, st);

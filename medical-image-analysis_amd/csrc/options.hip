@@ -26,7 +26,7 @@ Entry g_table[] = {
     {"conv64_dma", "MIA_CONV64_DMA", 1, 0, 2, {1}},
     {"conv_s2_wide", "MIA_CONV_S2_WIDE", 1, 0, 2, {1}},
     {"conv_pw", "MIA_CONV_PW", 1, 0, 1, {1}},
-    {"conv_pw_s2", "MIA_CONV_PW_S2", 0, 0, 2, {0}},
+    {"conv_pw_s2", "MIA_CONV_PW_S2", 1, 0, 2, {1}},
     {"wgrad_t2", "MIA_WGRAD_T2", 1, 0, 1, {1}},
     {"reserve_cus", "MIA_RESERVE_CUS", 0, 0, 64, {0}},
     {"conv_t3_wide", "MIA_CONV_T3_WIDE", 0, 0, 1, {0}},
