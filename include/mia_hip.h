@@ -97,6 +97,9 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
  *                                  workgroups with 128-channel blocks (the conv_s2_wide shape); bit-identical results
  *   wgrad_narrow (MIA_WGRAD_NARROW, 0)   3x3 stride-1 bf16 weight gradient with channel counts that are not multiples of 64: blocks
  *                                  with <= 32 valid channels skip their empty 16-channel tiles and re-deal the waves (same sums)
+ *   conv_pw_t3 (MIA_CONV_PW_T3, 0)    input gradient of the stride-2 3x3 conv (bf16) as exact-tap GEMMs per output-parity class on the
+ *                                  conv_pw ring (also the accumulating form of mia_conv_mma_acc); fp32 summation order differs
+ *                                  from the tile kernel's; slower than the tile kernel on the benchmarked shapes: off
  *   f32_split (MIA_F32_SPLIT, 0)      fp32 convs / weight gradients of the branch-free tile kernels on the bf16 matrix cores:
  *                                  every operand element enters as hi + lo (two bf16, 16-17 significant bits), four exact products,
  *                                  fp32 accumulation.  NOT bit-identical to the exact fp32 kernels (logits ~3e-5 instead of ~4e-6

@@ -378,10 +378,15 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
     return MIA_EUNSUPPORTED;
   }
   // conv64_dma: 1 = the one-pass two-destination input gradient only (measured faster there), 2 = every 64 -> 64 launch
-  if (acc_out) {  // out += result: the tile kernel's epilogue is the one that reads the previous values
-    if (!fast || t3_wide) { mia_set_error("mia_conv_mma_acc: shape outside the accumulating kernel's contract"); return MIA_EUNSUPPORTED; }
-    rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
+  const bool pw_t3 = opt.conv_pw && opt.conv_pw_t3 && mode == MODE_T3S2 && conv_pw_eligible(mode, dtype, a);  // exact-tap GEMMs on the ring
+  if (acc_out) {  // out += result: the kernels whose epilogue reads the previous values
+    if (pw_t3) rc = conv_pw_launch(mode, a, opt.reserve_cus, st);
+    else {
+      if (!fast || t3_wide) { mia_set_error("mia_conv_mma_acc: shape outside the accumulating kernel's contract"); return MIA_EUNSUPPORTED; }
+      rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
+    }
   }
+  else if (pw_t3) rc = conv_pw_launch(mode, a, opt.reserve_cus, st);
   else if (cr_y != nullptr) {  // column-reduce epilogue: the 64-channel register kernel (its epilogue overlaps the co-resident workgroup)
     if (!(mt == 4 && conv64_eligible(mode, dtype, a))) {
       mia_set_error("mia_conv_mma_cr: shape outside the column-reduce kernel's contract (ask mia_conv_cr_supported first)");
@@ -403,7 +408,7 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
   // 0.30 -> 0.30 at 512 in isolation (tools/s2_levels.py); step-time A/Bs could not resolve it (+-0.1 ms box noise), the per-kernel sums of
   // two interleaved rocprofv3 pairs inside the cfg3 step can: 36.90 / 36.91 -> 36.77 / 36.77 ms of kernels, so it is on;
   // conv_pw_s2 = 1 stops at 256 input channels, = 2 always)
-  else if (opt.conv_pw && (mode != MODE_G3S2 || opt.conv_pw_s2 >= 2 || (opt.conv_pw_s2 == 1 && c1 <= 256)) && conv_pw_eligible(mode, dtype, a))
+  else if (opt.conv_pw && mode != MODE_T3S2 && (mode != MODE_G3S2 || opt.conv_pw_s2 >= 2 || (opt.conv_pw_s2 == 1 && c1 <= 256)) && conv_pw_eligible(mode, dtype, a))
     rc = conv_pw_launch(mode, a, opt.reserve_cus, st);
   else if (fast) rc = conv_mma_fast_launch(mode, dtype, a, t3_wide ? 16 : mt, nt, grid_y, st);
   else rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);

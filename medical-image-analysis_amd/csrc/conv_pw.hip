@@ -8,6 +8,15 @@
 //                         K = Cin, N = 4 Cout; the store scatters column block `tap` to fine pixel (2i + ph, 2j + pw);
 //   gradient (MODE_G2S2): dx[p, ci] = sum_tap sum_co dout[(n, 2i + ph, 2j + pw), co] W[tap][ci][co]  K = 4 Cout (the gather of the
 //                         four fine pixels is a per-tap scalar offset of the row address), N = Cin.
+//   strided-conv input gradient (MODE_T3S2, round 4): dx[(n, 2i + ph, 2j + pw), ci] = sum over the taps of parity class (ph, pw) of
+//                         sum_co dy[(n, i + dh, j + dw), co] W[kh][kw][ci][co] -- the transposed form of the 3x3 / stride-2 conv
+//                         (unet.py:54-66).  A class uses the window positions (dh, dw) with dh <= ph, dw <= pw (1 / 2 / 2 / 4 taps:
+//                         kh = ph ? (dh ? 0 : 2) : 1, likewise kw): M = coarse pixels, N = 4 Cin columns class-major, K = positions
+//                         of the block's classes x Cout.  A 128-column block is one class when Cin >= 128; at Cin = 64 it holds
+//                         two classes and walks the union of their positions, the weight rows of a class that does not use a
+//                         position arriving as zeros (out-of-range DMA source): 12 position-halves issued for 9 useful.  The
+//                         store scatters to fine pixel (2i + ph, 2j + pw); with ConvArgs::acc_out it adds into the tensor (the
+//                         skip gradient accumulated in place, mia_conv_mma_acc).
 // The 256-thread tile kernel ran these as one-tap 32-channel chunks: 16 (forward) / 32 (gradient) MFMAs per wave between two
 // barriers, the four parity classes as separate workgroups re-staging the same input tile.  Here ONE 512-thread workgroup per
 // CU owns a 256-pixel x 128-column block and walks K in 64-wide stages through a ring of three LDS stages (A 32 KB + B 16 KB),
@@ -77,7 +86,7 @@ constexpr int PW_NSTORE = 8;                   // store instructions per wave an
 
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int mtot, int wco, int nk, int mtiles, int nwork, int tile_major) {
-  constexpr bool TR = (MODE == MODE_T2S2), S2 = (MODE == MODE_G3S2), BIAS = TR || S2;
+  constexpr bool TR = (MODE == MODE_T2S2), S2 = (MODE == MODE_G3S2), T3 = (MODE == MODE_T3S2), BIAS = TR || S2;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[PW_LDS];
   const unsigned lds0 = (unsigned)(size_t)(lds_u8*)smem;
 
@@ -97,9 +106,39 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
   const rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.out1, 0, (int)(unsigned)out_bytes, 0x00020000);
 
   struct Item { int m0, n0; };
+  // T3: parity classes of the block's two 64-column halves, the window positions they use (bit pos = 2 dh + dw) and the stage count
+  auto t3_cls = [&](int n0, int half) __attribute__((always_inline)) -> int { return (n0 + 64 * half) / a.o1; };
+  auto t3_posmask = [&](int n0) __attribute__((always_inline)) -> unsigned {
+    unsigned m = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int c = t3_cls(n0, half);
+      m |= 1u | ((c & 1) ? 2u : 0u) | ((c & 2) ? 4u : 0u) | ((c == 3) ? 8u : 0u);
+    }
+    return m;
+  };
+  auto t3_nk = [&](int n0) __attribute__((always_inline)) -> int { return __builtin_popcount(t3_posmask(n0)) * cpt; };
+  auto t3_tap = [&](int cls, int pos) __attribute__((always_inline)) -> int {  // weight tap of (class, position), -1 = the class skips it
+    const int ph = cls >> 1, pw = cls & 1, dh = pos >> 1, dw = pos & 1;
+    if (dh > ph || dw > pw) return -1;
+    const int kh = ph ? (dh ? 0 : 2) : 1, kw = pw ? (dw ? 0 : 2) : 1;
+    return kh * 3 + kw;
+  };
+  // T3: a workgroup owns whole pixel tiles (tile = blockIdx.x, + gridDim.x, ...) and walks ALL column blocks of a tile back to back:
+  // the parity classes cost 1 / 2 / 2 / 4 taps, so any order that pins a workgroup to one column block (the XCD-grouped order
+  // does: 32 slots per round, 16 blocks) leaves the four-tap workgroups running 1.8x longer than the average; here every workgroup
+  // does every class, and a tile's dy rows are re-read from the same CU's L2 sixteen times in a row.  `tile_major` = column blocks.
+  auto t3_live = [&](int w) __attribute__((always_inline)) -> bool {
+    const int k = (w - (int)blockIdx.x) / (int)gridDim.x;
+    return (int)blockIdx.x + (k / tile_major) * (int)gridDim.x < mtiles;
+  };
   auto decode = [&](int w) __attribute__((always_inline)) -> Item {
     int cb, tile;
-    if (tile_major > 0) {  // the column blocks of a pixel tile take consecutive slots of one XCD (its A rows stay in that L2)
+    if (T3) {
+      const int k = (w - (int)blockIdx.x) / (int)gridDim.x, kt = k / tile_major;
+      cb = k - kt * tile_major;
+      tile = (int)blockIdx.x + kt * (int)gridDim.x;
+    } else if (tile_major > 0) {  // the column blocks of a pixel tile take consecutive slots of one XCD (its A rows stay in that L2)
       const int slot = w >> 3, grp = slot / tile_major;
       cb = slot - grp * tile_major;
       tile = grp * 8 + (w & 7);
@@ -115,6 +154,8 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
   const unsigned uA = (unsigned)((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7));
   const unsigned uB = (unsigned)((lane & 7) ^ (((lane >> 4) & 1) | ((wave & 3) << 1)));
   unsigned va[4], vb[2], vbias = PW_SENT, vmask = 0;
+  int i_n0 = 0, i_nk = nk, ipos = 0;  // T3: the fetched item's column base, stage count, current window position
+  unsigned i_pm = 1;                  //     and remaining-position mask
   auto setup_issue = [&](int w) __attribute__((always_inline)) {
     const Item it = decode(w);
 #pragma unroll
@@ -127,21 +168,32 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
         base = (unsigned)((n * a.Hin + 2 * i) * a.Win + 2 * j) * (unsigned)(cin * 2);
         const unsigned bits = (i > 0 ? 1u : 0u) | 2u | (2 * i + 1 < a.Hin ? 4u : 0u) | (j > 0 ? 8u : 0u) | 16u | (2 * j + 1 < a.Win ? 32u : 0u);
         vmask = k == 0 ? bits : (vmask | (bits << (6 * k)));
+      } else if (T3) {  // coarse pixel (n, i, j) itself; positions (dh, dw) add a row / a column: two validity bits
+        const int t1 = p / wco, j = p - t1 * wco, i = t1 % a.Hin;
+        base = (unsigned)p * (unsigned)(cin * 2);
+        const unsigned bits = (i + 1 < a.Hin ? 1u : 0u) | (j + 1 < a.Win ? 2u : 0u);
+        vmask = k == 0 ? bits : (vmask | (bits << (2 * k)));
       } else { const int j = p % wco; base = (unsigned)(4 * p - 2 * j) * (unsigned)(cin * 2); }  // fine pixel (n, 2i, 2j)
       va[k] = p < mtot ? base + uA * 16u : PW_SENT;
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) vb[k] = (unsigned)(it.n0 + 8 * wave + 64 * k + lr) * kpitch + uB * 16u;
+    for (int k = 0; k < 2; ++k) {
+      int row = it.n0 + 8 * wave + 64 * k + lr;
+      if (T3) row -= t3_cls(it.n0, k) * a.o1;  // channel within its parity class (weights are [tap][Cin][Cout])
+      vb[k] = (unsigned)row * kpitch + uB * 16u;
+    }
+    if (T3) { i_n0 = it.n0; i_nk = t3_nk(it.n0); i_pm = t3_posmask(it.n0); ipos = __builtin_ctz(i_pm); }
     if (BIAS) vbias = lane < 32 ? (unsigned)((it.n0 + 4 * lane) % a.o1) * 4u : PW_SENT;
   };
   int wi = blockIdx.x, ki = 0, itap = 0, icc = 0, ita = 0, itb = 0, islot = 0, ibias = 0;
-  bool ihave = wi < nwork;
+  bool ihave = T3 ? t3_live(wi) : wi < nwork;
   if (ihave) setup_issue(wi);
   auto issue_next = [&]() __attribute__((always_inline)) -> int {
     if (!ihave) return 0;
     unsigned soffA, soffB;
     if (TR) { soffA = (unsigned)ki * 128u; soffB = soffA; }
     else if (S2) { soffA = 0u; soffB = (unsigned)itap * (unsigned)a.npad * kpitch + (unsigned)icc * 128u; }
+    else if (T3) { soffA = (unsigned)(((ipos >> 1) * a.Win + (ipos & 1)) * (cin * 2)) + (unsigned)icc * 128u; soffB = (unsigned)icc * 128u; }
     else {
       soffA = (unsigned)((itap >> 1) * a.Win + (itap & 1)) * (unsigned)(cin * 2) + (unsigned)icc * 128u;
       soffB = (unsigned)itap * (unsigned)a.npad * kpitch + (unsigned)icc * 128u;
@@ -155,19 +207,35 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
         const bool ok = ((vmask >> (6 * k + ita)) & (vmask >> (6 * k + 3 + itb)) & 1u) != 0u && v != PW_SENT;
         v = ok ? (unsigned)((int)v + toff) : PW_SENT;
       }
+      if (T3) {  // position (dh, dw): the row below / the column to the right must exist
+        const unsigned vb2 = vmask >> (2 * k);
+        const bool ok = (!(ipos & 2) || (vb2 & 1u)) && (!(ipos & 1) || (vb2 & 2u));
+        v = ok ? v : PW_SENT;
+      }
       pw_dma16(rsA, v, soffA, dst + (unsigned)k * 8192u);
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) pw_dma16(S2 ? rsW9 : rsW, vb[k], soffB, dst + PW_A + (unsigned)k * 8192u);
+    for (int k = 0; k < 2; ++k) {
+      if (T3) {  // the half's class picks the tap of this position, or zeros when it has none
+        const int tap = t3_tap(t3_cls(i_n0, k), ipos);
+        pw_dma16(rsW9, tap >= 0 ? vb[k] : PW_SENT, soffB + (unsigned)(tap >= 0 ? tap : 0) * (unsigned)a.npad * kpitch, dst + PW_A + (unsigned)k * 8192u);
+      } else pw_dma16(S2 ? rsW9 : rsW, vb[k], soffB, dst + PW_A + (unsigned)k * 8192u);
+    }
     int cnt = 6;
     if (BIAS && ki == 0) { pw_dma16(rsB, vbias, 0u, lds0 + PW_BIAS + (unsigned)ibias * 1024u); ibias ^= 1; cnt = 7; }
     islot = islot == PW_NSTAGE - 1 ? 0 : islot + 1;
     ++ki;
-    if (!TR) { if (++icc == cpt) { icc = 0; ++itap; if (S2 && ++itb == 3) { itb = 0; ++ita; } } }
-    if (ki == nk) {
+    if (!TR) {
+      if (++icc == cpt) {
+        icc = 0; ++itap;
+        if (S2 && ++itb == 3) { itb = 0; ++ita; }
+        if (T3) { i_pm &= i_pm - 1; ipos = i_pm ? __builtin_ctz(i_pm) : 0; }
+      }
+    }
+    if (ki == (T3 ? i_nk : nk)) {
       ki = 0; itap = 0; icc = 0; ita = 0; itb = 0;
       wi += gridDim.x;
-      ihave = wi < nwork;
+      ihave = T3 ? t3_live(wi) : wi < nwork;
       if (ihave) setup_issue(wi);
     }
     return cnt;
@@ -184,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
 
   int cslot = 0, cbias = 0, st_m0 = 0, st_n0 = 0;
   bool after_epilogue = false, stats_pending = false;
-  for (int wcur = blockIdx.x; wcur < nwork; wcur += gridDim.x) {
+  for (int wcur = blockIdx.x; T3 ? t3_live(wcur) : wcur < nwork; wcur += gridDim.x) {
     const Item it = decode(wcur);
     f32x4 acc[4][4];
 #pragma unroll
@@ -192,7 +260,8 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
 #pragma unroll
       for (int pf = 0; pf < 4; ++pf) acc[ct][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int kc = 0; kc < nk; ++kc) {
+    const int nk_cur = T3 ? t3_nk(it.n0) : nk;
+    for (int kc = 0; kc < nk_cur; ++kc) {
       const int cnt = issue_next();
       const unsigned char* st = smem + cslot * PW_STAGE;
       u32x4 wf[2][4], pfr[2][4];
@@ -220,11 +289,35 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
       else { if (cnt == 7) pw_wait_vm<7>(); else pw_wait_vm<6>(); }
       after_epilogue = false;
 
-      if (kc == nk - 1) {  // ---- epilogue: 8 consecutive channels per lane and fragment pair, 16-byte stores
+      if (kc == nk_cur - 1) {  // ---- epilogue: 8 consecutive channels per lane and fragment pair, 16-byte stores
         const int ncol = it.n0 + wn * 64;              // first GEMM column of this wave
         int tap = 0, co0 = ncol;
-        if (TR) { tap = ncol / a.o1; co0 = ncol - tap * a.o1; }
+        if (TR || T3) { tap = ncol / a.o1; co0 = ncol - tap * a.o1; }  // T3: `tap` = the wave's parity class (ph, pw)
         const unsigned tapoff = TR ? (unsigned)((tap >> 1) * a.Wout + (tap & 1)) : 0u;
+        unsigned t3pix[4];
+        if (T3) {
+#pragma unroll
+          for (int pf = 0; pf < 4; ++pf) {
+            const int p = it.m0 + wm * 64 + pf * 16 + r;
+            const int t1 = p / wco, j = p - t1 * wco, n = t1 / a.Hin, i = t1 - n * a.Hin;
+            const int oy = 2 * i + (tap >> 1), ox = 2 * j + (tap & 1);
+            t3pix[pf] = (p < mtot && oy < a.Hout && ox < a.Wout) ? (unsigned)((n * a.Hout + oy) * a.Wout + ox) : 0xFFFFFFFFu;
+          }
+        }
+        // accumulate mode: all eight previous 16-byte units of this lane are loaded before the first store (the compiler cannot move a
+        // load above a store itself).  The queue is drained first, so the compiler's own counted waits for these loads see only
+        // operations it knows about (the LDS-DMA pieces are invisible to it).
+        u32x4 prev[2][4];
+        if (T3 && a.acc_out) {
+          pw_wait_vm<0>();
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int pf = 0; pf < 4; ++pf) {
+              const unsigned vo = t3pix[pf] != 0xFFFFFFFFu ? (t3pix[pf] * (unsigned)a.o1 + (unsigned)(co0 + 32 * pr + 8 * q)) * 2u : PW_SENT;
+              prev[pr][pf] = __builtin_amdgcn_raw_buffer_load_b128(rsO, (int)vo, 0, 0);
+            }
+        }
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
           float bv[8], s1[8], s2[8];
@@ -245,11 +338,19 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
             unsigned pix;
             if (TR) { const int j = p % wco; pix = (unsigned)(4 * p - 2 * j) + tapoff; }
             else pix = (unsigned)p;
-            const unsigned voff = p < mtot ? (pix * (unsigned)a.o1 + (unsigned)(co0 + 32 * pr + 8 * q)) * 2u : PW_SENT;
+            unsigned voff = p < mtot ? (pix * (unsigned)a.o1 + (unsigned)(co0 + 32 * pr + 8 * q)) * 2u : PW_SENT;
+            if (T3) voff = t3pix[pf] != 0xFFFFFFFFu ? (t3pix[pf] * (unsigned)a.o1 + (unsigned)(co0 + 32 * pr + 8 * q)) * 2u : PW_SENT;
             const f32x4 lo = acc[2 * pr][pf], hi = acc[2 * pr + 1][pf];
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
+            if (T3 && a.acc_out) {  // out += result: the skip tensor's first gradient piece is already there
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[2 * e] += __builtin_bit_cast(float, prev[pr][pf][e] << 16);
+                v[2 * e + 1] += __builtin_bit_cast(float, prev[pr][pf][e] & 0xFFFF0000u);
+              }
+            }
             if (S2 && a.stats != nullptr) {  // whole tiles only (contract): every pixel counts
 #pragma unroll
               for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
@@ -292,12 +393,15 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
 }
 
 bool conv_pw_eligible(int mode, int dtype, const ConvArgs& a) {
-  if (dtype != MIA_BF16 || (mode != MODE_T2S2 && mode != MODE_G2S2 && mode != MODE_G3S2)) return false;
+  if (dtype != MIA_BF16 || (mode != MODE_T2S2 && mode != MODE_G2S2 && mode != MODE_G3S2 && mode != MODE_T3S2)) return false;
   if (a.c2 != 0 || a.o2 != 0 || !a.vec_in || !a.vec_out) return false;
   if (a.c1 % 64 != 0 || a.kpad != a.c1 || a.npad != a.o1) return false;
-  const int ntot = mode == MODE_T2S2 ? 4 * a.o1 : a.o1, ktot = mode == MODE_T2S2 ? a.c1 : (mode == MODE_G3S2 ? 9 : 4) * a.c1;
+  const int ntot = (mode == MODE_T2S2 || mode == MODE_T3S2) ? 4 * a.o1 : a.o1;
+  const int ktot = (mode == MODE_T2S2 || mode == MODE_T3S2) ? a.c1 : (mode == MODE_G3S2 ? 9 : 4) * a.c1;  // (T3: the one-tap class)
   if (ntot % PW_TN != 0 || ktot < 128 || a.o1 % 64 != 0) return false;
-  if ((mode != MODE_G2S2) != (a.bias != nullptr)) return false;  // the forwards carry the bias, the gradient none
+  if ((mode == MODE_T2S2 || mode == MODE_G3S2) != (a.bias != nullptr)) return false;  // the forwards carry the bias, the gradients none
+  if (a.acc_out && mode != MODE_T3S2) return false;
+  if (mode == MODE_T3S2 && !(a.Hin == (a.Hout + 1) / 2 && a.Win == (a.Wout + 1) / 2 && a.flip == 0)) return false;
   if (mode == MODE_G3S2) {
     // statistics: the finalize step only sums an image's entries, so any partition of its pixels into the host's tiles_y * tiles_x
     // entries will do -- here runs of 128 consecutive output pixels (two per block); needs whole 8 x 16 tilings and no block
@@ -320,17 +424,18 @@ static int pw_num_cus() {
 }
 
 int conv_pw_launch(int mode, const ConvArgs& a, int reserve, hipStream_t st) {
-  const bool tr = mode == MODE_T2S2;
-  const int hco = tr ? a.Hin : a.Hout, wco = tr ? a.Win : a.Wout;  // the coarse grid
+  const bool tr = mode == MODE_T2S2, t3 = mode == MODE_T3S2;
+  const int hco = (tr || t3) ? a.Hin : a.Hout, wco = (tr || t3) ? a.Win : a.Wout;  // the coarse grid
   const int mtot = a.N * hco * wco;
-  const int nk = (tr ? a.c1 : (mode == MODE_G3S2 ? 9 : 4) * a.c1) / 64;
-  const int nblocks = (tr ? 4 * a.o1 : a.o1) / PW_TN;
+  const int nk = ((tr || t3) ? a.c1 : (mode == MODE_G3S2 ? 9 : 4) * a.c1) / 64;  // (t3: per item, 1 .. 4 x this -- the kernel works it out)
+  const int nblocks = ((tr || t3) ? 4 * a.o1 : a.o1) / PW_TN;
   const int mtiles = ceil_div(mtot, PW_TM);
   const int nwork = mtiles * nblocks;
-  const int tile_major = (nblocks > 1 && mtiles % 8 == 0) ? nblocks : 0;
+  const int tile_major = t3 ? nblocks : ((nblocks > 1 && mtiles % 8 == 0) ? nblocks : 0);
   const int ncu = reserve > 0 ? persistent_cus(pw_num_cus(), reserve) : pw_num_cus();
-  const dim3 grid(nwork < ncu ? nwork : ncu);
-  if (mode == MODE_G3S2) hipLaunchKernelGGL(conv_pw_kernel<MODE_G3S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
+  const dim3 grid(t3 ? (mtiles < ncu ? mtiles : ncu) : (nwork < ncu ? nwork : ncu));  // t3: one workgroup per pixel tile at most
+  if (t3) hipLaunchKernelGGL(conv_pw_kernel<MODE_T3S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
+  else if (mode == MODE_G3S2) hipLaunchKernelGGL(conv_pw_kernel<MODE_G3S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
   else if (tr) hipLaunchKernelGGL(conv_pw_kernel<MODE_T2S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
   else hipLaunchKernelGGL(conv_pw_kernel<MODE_G2S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
   return MIA_OK;

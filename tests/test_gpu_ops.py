@@ -1512,3 +1512,45 @@ def test_f32_split_transposed_conv_close_to_exact(case):
         assert relerr(exact, want) < TOL[torch.float32], name
         assert relerr(got, want) < SPLIT_TOL, (name, relerr(got, want))
         assert not torch.equal(got, exact), (name, "the split kernel did not run")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 128, 64, 24, 40), (1, 256, 128, 17, 23), (3, 128, 64, 9, 8), (1, 1024, 512, 16, 16), (2, 512, 256, 33, 20),
+                                  (1, 128, 64, 1, 5), (2, 256, 128, 64, 64)])
+def test_stride2_input_gradient_on_the_pointwise_ring(case):
+    """Option conv_pw_t3 (csrc/conv_pw.hip MODE_T3S2): the stride-2 3x3 conv's input gradient as exact-tap GEMMs per output-parity
+    class on the LDS-DMA ring -- even and odd fine sizes, 64-channel outputs (two classes per column block, zero weight rows for the
+    positions a class skips), several pixel tiles and ragged last tiles -- against the tile kernel (fp32 summation order / one bf16
+    ulp) and fp32-CPU math, plain and accumulating (`mia_conv_mma_acc`: out += result, the skip gradient of unet.py:54-66)."""
+    import mia_hip
+    from mia_hip import CONV_T3S2, call, ops
+    from mia_hip.ops import _p, _stream
+    dev = _dev()
+    n, cout, cin, hc, wc = case          # dy: [n, hc, wc, cout] -> dx: [n, 2hc(-1), 2wc(-1), cin]
+    g = torch.Generator().manual_seed(cout + hc + wc)
+    dy = torch.randn(n, hc, wc, cout, generator=g).to(dev, torch.bfloat16)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cout * 2.25)).to(dev)
+    pc = ops.PackCache()
+    wb, npad, kpad = pc.get(wt, mia_hip.BF16, False)
+    old = mia_hip.get_option("conv_pw_t3")
+    try:
+        for fine in ((2 * hc, 2 * wc), (2 * hc - 1, 2 * wc - 1)):
+            want = F.conv_transpose2d(dy.float().cpu().permute(0, 3, 1, 2), wt.cpu().to(torch.bfloat16).float(), stride=2, padding=1,
+                                      output_padding=(fine[0] - (2 * hc - 1), fine[1] - (2 * wc - 1)))
+            prev = (torch.randn(n, fine[0], fine[1], cin, generator=g) * want.abs().mean().item()).to(dev, torch.bfloat16)
+            outs, accs = [], []
+            for v in (0, 1):
+                mia_hip.set_option("conv_pw_t3", v)
+                o, _, _ = ops.conv_mma(CONV_T3S2, dy, None, wb, npad, kpad, False, None, cin, fine)
+                outs.append(o)
+                acc = prev.clone()
+                call("mia_conv_mma_acc", CONV_T3S2, mia_hip.BF16, _p(dy), cout, _p(wb), npad, kpad, 0, _p(acc), cin, n, hc, wc, fine[0], fine[1], _stream())
+                accs.append(acc)
+            torch.cuda.synchronize()
+            assert relerr(nchw(outs[0]), want) < 1e-2 and relerr(nchw(outs[1]), want) < 1e-2, fine
+            assert relerr(outs[1], outs[0]) < 2 ** -7, fine                     # one bf16 ulp where the fp32 sums round apart
+            want_acc = want + prev.float().cpu().permute(0, 3, 1, 2)
+            assert relerr(nchw(accs[0]), want_acc) < 1.5e-2 and relerr(nchw(accs[1]), want_acc) < 1e-2, fine
+            assert bool(torch.isfinite(outs[1].float()).all())
+    finally:
+        mia_hip.set_option("conv_pw_t3", old)
