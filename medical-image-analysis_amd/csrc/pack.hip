@@ -115,12 +115,26 @@ __device__ __forceinline__ void pack_brick(const MiaPackDesc& d, int brick, floa
   const int TA = d.n_from_d0 ? 16 : 64, TB = d.n_from_d0 ? 64 : 16;
   const int pitch = TB * taps + 1, run = TB * taps;
   const int a0 = (brick / d.bricks_x) * TA, b0 = (brick % d.bricks_x) * TB;
-  // source rows: TB * taps contiguous floats each; a thread walks one row position across the TA rows
+  // source rows: TB * taps contiguous floats each; a thread walks one row position across the TA rows, EIGHT loads in flight at a
+  // time: branch-free buffer loads (out-of-range rows / columns read zero through an out-of-range offset).  The first version
+  // guarded each load with a branch and hipcc waited vmcnt(0) after every one of them -- 36-64 serialized memory round trips per
+  // thread, ~30 us per brick, 1.75 TB/s for the launch.
+  // (a source tensor is < 4 GiB: ops.PackPlan checks it when it builds the descriptors)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.src), 0, d.d0 * d.d1 * taps * 4, 0x00020000);
+  const unsigned rstep = (unsigned)(d.d1 * taps * 4);
   for (int r = threadIdx.x; r < run; r += 256) {
-    const int b = r / taps;
-    const bool bok = b0 + b < d.d1;
-    const float* src = d.src + ((size_t)a0 * d.d1 + b0) * taps + r;
-    for (int a = 0; a < TA; ++a) tile[a * pitch + r] = (bok && a0 + a < d.d0) ? src[(size_t)a * d.d1 * taps] : 0.f;
+    const bool bok = b0 + r / taps < d.d1;
+    const unsigned row0 = (unsigned)(((a0 * d.d1 + b0) * taps + r) * 4);
+    for (int a = 0; a < TA; a += 8) {
+      unsigned v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool ok = bok && a0 + a + u < d.d0;
+        v[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (int)(row0 + (unsigned)(a + u) * rstep) : (int)0xFFFFFFF0u, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tile[(a + u) * pitch + r] = __builtin_bit_cast(float, v[u]);
+    }
   }
   __syncthreads();
   T* dst = static_cast<T*>(d.dst);

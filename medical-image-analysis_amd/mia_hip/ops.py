@@ -118,6 +118,8 @@ class PackPlan:
             key = (dtype, n_from_d0)
             _, buf, npad, kpad = pc._store[key]
             d0, d1, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+            if d0 * d1 * taps * 4 >= 1 << 31:
+                raise MiaError("PackPlan: a weight tensor of 2 GiB or more is outside the batched pack kernel's 32-bit offsets")
             pa, pb = (npad, kpad) if n_from_d0 else (kpad, npad)  # padded extents along D0 / D1
             ta, tb = (16, 64) if n_from_d0 else (64, 16)
             bx, by = -(-pb // tb), -(-pa // ta)
