@@ -103,7 +103,8 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
  *   f32_split (MIA_F32_SPLIT, 0)      fp32 convs / weight gradients of the branch-free tile kernels on the bf16 matrix cores:
  *                                  every operand element enters as hi + lo (two bf16, 16-17 significant bits), four exact products,
  *                                  fp32 accumulation.  NOT bit-identical to the exact fp32 kernels (logits ~3e-5 instead of ~4e-6
- *                                  from the fp32 CPU reference); ~1.9x on the fp32 training step.  Tensors stay fp32.
+ *                                  from the fp32 CPU reference); ~1.9x on the fp32 training step.  Tensors stay fp32.  Value 2 (experiment,
+ *                                  conv kernel only): three bf16 parts, six products in three MFMAs -- fp32 accuracy, 1.25x.
  *   reserve_cus (MIA_RESERVE_CUS, 0)   CUs the persistent kernels leave free (0..64, rounded so that the grids stay
  *                                  multiples of 8): the grids of conv_bt / conv_pw / conv64 / conv64_dma shrink to CUs - k
  *                                  workgroups (same work items: bit-identical results) and mia_wgrad_target_blocks follows

@@ -106,6 +106,51 @@ struct SplitBf16 {
   static __device__ __forceinline__ f32x4 mma_a(const u32x4& ah, const u32x4& al, const u32x4& b, f32x4 c) { return mfma(al, b, mfma(ah, b, c)); }
 };
 
+// Three-way split (option f32_split = 2): x = h + m + l holds all 24 significand bits of an fp32 value in three bf16 parts, and six of
+// the nine part products reach ~2^-24 per product in THREE MFMAs per 16 channels: (xh, xm) x (wh, wh) -> xh wh + xm wh;
+// (xh, xm) x (wm, wm) -> xh wm + xm wm; (xh, xl) x (wl, wh) -> xh wl + xl wh (dropped: xm wl, xl wm, xl wl <= 2^-24 of the product).
+// 48 matrix cycles per 16 channels against 128 for the four v_mfma_f32_16x16x4_f32, at the accuracy of the fp32 kernel.
+struct Split3 {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+  static __device__ __forceinline__ unsigned cvt2(f2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2)); }
+  static __device__ __forceinline__ f2 up2(unsigned p) { return f2{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xFFFF0000u)}; }
+  // 4 fp32 -> words (h | m << 16) and (h | l << 16) of the same four channels
+  static __device__ __forceinline__ void act(const u32x4& raw, u32x4& hm, u32x4& hl) {
+    const f32x4 x = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f2 v = {x[2 * p], x[2 * p + 1]};
+      const unsigned hp = cvt2(v);
+      const f2 r1 = v - up2(hp);
+      const unsigned mp = cvt2(r1);
+      const unsigned lp = cvt2(r1 - up2(mp));
+      hm[2 * p] = __builtin_amdgcn_perm(mp, hp, 0x05040100u); hm[2 * p + 1] = __builtin_amdgcn_perm(mp, hp, 0x07060302u);
+      hl[2 * p] = __builtin_amdgcn_perm(lp, hp, 0x05040100u); hl[2 * p + 1] = __builtin_amdgcn_perm(lp, hp, 0x07060302u);
+    }
+  }
+  // weights: 4 fp32 -> words (h | m << 16) and the four l parts as two words (l0 | l1 << 16), (l2 | l3 << 16)
+  static __device__ __forceinline__ void wgt(const u32x4& raw, u32x4& hm, unsigned& l01, unsigned& l23) {
+    const f32x4 x = __builtin_bit_cast(f32x4, raw);
+    unsigned lp[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f2 v = {x[2 * p], x[2 * p + 1]};
+      const unsigned hp = cvt2(v);
+      const f2 r1 = v - up2(hp);
+      const unsigned mp = cvt2(r1);
+      lp[p] = cvt2(r1 - up2(mp));
+      hm[2 * p] = __builtin_amdgcn_perm(mp, hp, 0x05040100u); hm[2 * p + 1] = __builtin_amdgcn_perm(mp, hp, 0x07060302u);
+    }
+    l01 = lp[0]; l23 = lp[1];
+  }
+  // (l | h << 16) words of the B operand from the (h | m) words and the l pairs
+  static __device__ __forceinline__ u32x4 lh(const u32x4& hm, unsigned l01, unsigned l23) {
+    return u32x4{__builtin_amdgcn_perm(hm[0], l01, 0x05040100u), __builtin_amdgcn_perm(hm[1], l01, 0x05040302u),
+                 __builtin_amdgcn_perm(hm[2], l23, 0x05040100u), __builtin_amdgcn_perm(hm[3], l23, 0x05040302u)};
+  }
+};
+
 // Norm + LeakyReLU backward for one element (reference autograd of blocks.py:98-102): g = dz * lrelu'(scale*y + shift),
 // dy = scale*(g - c1 - xhat*c2) = scale*g + ka*y + kb with ka = -scale*c2*xa, kb = -scale*(c1 + c2*xb).  ONE definition with explicit
 // fmas, shared by the streaming apply pass (norm.hip) and the kernels that form dy on load (stem.hip: mia_stem_wgrad_fused), so

@@ -337,7 +337,7 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
   a.npad = npad; a.kpad = kpad; a.flip = flip_taps;
   a.nl_scale = nl_scale; a.nl_shift = nl_shift; a.nl_slope = nl_slope;
   a.acc_out = acc_out;
-  a.split = (opt.f32_split && dtype == MIA_F32) ? 1 : 0;
+  a.split = dtype == MIA_F32 ? opt.f32_split : 0;  // 0 exact fp32 MFMAs, 1 two-way, 2 three-way split bf16 products
   if (cr_y != nullptr) {
     a.cr_y = cr_y; a.cr_scale = cr_coef[0]; a.cr_shift = cr_coef[1]; a.cr_xa = cr_coef[2]; a.cr_xb = cr_coef[3]; a.cr_slope = cr_slope;
   }

@@ -22,11 +22,14 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 // WC = 2 (stride-2 3x3 forward, bf16): 512 threads, the eight waves are 4 row groups x 2 halves of a 128-channel block on a
 // 16-row tile -- each wave owns 4 x 4 accumulators (8 fragment reads per 16 MFMAs instead of 6 per 8: the 256-thread
 // 8-row shape saturates the LDS pipe), one workgroup per CU.  The statistics stay in the host's 8-row tile layout.
-// SPLIT (T = float only): fp32 tensors, products on the bf16 matrix cores from two-way split operands (SplitBf16 in
-// common.h): commit() turns every staged fp32 unit into (hi | lo) words, an MFMA step is two 16x16x32 bf16 instructions.
-template <typename T, int MODE, int MT, int NT, int WC = 1, bool SPLIT = false>
+// SPLIT (T = float only): fp32 tensors, products on the bf16 matrix cores from split operands (common.h).  1 = two-way (SplitBf16):
+// commit() turns every staged fp32 unit into (hi | lo) words, an MFMA step is two 16x16x32 bf16 instructions (operands to 2^-17).
+// 2 = three-way (Split3): the A tile is staged twice ((h | m) and (h | l) words), the weights as (h | m) words plus 8 bytes of l
+// parts, an MFMA step is three instructions covering six part products (~2^-24 per product: the accuracy of the fp32 kernel).
+template <typename T, int MODE, int MT, int NT, int WC = 1, int SPLIT = 0>
 __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_mma_fast_kernel(const ConvArgs a) {
-  static_assert(!SPLIT || sizeof(T) == 4, "split mode is a mode of the fp32 kernel");
+  static_assert(SPLIT == 0 || sizeof(T) == 4, "split mode is a mode of the fp32 kernel");
+  static_assert(SPLIT != 2 || WC == 1, "three-way split: 256-thread shapes only");
   using G = Geo<MODE, MT>;
   constexpr int NTHR = 256 * WC, PL = 64 * WC;  // threads; pixel lanes (x 4 channel groups) of a staging iteration
   constexpr int TH = G::TH, BN = 16 * NT * WC, EPU = Elem<T>::EPU, KB = 4 * EPU, ES = (int)sizeof(T);
@@ -39,13 +42,15 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   constexpr int B_IT = (G::MAXTAPS + TPI - 1) / TPI;
   constexpr int OSTR = BN + EPU;
   constexpr int A_UNITS = 4 * NPA, B_UNITS = B_IT * TPI * 4 * NPB;
-  constexpr int STAGE_BYTES = (A_UNITS + B_UNITS) * 16;
+  constexpr int STAGE_BYTES = SPLIT == 2 ? (2 * A_UNITS + B_UNITS) * 16 + B_UNITS * 8 : (A_UNITS + B_UNITS) * 16;
   constexpr int OUT_BYTES = TH * 16 * OSTR * ES;
   constexpr int LDS_BYTES = STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES;
   static_assert(PL % BN == 0 && TPI >= 1, "weight staging deals whole taps");
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + 2 * 4 * BN * 4];
   u32x4* ldsA = reinterpret_cast<u32x4*>(smem);
-  u32x4* ldsB = ldsA + A_UNITS;
+  u32x4* ldsB = ldsA + (SPLIT == 2 ? 2 : 1) * A_UNITS;  // SPLIT 2: [A (h|m)][A (h|l)][B (h|m)][B l pairs, 8 bytes per unit]
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+  u32x2_t* ldsBl = reinterpret_cast<u32x2_t*>(ldsB + B_UNITS);
   T* ldsO = reinterpret_cast<T*>(smem);
   float* ldsR = reinterpret_cast<float*>(smem + LDS_BYTES);
 
@@ -172,16 +177,33 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
     }
   };
   auto commit = [&]() {
+    if constexpr (SPLIT == 2) {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) ldsA[g * NPA + (S == 2 ? a_lds[i] : p4 + PL * i)] = SPLIT ? SplitBf16::unit(pa[i]) : pa[i];
+      for (int i = 0; i < A_IT; ++i) {
+        u32x4 hm, hl;
+        Split3::act(pa[i], hm, hl);
+        const int at = g * NPA + (S == 2 ? a_lds[i] : p4 + PL * i);
+        ldsA[at] = hm; ldsA[A_UNITS + at] = hl;
+      }
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) ldsB[((i * TPI + tsub) * 4 + g) * NPB + bn_] = SPLIT ? SplitBf16::unit(pb[i]) : pb[i];
+      for (int i = 0; i < B_IT; ++i) {
+        u32x4 hm; unsigned l01, l23;
+        Split3::wgt(pb[i], hm, l01, l23);
+        const int at = ((i * TPI + tsub) * 4 + g) * NPB + bn_;
+        ldsB[at] = hm; ldsBl[at] = u32x2_t{l01, l23};
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) ldsA[g * NPA + (S == 2 ? a_lds[i] : p4 + PL * i)] = SPLIT == 1 ? SplitBf16::unit(pa[i]) : pa[i];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) ldsB[((i * TPI + tsub) * 4 + g) * NPB + bn_] = SPLIT == 1 ? SplitBf16::unit(pb[i]) : pb[i];
   };
   // one step of the matrix loop: acc[m][n] += A(m) x B(n) for the wave's MT x NT accumulators.  Split mode forms the (H, H) /
   // (L, L) forms of a B fragment right before its MT MFMA pairs (8 v_perm per 2 * MT MFMAs; kept out of the double buffer:
   // 32 more live registers would spill the 4 x 4 shape)
   auto mma_step = [&](auto&& a_of, const u32x4* bfr) {
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT == 1) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const u32x4 bh = SplitBf16::dup_hi(bfr[n]), bl = SplitBf16::dup_lo(bfr[n]);
@@ -201,7 +223,35 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
     commit();
     __syncthreads();
     if (c0 + KB < ctot) fetch(c0 + KB);
-    if constexpr (MODE == MODE_T3S2) {  // run-time tap count (depends on the output parity)
+    if constexpr (SPLIT == 2) {
+      // three-way split: plain tap loop (fragments read per tap, no register double buffer: the second workgroup of the CU covers
+      // the LDS latency), three MFMAs per (row, channel tile) and tap
+      for (int ta = 0; ta < nth; ++ta) {
+        for (int tb = 0; tb < ntw; ++tb) {
+          const int tl = ta * ntw + tb;
+          const int toff = tap_off(ta, tb);
+          u32x4 a1[MT], a2[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int at = q * NPA + S * (wave * MT + m) * PITCH + toff + pr;
+            a1[m] = ldsA[at]; a2[m] = ldsA[A_UNITS + at];
+          }
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const int bt = (tl * 4 + q) * NPB + n * 16 + pr;
+            const u32x4 whm = ldsB[bt];
+            const u32x2_t wl = ldsBl[bt];
+            const u32x4 bhh = SplitBf16::dup_hi(whm), bmm = SplitBf16::dup_lo(whm), blh = Split3::lh(whm, wl[0], wl[1]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              acc[m][n] = SplitBf16::mfma(a1[m], bhh, acc[m][n]);
+              acc[m][n] = SplitBf16::mfma(a1[m], bmm, acc[m][n]);
+              acc[m][n] = SplitBf16::mfma(a2[m], blh, acc[m][n]);
+            }
+          }
+        }
+      }
+    } else if constexpr (MODE == MODE_T3S2) {  // run-time tap count (depends on the output parity)
       for (int ta = 0; ta < nth; ++ta) {
         for (int tb = 0; tb < ntw; ++tb) {
           const int tl = ta * ntw + tb;
@@ -378,7 +428,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   if (second_part) store_to(true);
 }
 
-template <typename T, int MODE, int MT, int NT, int WC = 1, bool SPLIT = false>
+template <typename T, int MODE, int MT, int NT, int WC = 1, int SPLIT = 0>
 static void flaunch(const ConvArgs& a, int grid_y, hipStream_t st) {
   int grid_x = a.N * a.tiles_x * a.tiles_y * a.nblk_n;
   if (a.xcd) {  // groups of (channel blocks x parity classes) per tile, tiles rounded up to a multiple of 8
@@ -390,10 +440,16 @@ static void flaunch(const ConvArgs& a, int grid_y, hipStream_t st) {
 template <typename T, int MODE, int MT>
 static void flaunch_nt(const ConvArgs& a, int nt, int grid_y, hipStream_t st) {
   if constexpr (sizeof(T) == 4) {
-    if (a.split) {  // fp32 tensors, split-bf16 products
-      if (nt == 4) flaunch<T, MODE, MT, 4, 1, true>(a, grid_y, st);
-      else if (nt == 2) flaunch<T, MODE, MT, 2, 1, true>(a, grid_y, st);
-      else flaunch<T, MODE, MT, 1, 1, true>(a, grid_y, st);
+    if (a.split == 2) {  // fp32 tensors, three-way split products (fp32 accuracy)
+      if (nt == 4) flaunch<T, MODE, MT, 4, 1, 2>(a, grid_y, st);
+      else if (nt == 2) flaunch<T, MODE, MT, 2, 1, 2>(a, grid_y, st);
+      else flaunch<T, MODE, MT, 1, 1, 2>(a, grid_y, st);
+      return;
+    }
+    if (a.split) {  // fp32 tensors, two-way split products
+      if (nt == 4) flaunch<T, MODE, MT, 4, 1, 1>(a, grid_y, st);
+      else if (nt == 2) flaunch<T, MODE, MT, 2, 1, 1>(a, grid_y, st);
+      else flaunch<T, MODE, MT, 1, 1, 1>(a, grid_y, st);
       return;
     }
   }

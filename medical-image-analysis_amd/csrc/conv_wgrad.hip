@@ -2017,7 +2017,7 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
   } else if (dtype == MIA_F32 && chan_ok && (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 4 < lim &&
              (size_t)hy * wy * cdy * 4 < lim) {
     const bool narrow = cdy <= 32 && c1 <= 32 && c2 <= 32;  // 32-channel layers: half-width blocks, all four waves busy
-    if (o.f32_split) {  // fp32 tensors, split-bf16 products
+    if (o.f32_split == 1) {  // fp32 tensors, two-way split-bf16 products (the three-way experiment exists in the conv kernel only)
       if (narrow) {
         if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, true, true>), fgrid, dim3(256), 0, st, a);
         else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S2, true, true>), fgrid, dim3(256), 0, st, a);

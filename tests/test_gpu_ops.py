@@ -1554,3 +1554,48 @@ def test_stride2_input_gradient_on_the_pointwise_ring(case):
             assert bool(torch.isfinite(outs[1].float()).all())
     finally:
         mia_hip.set_option("conv_pw_t3", old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 0, 96, 33, 47, 1), (1, 128, 0, 64, 24, 40, 2), (1, 64, 64, 64, 17, 33, 1), (2, 32, 0, 32, 20, 28, 1)])
+def test_f32_three_way_split_conv_has_fp32_accuracy(case):
+    """Option f32_split = 2 (experiment, conv kernel only; csrc/common.h Split3): x = h + m + l in three bf16 parts, six part products in
+    three MFMAs per 16 channels -- the result must be as close to fp64 math as the exact fp32 kernel's (2e-6 max-norm), i.e. well
+    inside the two-way split's 6e-5, forward and both input gradients, and not bit-equal to the exact kernel's (it ran)."""
+    import mia_hip
+    from mia_hip import CONV_G3S1, CONV_G3S2, CONV_T3S2, ops
+    dev = _dev()
+    n, c1, c2, cout, h, w, stride = case
+    cin = c1 + c2
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
+    dy = torch.randn(n, cout, ho, wo, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr.double(), wt.double(), b.double(), stride=stride, padding=1)
+    yr.backward(dy.double())
+    x1 = nhwc(x[:, :c1], torch.float32, dev)
+    x2 = nhwc(x[:, c1:], torch.float32, dev) if c2 else None
+    dyd, wd = nhwc(dy, torch.float32, dev), wt.to(dev)
+    old = mia_hip.get_option("f32_split")
+    res = {}
+    try:
+        for flag in (0, 2):
+            mia_hip.set_option("f32_split", flag)
+            pc = ops.PackCache()
+            wp, npad, kpad = pc.get(wd, mia_hip.F32, True)
+            wb, npb, kpb = pc.get(wd, mia_hip.F32, False)
+            y, _, _ = ops.conv_mma(CONV_G3S2 if stride == 2 else CONV_G3S1, x1, x2, wp, npad, kpad, False, b.to(dev), cout, (ho, wo), want_stats=True)
+            if stride == 2:
+                dx1, dx2, _ = ops.conv_mma(CONV_T3S2, dyd, None, wb, npb, kpb, False, None, cin, (h, w), out_split=c1 if c2 else None)
+            else:
+                dx1, dx2, _ = ops.conv_mma(CONV_G3S1, dyd, None, wb, npb, kpb, True, None, cin, (h, w), out_split=c1 if c2 else None)
+            res[flag] = (nchw(y), nchw(dx1) if dx2 is None else torch.cat([nchw(dx1), nchw(dx2)], 1))
+    finally:
+        mia_hip.set_option("f32_split", old)
+    for name, exact, got, want in zip(("y", "dx"), res[0], res[2], (yr, xr.grad)):
+        assert relerr(got, want) < 2e-6, (name, relerr(got, want))
+        assert relerr(got, want) < 2.0 * relerr(exact, want) + 5e-7, (name, relerr(got, want), relerr(exact, want))
+        assert not torch.equal(got, exact), name
