@@ -1599,3 +1599,33 @@ def test_f32_three_way_split_conv_has_fp32_accuracy(case):
         assert relerr(got, want) < 2e-6, (name, relerr(got, want))
         assert relerr(got, want) < 2.0 * relerr(exact, want) + 5e-7, (name, relerr(got, want), relerr(exact, want))
         assert not torch.equal(got, exact), name
+
+
+@pytest.mark.gpu
+def test_batched_weight_pack_matches_per_tensor_pack():
+    """`mia_pack_weight_batch` (ops.PackPlan: one launch re-packs every weight of a model after the optimizer step) against the
+    per-tensor `mia_pack_weight` on the same values: both orientations, 3x3 / 2x2 / 1x1 taps, channel counts that are not multiples
+    of the 16 x 64 brick (96, 40, 3), bf16 and fp32 -- bit-identical, zero padding included."""
+    import mia_hip
+    from mia_hip import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 64, 3, 3), (96, 192, 3, 3), (128, 40, 3, 3), (256, 128, 2, 2), (96, 48, 2, 2), (3, 64, 1, 1), (16, 16, 3, 3), (1024, 512, 3, 3)]
+    for dt in (mia_hip.BF16, mia_hip.F32):
+        ws = [torch.nn.Parameter(torch.randn(*s, generator=g).to(dev)) for s in shapes]
+        for w in ws:  # first use: per-tensor packs, which also tells the plan which copies exist
+            for orient in (True, False):
+                ops.pack_cache(w).get(w, dt, n_from_d0=orient)
+        plan = ops.PackPlan(ws, dt)
+        with torch.no_grad():
+            for w in ws:
+                w.mul_(1.7).add_(0.01)  # new values behind the caches' back
+        ops.bump_param_epoch()
+        plan.repack()
+        torch.cuda.synchronize()
+        for w in ws:
+            for orient in (True, False):
+                got, npad, kpad = ops.pack_cache(w).get(w, dt, n_from_d0=orient)   # planted by the plan
+                ref, npad2, kpad2 = ops.PackCache().get(w, dt, n_from_d0=orient)   # a fresh per-tensor pack of the same values
+                assert (npad, kpad) == (npad2, kpad2)
+                assert got.data_ptr() != ref.data_ptr() and torch.equal(got, ref), (tuple(w.shape), orient, dt)
