@@ -256,6 +256,10 @@ class GradBucketReducer:
         return 1.0 / self.world
 
 
+class _CaptureFailed(RuntimeError):
+    """Recording the train step into a hipGraph failed (TrainEngine falls back to eager steps)."""
+
+
 class _CapturedStep:
     """A captured train step: static inputs, the device-resident per-step scalars, the graph, the static loss."""
     __slots__ = ("img", "lab", "dyn", "graph", "loss")
@@ -359,7 +363,10 @@ class TrainEngine:
         key = (tuple(image.shape), tuple(label.shape))
         g = self._graphs.get(key)
         if g is None:
-            g = self._graphs[key] = self._capture(image, label)
+            try:
+                g = self._graphs[key] = self._capture(image, label)
+            except Exception as e:  # capture errors surface as RuntimeError from torch / MiaError from a launch
+                raise _CaptureFailed() from e
         opt = self.optimizer
         pg = opt.param_groups[0]
         opt.step_count += 1
@@ -383,9 +390,17 @@ class TrainEngine:
         image = sampled_batch["image"].to(dev, dtype=torch.float32, non_blocking=True)
         label = sampled_batch["label"].to(dev, dtype=torch.long, non_blocking=True)
         if self.graph_mode and self._eager_steps >= self.GRAPH_WARMUP:
-            loss = self._train_step_graph(image.contiguous(), label.contiguous())
-            self.current_iter += 1
-            return loss
+            try:
+                loss = self._train_step_graph(image.contiguous(), label.contiguous())
+                self.current_iter += 1
+                return loss
+            except _CaptureFailed as e:
+                # nothing has executed (a capture records, it does not run): drop to the eager step for good, from a clean slate
+                import warnings
+                warnings.warn(f"TrainEngine: hipGraph capture of the train step failed ({e.__cause__!r}); continuing with eager steps")
+                self.graph_mode = False
+                self._graphs.clear()
+                self.optimizer.zero_grad()
         self._eager_steps += 1
         output = self.model(image)
         loss = self.loss_fn(output, label)
