@@ -394,6 +394,14 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
     }
     rc = conv64_launch(a, opt.conv64_blocks, opt.reserve_cus, st);
   }
+  else if (nl_scale != nullptr && dtype == MIA_F32) {  // fp32: every stride-1 3x3 launch is the register-staged tile kernel
+    if (!(fast && mode == MODE_G3S1 && c2 == 0 && a.o2 == 0 && !flip_taps && (reinterpret_cast<uintptr_t>(nl_scale) & 15) == 0 &&
+          (reinterpret_cast<uintptr_t>(nl_shift) & 15) == 0)) {
+      mia_set_error("mia_conv_mma_nl: shape outside the fp32 normalise-on-load contract (ask mia_conv_nl_supported first)");
+      return MIA_EUNSUPPORTED;
+    }
+    rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
+  }
   else if (nl_scale != nullptr) {  // normalise-on-load: the register-staged 64-channel kernel is the one consumer that transforms
     if (!(mt == 4 && conv64_eligible(mode, dtype, a))) {
       mia_set_error("mia_conv_mma_nl: shape outside the normalise-on-load kernel's contract (ask mia_conv_nl_supported first)");
@@ -427,8 +435,10 @@ extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const 
 // Normalise-on-load forward conv (the fused PlainBlock, SURVEY 8b export list "conv3x3_nhwc ... optional fused normalise +
 // LeakyReLU on load taking per-(n,c) scale / shift"): see include/mia_hip.h.
 extern "C" int mia_conv_nl_supported(int mode, int dtype, int c1, int nout, int hout, int wout) {
-  (void)wout;
-  return (mode == MODE_G3S1 && dtype == MIA_BF16 && c1 == 64 && nout == 64 && hout > 8) ? 1 : 0;
+  if (mode != MODE_G3S1) return 0;
+  if (dtype == MIA_F32)  // the branch-free tile kernel's contract (conv_mma_fast_eligible) for one source, one destination
+    return (c1 % 16 == 0 && nout % 4 == 0 && (size_t)hout * wout * (c1 > nout ? c1 : nout) * 4 < ((size_t)1 << 31)) ? 1 : 0;
+  return (dtype == MIA_BF16 && c1 == 64 && nout == 64 && hout > 8) ? 1 : 0;
 }
 
 extern "C" int mia_conv_mma_nl(int mode, int dtype, const void* y_in, int c1, const float* in_scale, const float* in_shift,

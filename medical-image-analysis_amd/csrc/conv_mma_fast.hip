@@ -26,8 +26,13 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 // commit() turns every staged fp32 unit into (hi | lo) words, an MFMA step is two 16x16x32 bf16 instructions (operands to 2^-17).
 // 2 = three-way (Split3): the A tile is staged twice ((h | m) and (h | l) words), the weights as (h | m) words plus 8 bytes of l
 // parts, an MFMA step is three instructions covering six part products (~2^-24 per product: the accuracy of the fp32 kernel).
-template <typename T, int MODE, int MT, int NT, int WC = 1, int SPLIT = 0>
+// NL (T = float, stride-1 3x3, one source): normalise-on-load -- in1 is the RAW conv output of the producing PlainBlock and commit()
+// forms lrelu(nl_scale[n][c] * y + nl_shift[n][c]) (zero outside the image) with the arithmetic of norm_act_fwd_stream_kernel<float>,
+// so that block's normalise + LeakyReLU pass never runs (the fp32 twin of conv64_persist_kernel<NL>; every level, because in fp32 every
+// level's conv is this register-staged kernel).  The eight coefficients of a thread's unit travel with the chunk's prefetch.
+template <typename T, int MODE, int MT, int NT, int WC = 1, int SPLIT = 0, bool NL = false>
 __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_mma_fast_kernel(const ConvArgs a) {
+  static_assert(!NL || (sizeof(T) == 4 && MODE == MODE_G3S1 && WC == 1), "normalise-on-load: fp32, stride-1 3x3");
   static_assert(SPLIT == 0 || sizeof(T) == 4, "split mode is a mode of the fp32 kernel");
   static_assert(SPLIT != 2 || WC == 1, "three-way split: 256-thread shapes only");
   using G = Geo<MODE, MT>;
@@ -158,7 +163,12 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   }
 
   u32x4 pa[A_IT], pb[B_IT];
+  f32x4 nsc = {0.f, 0.f, 0.f, 0.f}, nsh = {0.f, 0.f, 0.f, 0.f};  // NL: scale / shift of channels c0 + 4g .. + 3 of this image
   auto fetch = [&](int c0) {
+    if constexpr (NL) {
+      nsc = *reinterpret_cast<const f32x4*>(a.nl_scale + (size_t)img * a.c1 + c0 + 4 * g);
+      nsh = *reinterpret_cast<const f32x4*>(a.nl_shift + (size_t)img * a.c1 + c0 + 4 * g);
+    }
     const bool second = c0 >= a.c1;  // uniform: chunks never straddle the two sources
     const rsrc_t rs = second ? rs2 : rs1;
     const unsigned cs_es = (unsigned)((second ? a.c2 : a.c1) * ES);
@@ -177,6 +187,19 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
     }
   };
   auto commit = [&]() {
+    if constexpr (NL) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const f32x4 y = __builtin_bit_cast(f32x4, pa[i]);
+        f32x4 z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = nsc[e] * y[e] + nsh[e];
+          z[e] = ((a_valid >> i) & 1u) ? (v > 0.f ? v : v * a.nl_slope) : 0.f;  // zero padding is padding of z, not of y
+        }
+        pa[i] = __builtin_bit_cast(u32x4, z);
+      }
+    }
     if constexpr (SPLIT == 2) {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
@@ -428,17 +451,31 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   if (second_part) store_to(true);
 }
 
-template <typename T, int MODE, int MT, int NT, int WC = 1, int SPLIT = 0>
+template <typename T, int MODE, int MT, int NT, int WC = 1, int SPLIT = 0, bool NL = false>
 static void flaunch(const ConvArgs& a, int grid_y, hipStream_t st) {
   int grid_x = a.N * a.tiles_x * a.tiles_y * a.nblk_n;
   if (a.xcd) {  // groups of (channel blocks x parity classes) per tile, tiles rounded up to a multiple of 8
     grid_x = ((a.N * a.tiles_x * a.tiles_y + 7) / 8) * 8 * a.nblk_n * grid_y;
     grid_y = 1;
   }
-  hipLaunchKernelGGL((conv_mma_fast_kernel<T, MODE, MT, NT, WC, SPLIT>), dim3(grid_x, grid_y), dim3(256 * WC), 0, st, a);
+  hipLaunchKernelGGL((conv_mma_fast_kernel<T, MODE, MT, NT, WC, SPLIT, NL>), dim3(grid_x, grid_y), dim3(256 * WC), 0, st, a);
+}
+template <typename T, int MODE, int MT, int SPLIT>
+static void flaunch_nl(const ConvArgs& a, int nt, int grid_y, hipStream_t st) {  // fp32 stride-1 3x3 with normalise-on-load
+  if (nt == 4) flaunch<T, MODE, MT, 4, 1, SPLIT, true>(a, grid_y, st);
+  else if (nt == 2) flaunch<T, MODE, MT, 2, 1, SPLIT, true>(a, grid_y, st);
+  else flaunch<T, MODE, MT, 1, 1, SPLIT, true>(a, grid_y, st);
 }
 template <typename T, int MODE, int MT>
 static void flaunch_nt(const ConvArgs& a, int nt, int grid_y, hipStream_t st) {
+  if constexpr (sizeof(T) == 4 && MODE == MODE_G3S1) {
+    if (a.nl_scale != nullptr) {
+      if (a.split == 2) flaunch_nl<T, MODE, MT, 2>(a, nt, grid_y, st);
+      else if (a.split) flaunch_nl<T, MODE, MT, 1>(a, nt, grid_y, st);
+      else flaunch_nl<T, MODE, MT, 0>(a, nt, grid_y, st);
+      return;
+    }
+  }
   if constexpr (sizeof(T) == 4) {
     if (a.split == 2) {  // fp32 tensors, three-way split products (fp32 accuracy)
       if (nt == 4) flaunch<T, MODE, MT, 4, 1, 2>(a, grid_y, st);

@@ -1631,8 +1631,11 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgArgs a) {
 // LDS holds one (hi | lo << 16) word per element in the exact kernel's layout; the reduction dimension of an MFMA is 16 pixels
 // (one tile row) x 2 parts: lane group q takes pixels q, q + 4, q + 8, q + 12 (the exact kernel's conflict-free bank pattern),
 // the dy fragment is expanded to its (H, H) and (L, L) forms once per row and meets every tap's (h, l) x fragment in two MFMAs.
-template <int MODE, bool NARROW = false, bool SPLIT = false>
+// NL (stride-1 3x3, one source): x1 is the RAW conv output of the producing PlainBlock; lrelu(nl_scale[n][k] * y + nl_shift[n][k]) is
+// formed when the tile is written to LDS (zero outside the image), with the arithmetic of norm_act_fwd_stream_kernel<float>.
+template <int MODE, bool NARROW = false, bool SPLIT = false, bool NL = false>
 __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
+  static_assert(!NL || MODE == MODE_W3S1, "normalise-on-load: stride-1 3x3");
   using G = WGeo<MODE>;
   constexpr int KS = G::KS, S = G::S, PAD = G::PAD, TAPS = G::TAPS;
   constexpr int TH = (S == 1) ? 4 : 2;
@@ -1674,6 +1677,8 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
     for (int c = 0; c < NC; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 px[X_IT], pd[D_IT];
+  f32x4 nsc = {0.f, 0.f, 0.f, 0.f}, nsh = {0.f, 0.f, 0.f, 0.f};  // NL: coefficients of channels kloc + 4 ch4 .. + 3 of the fetched tile's image
+  unsigned xvalid = 0;                                            //     and which of the thread's X_IT pixels lie inside the image
   const int ntiles = a.N * a.tiles_x * a.tiles_y;
   auto fetch = [&](int tile) {
     int tt = tile;
@@ -1684,12 +1689,19 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
     const wrsrc_t rx = wmake_rsrc(xsrc + (size_t)img * xpix * cs, (unsigned)(xpix * cs * 4));
     const wrsrc_t rd = wmake_rsrc(dy + (size_t)img * ypix * a.cdy, (unsigned)(ypix * a.cdy * 4));
+    if constexpr (NL) {
+      const bool cok = kloc + ch4 * 4 < cs;
+      nsc = cok ? *reinterpret_cast<const f32x4*>(a.nl_scale + (size_t)img * cs + kloc + ch4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      nsh = cok ? *reinterpret_cast<const f32x4*>(a.nl_shift + (size_t)img * cs + kloc + ch4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      xvalid = 0;
+    }
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
       const int gy = iy0 + x_iy[i], gx = ix0 + x_ix[i];
       const bool ok = gy >= 0 && gy < a.Hx && gx >= 0 && gx < a.Wx;
       const unsigned voff = (ok && kloc + ch4 * 4 < cs) ? (unsigned)(((gy * a.Wx + gx) * cs + kloc + ch4 * 4) * 4) : WSENT;
       px[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, 0, 0);
+      if constexpr (NL) xvalid |= (ok ? 1u : 0u) << i;
     }
 #pragma unroll
     for (int i = 0; i < D_IT; ++i) {
@@ -1705,6 +1717,19 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
   if (tile < ntiles) fetch(tile);
   for (; tile < ntiles; tile += a.ksplit) {
     __syncthreads();
+    if constexpr (NL) {
+#pragma unroll
+      for (int i = 0; i < X_IT; ++i) {
+        const f32x4 y = __builtin_bit_cast(f32x4, px[i]);
+        f32x4 z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = nsc[e] * y[e] + nsh[e];
+          z[e] = ((xvalid >> i) & 1u) ? (v > 0.f ? v : v * a.nl_slope) : 0.f;
+        }
+        px[i] = __builtin_bit_cast(u32x4, z);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) *reinterpret_cast<u32x4*>(xs + (p16 + 16 * i) * PS + ch4 * 4) = SPLIT ? SplitBf16::unit(px[i]) : px[i];
 #pragma unroll
@@ -1976,6 +2001,25 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
     a.opt |= 16;
     fgrid = dim3(fgrid.x * (unsigned)(ceil_div(ksplit, 8) * 8), 1);
   }
+  if (nl_scale != nullptr && dtype == MIA_F32) {  // fp32 normalise-on-load: the register-staged fp32 kernel, exact or split products
+    const bool f32fast = chan_ok && (size_t)hx * wx * c1 * 4 < lim && (size_t)hy * wy * cdy * 4 < lim;
+    if (!(f32fast && mode == MODE_W3S1 && c2 == 0 && (reinterpret_cast<uintptr_t>(nl_scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(nl_shift) & 15) == 0)) {
+      mia_set_error("mia_conv_wgrad_nl: shape outside the fp32 normalise-on-load contract (ask mia_wgrad_nl_supported first)");
+      return MIA_EUNSUPPORTED;
+    }
+    a.tiles_y = ceil_div(hy, 4);
+    a.tiles_x = ceil_div(wy, 16);
+    const bool narrow = cdy <= 32 && c1 <= 32;
+    if (o.f32_split == 1) {
+      if (narrow) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, true, true, true>), fgrid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, false, true, true>), fgrid, dim3(256), 0, st, a);
+    } else {
+      if (narrow) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, true, false, true>), fgrid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, false, false, true>), fgrid, dim3(256), 0, st, a);
+    }
+    MIA_LAUNCH_CHECK();
+    return MIA_OK;
+  }
   if (nl_scale != nullptr) {  // normalise-on-load: the register-staged two-workgroup kernel is the one that transforms
     if (!(fast && mode == MODE_W3S1 && c2 == 0)) {
       mia_set_error("mia_conv_wgrad_nl: shape outside the normalise-on-load kernel's contract (ask mia_wgrad_nl_supported first)");
@@ -2053,7 +2097,9 @@ extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const
 
 // Weight gradient with normalise-on-load of x (the backward half of the fused PlainBlock): see include/mia_hip.h.
 extern "C" int mia_wgrad_nl_supported(int mode, int dtype, int c1, int cdy) {
-  return (mode == MODE_W3S1 && dtype == MIA_BF16 && c1 % 8 == 0 && cdy % 8 == 0) ? 1 : 0;
+  if (mode != MODE_W3S1) return 0;
+  if (dtype == MIA_F32) return (c1 % 4 == 0 && cdy % 4 == 0) ? 1 : 0;
+  return (dtype == MIA_BF16 && c1 % 8 == 0 && cdy % 8 == 0) ? 1 : 0;
 }
 
 extern "C" int mia_conv_wgrad_nl(int mode, int dtype, const void* y_in, int c1, const float* in_scale, const float* in_shift,

@@ -560,15 +560,17 @@ class LazyMaterializeFn(torch.autograd.Function):
 FUSE_HEAD_W = __import__('os').environ.get('MIA_FUSE_HEAD_W', '1') != '0'  # A/B knob: head dW / db in the norm-backward reduction pass
 FUSE_STEM_BWD = __import__('os').environ.get('MIA_FUSE_STEM_BWD', '1') != '0'  # A/B knob: the stem's backward apply pass folded into its weight gradient
 FUSE_NL = __import__('os').environ.get('MIA_FUSE_NL', '1') != '0'  # A/B knob: 0 = every block materialises its activation
+FUSE_NL_F32 = __import__('os').environ.get('MIA_FUSE_NL_F32', '0') != '0'  # normalise-on-load pairs in fp32 models (every level; bit-identical; measured +-0 on cfg2 / cfg4: off)
 
 
 def nl_supported(dtype, cin: int, cout: int, h: int, w: int, train: bool) -> bool:
     """Can a stride-1 3x3 block with these shapes consume its predecessor's raw output (normalise-on-load)?"""
-    if not FUSE_NL or dtype != torch.bfloat16:
+    if not FUSE_NL or dtype not in (torch.bfloat16, torch.float32) or (dtype == torch.float32 and not FUSE_NL_F32):
         return False
-    if not lib().mia_conv_nl_supported(CONV_G3S1, BF16, cin, cout, h, w):
+    dtc = _dt(dtype)  # bf16: the 64 -> 64 register-staged kernels; fp32: every shape of the branch-free tile kernels (all levels)
+    if not lib().mia_conv_nl_supported(CONV_G3S1, dtc, cin, cout, h, w):
         return False
-    return (not train) or bool(lib().mia_wgrad_nl_supported(WGRAD_3S1, BF16, cin, cout))
+    return (not train) or bool(lib().mia_wgrad_nl_supported(WGRAD_3S1, dtc, cin, cout))
 
 
 class PlainBlockFn(torch.autograd.Function):

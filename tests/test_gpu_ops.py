@@ -1629,3 +1629,112 @@ def test_batched_weight_pack_matches_per_tensor_pack():
                 ref, npad2, kpad2 = ops.PackCache().get(w, dt, n_from_d0=orient)   # a fresh per-tensor pack of the same values
                 assert (npad, kpad) == (npad2, kpad2)
                 assert got.data_ptr() != ref.data_ptr() and torch.equal(got, ref), (tuple(w.shape), orient, dt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 64, 37, 53), (1, 32, 48, 16, 16), (3, 128, 64, 24, 40), (2, 16, 16, 9, 200)])
+@pytest.mark.parametrize("split", [0, 1])
+def test_fp32_normalise_on_load_matches_materialised_path(case, split):
+    """fp32 twin of the fused PlainBlock (round 4): `mia_conv_mma_nl` / `mia_conv_wgrad_nl` on the register-staged fp32 tile kernels
+    (exact and split-bf16 products) against `mia_norm_act_fwd` + the plain calls on the same raw producer output and coefficient
+    table: BIT-IDENTICAL outputs, statistics and weight gradients (same kernel, same fp32 fma / select, zero padding of z not of y),
+    ragged tiles, several images, per-(n, c) coefficients of both signs incl. dropped channels."""
+    import mia_hip
+    from mia_hip import CONV_G3S1, WGRAD_3S1, call, ops
+    from mia_hip.ops import _c_float, _c_i64, _p, _stream
+    dev = _dev()
+    n, c, cout, h, w = case
+    g = torch.Generator().manual_seed(7 + c + h)
+    y = (torch.randn(n, h, w, c, generator=g) * 1.5).to(dev)
+    coefs = torch.zeros(5, n, c)
+    coefs[2] = torch.randn(n, c, generator=g)
+    coefs[3] = torch.randn(n, c, generator=g) * 0.7
+    coefs[2][:, 5] = 0.0
+    coefs[2][0, 9], coefs[3][0, 9] = 0.0, 0.0
+    coefs = coefs.to(dev)
+    wt = (torch.randn(cout, c, 3, 3, generator=g) / math.sqrt(9 * c)).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    dy = torch.randn(n, h, w, cout, generator=g).to(dev)
+    slope = 0.01
+    old, old_flag = mia_hip.get_option("f32_split"), ops.FUSE_NL_F32
+    mia_hip.set_option("f32_split", split)
+    ops.FUSE_NL_F32 = True
+    try:
+        assert ops.nl_supported(torch.float32, c, cout, h, w, True)
+        wp, npad, kpad = ops.PackCache().get(wt, mia_hip.F32, True)
+        z = torch.empty_like(y)
+        call("mia_norm_act_fwd", _p(y), _p(z), mia_hip.F32, _p(coefs[2]), _p(coefs[3]), n, _c_i64(h * w), c, _c_float(slope), _stream())
+        ref, _, ref_stats = ops.conv_mma(CONV_G3S1, z, None, wp, npad, kpad, False, bias, cout, (h, w), want_stats=True)
+        got, _, got_stats = ops.conv_mma(CONV_G3S1, y, None, wp, npad, kpad, False, bias, cout, (h, w), want_stats=True, nl=(coefs, slope))
+        assert torch.equal(got, ref) and torch.equal(got_stats, ref_stats)
+        dw_ref = ops.conv_wgrad(WGRAD_3S1, z, None, dy, wt.shape, cout, c)
+        dw_nl = ops.conv_wgrad(WGRAD_3S1, y, None, dy, wt.shape, cout, c, nl=(coefs, slope))
+        assert torch.equal(dw_nl, dw_ref)
+        zc = z.cpu().permute(0, 3, 1, 2).double()
+        want = F.conv2d(zc, wt.cpu().double(), bias.cpu().double(), padding=1)
+        assert relerr(nchw(got), want) < (SPLIT_TOL if split else TOL[torch.float32])
+    finally:
+        mia_hip.set_option("f32_split", old)
+        ops.FUSE_NL_F32 = old_flag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm,drop", [("instance", None), ("batch", 0.2)])
+def test_fp32_fused_pairs_match_unfused_model(norm, drop):
+    """An fp32 UNet runs the two blocks of EVERY level as a fused pair (ops.LazyAct: in fp32 every stride-1 conv and weight gradient is
+    the register-staged tile kernel).  Against the same model with `ops.FUSE_NL_F32 = False`: logits, loss, every gradient, eval-mode
+    outputs and pixel features BIT-IDENTICAL (same kernels, same arithmetic; only the separate normalise + LeakyReLU pass is gone)."""
+    from losses.compound_losses import DiceAndCELoss
+    from mia_hip import ops
+    from models.unet import UNet
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(3, 1, 48, 80, generator=g).to(dev)
+    lab = torch.randint(0, 3, (3, 48, 80), generator=g).to(dev)
+    loss_fn = DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True), ce_loss=torch.nn.CrossEntropyLoss)
+    res, calls = {}, {}
+    old = ops.FUSE_NL_F32
+    raw_call = ops.call
+    try:
+        for fuse in (False, True):
+            ops.FUSE_NL_F32 = fuse
+            torch.manual_seed(11)
+            m = UNet(2, 1, 3, [16, 32, 64], normalization=norm, dropout_prob=drop).to(dev)
+            gp = torch.Generator().manual_seed(17)
+            with torch.no_grad():
+                for p in m.parameters():
+                    if p.ndim == 1:
+                        p.add_(0.1 * torch.randn(p.shape, generator=gp).to(dev))
+            m.train()
+            torch.manual_seed(5)
+            torch.cuda.manual_seed(5)
+            count = {"apply": 0, "nl": 0}
+
+            def counting(name, *a, _c=count):
+                if name == "mia_norm_act_fwd":
+                    _c["apply"] += 1
+                if name in ("mia_conv_mma_nl", "mia_conv_wgrad_nl"):
+                    _c["nl"] += 1
+                return raw_call(name, *a)
+
+            ops.call = counting
+            out = m(x)
+            loss = loss_fn(out, lab)
+            loss.backward()
+            ops.call = raw_call
+            grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+            m.eval()
+            with torch.no_grad():
+                ev = m(x).clone()
+                feat = m.get_pixel_feature(x)[1].clone()
+            res[fuse], calls[fuse] = (out.detach().clone(), loss.item(), grads, ev, feat), count
+    finally:
+        ops.FUSE_NL_F32 = old
+        ops.call = raw_call
+    a, b = res[False], res[True]
+    assert calls[False]["nl"] == 0 and calls[True]["nl"] >= 2 * 5   # 3 encoder + 2 decoder pairs: a conv and a weight gradient each
+    assert calls[True]["apply"] <= calls[False]["apply"] - 5
+    assert torch.equal(a[0], b[0]) and a[1] == b[1]
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
