@@ -402,6 +402,7 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
     }
     rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
   }
+  else if (nl_scale != nullptr && opt.conv64_wino && mt == 4 && conv64_wino_eligible(mode, dtype, a)) rc = conv64_wino_launch(a, opt.reserve_cus, st);
   else if (nl_scale != nullptr) {  // normalise-on-load: the register-staged 64-channel kernel is the one consumer that transforms
     if (!(mt == 4 && conv64_eligible(mode, dtype, a))) {
       mia_set_error("mia_conv_mma_nl: shape outside the normalise-on-load kernel's contract (ask mia_conv_nl_supported first)");
@@ -409,6 +410,7 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
     }
     rc = conv64_launch(a, opt.conv64_blocks, opt.reserve_cus, st);
   }
+  else if (opt.conv64_wino && mt == 4 && conv64_wino_eligible(mode, dtype, a)) rc = conv64_wino_launch(a, opt.reserve_cus, st);
   else if (opt.conv64 && opt.conv64_dma && (opt.conv64_dma >= 2 || a.o2 != 0) && mt == 4 && conv64_dma_eligible(mode, dtype, a)) rc = conv64_dma_launch(a, opt.reserve_cus, st);
   else if (opt.conv64 && mt == 4 && conv64_eligible(mode, dtype, a)) rc = conv64_launch(a, opt.conv64_blocks, opt.reserve_cus, st);
   else if (opt.conv_bt && mt == 4 && conv_bt_eligible(mode, dtype, a)) rc = conv_bt_launch(a, opt.conv_bt_order, opt.reserve_cus, st);

@@ -21,6 +21,7 @@ struct MiaOptions {
   int conv_pw;        // ConvTranspose 2x2 stride 2 forward / input gradient (bf16) as one pointwise GEMM on the LDS-DMA ring   env MIA_CONV_PW       default 1
   int conv_pw_s2;     // stride-2 3x3 bf16 forward as a tap-gathered GEMM on the conv_pw ring (needs conv_pw; 1: up to 256 input channels, 2: always; -0.13 ms of kernel time per cfg3 step measured INSIDE the step with rocprofv3, two interleaved pairs)   env MIA_CONV_PW_S2    default 1
   int conv_pw_t3;     // stride-2 3x3 INPUT GRADIENT (bf16, >= 64 output channels, >= 128 dy channels) as exact-tap GEMMs per output-parity class on the conv_pw ring, incl. the accumulating form (needs conv_pw; measured SLOWER than the tile kernel at every cfg3 level, profiles/r04_ab_conv_pw_t3.txt)   env MIA_CONV_PW_T3    default 0
+  int conv64_wino;    // EXPERIMENT: the 64 -> 64 3x3 stride-1 bf16 conv (plain and normalise-on-load) as Winograd F(2x2, 3x3) (conv64w.hip): 2.25x fewer MFMAs, bf16-rounded transforms   env MIA_CONV64_WINO   default 0
   int conv_mt8;       // 32-row tiles of the tile kernel (experiment)                          env MIA_CONV_MT8      default 0
   int conv64_blocks;  // workgroups of conv64_persist_kernel, 0 = library default (512)        env MIA_CONV64_BLOCKS default 0
   int wgrad_xcd;      // XCD-aware block order of the bf16 weight-gradient kernels             env MIA_WGRAD_XCD     default 1

@@ -33,6 +33,7 @@ Entry g_table[] = {
     {"wgrad_narrow", "MIA_WGRAD_NARROW", 0, 0, 1, {0}},
     {"f32_split", "MIA_F32_SPLIT", 0, 0, 2, {0}},
     {"conv_pw_t3", "MIA_CONV_PW_T3", 0, 0, 1, {0}},
+    {"conv64_wino", "MIA_CONV64_WINO", 0, 0, 1, {0}},
 };
 constexpr int N_OPT = (int)(sizeof(g_table) / sizeof(g_table[0]));
 std::once_flag g_env_once;
@@ -62,7 +63,7 @@ MiaOptions mia_options() {
   MiaOptions o;
   o.conv_xcd = get(0); o.conv64 = get(1); o.conv_bt = get(2); o.conv_mt8 = get(3); o.conv64_blocks = get(4);
   o.wgrad_xcd = get(5); o.wgrad_dma = get(6); o.wgrad_tab = get(7); o.wgrad_w8 = get(8); o.stream_blocks = get(9);
-  o.stem_mfma = get(10); o.conv_bt_order = get(11); o.wgrad_bt = get(12); o.conv64_dma = get(13); o.conv_s2_wide = get(14); o.conv_pw = get(15); o.conv_pw_s2 = get(16); o.wgrad_t2 = get(17); o.reserve_cus = get(18); o.conv_t3_wide = get(19); o.wgrad_narrow = get(20); o.f32_split = get(21); o.conv_pw_t3 = get(22);
+  o.stem_mfma = get(10); o.conv_bt_order = get(11); o.wgrad_bt = get(12); o.conv64_dma = get(13); o.conv_s2_wide = get(14); o.conv_pw = get(15); o.conv_pw_s2 = get(16); o.wgrad_t2 = get(17); o.reserve_cus = get(18); o.conv_t3_wide = get(19); o.wgrad_narrow = get(20); o.f32_split = get(21); o.conv_pw_t3 = get(22); o.conv64_wino = get(23);
   return o;
 }
 

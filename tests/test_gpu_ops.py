@@ -1738,3 +1738,57 @@ def test_fp32_fused_pairs_match_unfused_model(norm, drop):
     assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
     for k in a[2]:
         assert torch.equal(a[2][k], b[2][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 37, 53), (1, 16, 16), (3, 64, 48), (1, 9, 200), (2, 128, 128)])
+def test_conv64_winograd_matches_direct_kernel(case):
+    """Option conv64_wino (EXPERIMENT, csrc/conv64w.hip): the 64 -> 64 3x3 stride-1 bf16 conv as Winograd F(2x2, 3x3) -- forward with
+    bias + statistics, flipped taps (the input gradient), and normalise-on-load -- against the direct conv64 kernel and fp32-CPU math on the
+    same bf16 operands.  bf16-rounded transforms: tolerance 2.5x the direct kernel's, ragged tiles."""
+    import mia_hip
+    from mia_hip import CONV_G3S1, call, ops
+    from mia_hip.ops import _c_float, _c_i64, _p, _stream
+    dev = _dev()
+    n, h, w = case
+    c = 64
+    g = torch.Generator().manual_seed(n * h + w)
+    x = F.leaky_relu(torch.randn(n, h, w, c, generator=g), 0.01).to(dev, torch.bfloat16)
+    wt = (torch.randn(c, c, 3, 3, generator=g) / 24).to(dev)
+    bias = torch.randn(c, generator=g).to(dev)
+    coefs = torch.zeros(5, n, c)
+    coefs[2] = torch.randn(n, c, generator=g)
+    coefs[3] = torch.randn(n, c, generator=g) * 0.7
+    coefs = coefs.to(dev)
+    pc = ops.PackCache()
+    wp, npad, kpad = pc.get(wt, mia_hip.BF16, True)
+    wb, npb, kpb = pc.get(wt, mia_hip.BF16, False)
+    xc = x.float().cpu().permute(0, 3, 1, 2)
+    want = F.conv2d(xc, wt.cpu().to(torch.bfloat16).float(), bias.cpu(), padding=1)
+    want_dx = F.conv_transpose2d(xc, wt.cpu().to(torch.bfloat16).float(), padding=1)  # x plays dy: dgrad = flipped taps, transposed channels
+    old = mia_hip.get_option("conv64_wino")
+    res = {}
+    try:
+        for v in (0, 1):
+            mia_hip.set_option("conv64_wino", v)
+            y, _, st = ops.conv_mma(CONV_G3S1, x, None, wp, npad, kpad, False, bias, c, (h, w), want_stats=True)
+            dx, _, _ = ops.conv_mma(CONV_G3S1, x, None, wb, npb, kpb, True, None, c, (h, w))
+            if ops.nl_supported(torch.bfloat16, c, c, h, w, False):
+                ynl, _, stnl = ops.conv_mma(CONV_G3S1, x, None, wp, npad, kpad, False, bias, c, (h, w), want_stats=True, nl=(coefs, 0.01))
+            else:
+                ynl, stnl = None, None
+            res[v] = (y, st.sum(1), dx, ynl, None if stnl is None else stnl.sum(1))
+    finally:
+        mia_hip.set_option("conv64_wino", old)
+    d, wv = res[0], res[1]
+    assert relerr(nchw(d[0]), want) < 1e-2 and relerr(nchw(wv[0]), want) < 2.5e-2
+    assert relerr(nchw(d[2]), want_dx) < 1e-2 and relerr(nchw(wv[2]), want_dx) < 2.5e-2
+    if h > 8:
+        assert not torch.equal(wv[0], d[0])  # the Winograd kernel ran
+    assert torch.allclose(wv[1].cpu(), d[1].cpu(), rtol=2e-2, atol=2e-2 * d[1].abs().max().item())
+    if d[3] is not None:
+        z = torch.empty_like(x)
+        call("mia_norm_act_fwd", _p(x), _p(z), mia_hip.BF16, _p(coefs[2]), _p(coefs[3]), n, _c_i64(h * w), c, _c_float(0.01), _stream())
+        want_nl = F.conv2d(z.float().cpu().permute(0, 3, 1, 2), wt.cpu().to(torch.bfloat16).float(), bias.cpu(), padding=1)
+        assert relerr(nchw(d[3]), want_nl) < 1e-2 and relerr(nchw(wv[3]), want_nl) < 2.5e-2
+        assert torch.allclose(wv[4].cpu(), d[4].cpu(), rtol=2e-2, atol=2e-2 * d[4].abs().max().item())
