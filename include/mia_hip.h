@@ -100,11 +100,12 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
  *   conv_pw_t3 (MIA_CONV_PW_T3, 0)    input gradient of the stride-2 3x3 conv (bf16) as exact-tap GEMMs per output-parity class on the
  *                                  conv_pw ring (also the accumulating form of mia_conv_mma_acc); fp32 summation order differs
  *                                  from the tile kernel's; slower than the tile kernel on the benchmarked shapes: off
- *   f32_split (MIA_F32_SPLIT, 0)      fp32 convs / weight gradients of the branch-free tile kernels on the bf16 matrix cores:
- *                                  every operand element enters as hi + lo (two bf16, 16-17 significant bits), four exact products,
- *                                  fp32 accumulation.  NOT bit-identical to the exact fp32 kernels (logits ~3e-5 instead of ~4e-6
- *                                  from the fp32 CPU reference); ~1.9x on the fp32 training step.  Tensors stay fp32.  Value 2 (experiment,
- *                                  conv kernel only): three bf16 parts, six products in three MFMAs -- fp32 accuracy, 1.25x.
+ *   f32_split (MIA_F32_SPLIT, 1)      fp32 convs / weight gradients of the branch-free tile kernels on the f16 matrix cores: every
+ *                                  operand element, scaled by a per-tensor power of two taken from the tensor's max |x| (the amax_*
+ *                                  arguments below), enters as h + l (two fp16: 22-23 significand bits), four exact products, fp32
+ *                                  accumulation, exact rescaling.  Accuracy of the exact fp32 MFMA kernels (not bit-identical to
+ *                                  them), ~2x on the fp32 training step.  Tensors stay fp32.  A call without the maxima, or value 0,
+ *                                  runs the exact fp32 MFMA kernels.
  *   reserve_cus (MIA_RESERVE_CUS, 0)   CUs the persistent kernels leave free (0..64, rounded so that the grids stay
  *                                  multiples of 8): the grids of conv_bt / conv_pw / conv64 / conv64_dma shrink to CUs - k
  *                                  workgroups (same work items: bit-identical results) and mia_wgrad_target_blocks follows
@@ -122,9 +123,22 @@ int mia_get_option(const char* name, int* value);
  * (feeds mia_norm_finalize; replaces the statistics pass of InstanceNorm2d/BatchNorm2d, blocks.py:98).
  * tiles = tiles_y * tiles_x from mia_conv_mma_tiles(). */
 int mia_conv_mma_tiles(int mode, int hout, int wout, int* tiles_y, int* tiles_x, int* tile_h);
+/* amax_in1 / amax_in2 / amax_w (optional, fp32 tensors only): device pointers to max |x| of in1 / in2 / the weight tensor as fp32
+ * bit patterns (mia_amax / mia_amax_batch).  All present (amax_in2 only when c2 > 0) and option f32_split on: the products run on the
+ * f16 matrix cores from two-part split operands (see f32_split above); any of them NULL: exact fp32 MFMAs. */
 int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const void* in2, int c2, const void* wpack, int npad,
                  int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2, int o2,
-                 float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream);
+                 float* stat_partials, int n, int hin, int win, int hout, int wout, const void* amax_in1, const void* amax_in2,
+                 const void* amax_w, void* stream);
+/* max |x| of an fp32 tensor of n elements, folded (atomic unsigned maximum of the fp32 bit pattern: order-independent, deterministic)
+ * into *slot; reset != 0 zeroes the slot first (stream-ordered, by a kernel: hipMemsetAsync nodes on graph-pool memory were seen to
+ * replay wrongly inside a captured step).  The batched form takes a device table of `count`
+ * {const float* src; int64_t n;} records (mia_amax_desc_bytes() each) and writes slots[0 .. count): every weight of a model in one
+ * launch after the optimizer step.  These maxima are the scale source of the split-f16 products (no reference counterpart: the
+ * reference multiplies in fp32, blocks.py:83-90). */
+int mia_amax(const float* x, int64_t n, void* slot, int reset, void* stream);
+int mia_amax_desc_bytes(void);
+int mia_amax_batch(const void* descs_dev, int count, void* slots, void* stream);
 
 /* Fused PlainBlock, consumer side ("normalise-on-load"; SURVEY 8b export list: conv3x3 with "optional fused normalise +
  * LeakyReLU on load taking per-(n,c) scale/shift").  Replaces, for a PlainBlock whose only consumer is the next block's conv
@@ -153,7 +167,8 @@ int mia_conv_mma_nl(int mode, int dtype, const void* y_in, int c1, const float* 
  * epilogue (read-modify-write), and the skip block's norm backward reads one gradient tensor instead of two. */
 int mia_conv_acc_supported(int mode, int dtype, int c1, int nout);
 int mia_conv_mma_acc(int mode, int dtype, const void* in1, int c1, const void* wpack, int npad, int kpad, int flip_taps,
-                     void* out_inout, int nout, int n, int hin, int win, int hout, int wout, void* stream);
+                     void* out_inout, int nout, int n, int hin, int win, int hout, int wout, const void* amax_in, const void* amax_w,
+                     void* stream);
 
 int mia_conv_cr_supported(int mode, int dtype, int c1, int nout, int hout, int wout);
 int mia_conv_mma_cr(int mode, int dtype, const void* in1, int c1, const void* wpack, int npad, int kpad, int flip_taps,
@@ -187,7 +202,8 @@ int mia_stem_wgrad_fused(const void* x, int x_dtype, const void* dz, const void*
 int mia_wgrad_target_blocks(int mode, int dtype); /* split-K workgroups to aim for (ksplit = target / (npad/64 * kpad/64)) */
 int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x);
 int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const void* x2, int c2, const void* dy, int cdy,
-                   float* slabs, int ksplit, int npad, int kpad, int n, int hx, int wx, int hy, int wy, void* stream);
+                   float* slabs, int ksplit, int npad, int kpad, int n, int hx, int wx, int hy, int wy, const void* amax_x1,
+                   const void* amax_x2, const void* amax_dy, void* stream); /* amax_*: as for mia_conv_mma */
 /* mia_conv_wgrad with normalise-on-load of x (backward half of the fused PlainBlock, see mia_conv_mma_nl): y_in is the raw
  * conv output of the PRODUCING block, x = lrelu(in_scale[n][k] * y + in_shift[n][k]) is formed while the tile is staged (zero
  * outside the image), so the activation the weight gradient of blocks.py:83-90 contracts with is never read from memory.
@@ -211,8 +227,11 @@ int mia_norm_finalize(const float* partials, int n, int tiles, int c, int64_t hw
                       float* scale, float* shift, float* ysum, void* stream);
 /* stand-alone statistics partials [N][slabs][C][2] when no conv epilogue produced them */
 int mia_norm_stats(const void* y, int dtype, int n, int64_t hw, int c, int slabs, float* partials, void* stream);
+/* amax_out (nullable; here and in the backward forms below): 4-byte device slot, ZEROED by the caller, into which max |output| is
+ * folded as an fp32 bit pattern during the same pass (atomic unsigned maximum; fp32 tensors, ignored for bf16) -- the scale source
+ * of the split-f16 convs that consume the output (mia_conv_mma amax_*), so no separate mia_amax pass over it is needed. */
 int mia_norm_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift, int n, int64_t hw, int c,
-                     float slope, void* stream);
+                     float slope, void* amax_out, void* stream);
 /* dz2 (nullable, here and in the _reduce / _apply_sync forms): a second piece of the output gradient, summed on load --
  * the two consumers of a skip tensor (unet.py:213 and the next encoder level) each deliver one; needs c % 32 == 0
  * (mia_norm_two_piece_ok). */
@@ -223,7 +242,7 @@ int mia_norm_two_piece_ok(int dtype, int c);
 int mia_norm_act_bwd(const void* dz, const void* dz2, const void* y, void* dy, int dtype, const float* scale, const float* shift,
                      const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
                      int fixed_stats, float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma,
-                     float* dbeta, float* dbias, int accumulate, void* stream);
+                     float* dbeta, float* dbias, int accumulate, void* amax_out, void* stream);
 /* mia_norm_act_bwd without its apply pass (no dy is written): reduction + finalize only -- c1 / c2 (group means of g and
  * g * xhat), dgamma, dbeta, dbias.  For a block whose only consumer of dy forms it on load (mia_stem_wgrad_fused). */
 int mia_norm_bwd_sums(const void* dz, const void* dz2, const void* y, int dtype, const float* scale, const float* shift,
@@ -235,7 +254,7 @@ int mia_norm_bwd_sums(const void* dz, const void* dz2, const void* y, int dtype,
 int mia_norm_act_bwd_pre(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
                          const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
                          int fixed_stats, float slope, int parts, const float* partials, float* c1, float* c2,
-                         float* dgamma, float* dbeta, float* dbias, int accumulate, void* stream);
+                         float* dgamma, float* dbeta, float* dbias, int accumulate, void* amax_out, void* stream);
 
 /* Synchronised batch norm for data-parallel runs (build-side addition; SURVEY.md 8e: "a second, small collective"):
  * the caller moves 3*C floats (forward, all-gather) and 2*C floats (backward, all-reduce sum) per layer over RCCL and
@@ -258,7 +277,7 @@ int mia_norm_act_bwd_reduce(const void* dz, const void* dz2, const void* y, int 
 int mia_norm_act_bwd_apply_sync(const void* dz, const void* dz2, const void* y, void* dy, int dtype, const float* scale, const float* shift,
                                 const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, float slope,
                                 float* c1, float* c2, const float* group_tot, float* dgamma, float* dbeta, float* dbias,
-                                int accumulate, void* stream);
+                                int accumulate, void* amax_out, void* stream);
 
 /* ------------------------------------------------------------------ 1x1 head + Dice/CE loss */
 /* seg_output = Conv2d(c0, K1, 1) (unet.py:176), K1 <= 8.  Logits are fp32 with element strides (osn, osk, osp). */
@@ -304,7 +323,7 @@ int mia_norm_act_bwd_head(const float* dlogits, const float* w, int k1, int64_t 
                           void* dy, int dtype, const float* scale, const float* shift, const float* xa, const float* xb,
                           const float* ysum, int n, int64_t hw, int c, int mode, int fixed_stats, float slope, int slabs,
                           float* partials, float* c1, float* c2, float* dgamma, float* dbeta, float* dbias, int accumulate,
-                          void* stream);
+                          void* amax_out, void* stream);
 /* mia_norm_act_bwd_head + mia_head_norm_wgrad in ONE reduction pass (both read exactly dlogits and y): the kernel that adds up the
  * block's norm-backward sums also accumulates the head's dW[k][c] = sum_p dl[p][k] * lrelu(scale * y + shift) and db[k] (unet.py:176
  * backward).  c == 64 (mia_head_w_supported); head_workspace: n * slabs * k1 * (c + 1) floats. */
@@ -314,7 +333,7 @@ int mia_norm_act_bwd_head_w(const float* dlogits, const float* w, int k1, int64_
                             const float* xb, const float* ysum, int n, int64_t hw, int c, int mode, int fixed_stats,
                             float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta,
                             float* dbias, int accumulate, float* head_workspace, float* dw_head, float* db_head,
-                            int accumulate_head, void* stream);
+                            int accumulate_head, void* amax_out, void* stream);
 
 /* ------------------------------------------------------------------ optimizer (al_trainer.py:1374-1379) */
 #define MIA_OPT_ADAM 0

@@ -62,25 +62,39 @@ template <> struct Elem<bf16_t> {
   __device__ static __forceinline__ bf16_t cvt(float v) { return f2bf(v); }
 };
 
-// fp32 tensors on the bf16 matrix cores ("split" mode of the fp32 tile kernels, option f32_split).  Every fp32 operand element
-// becomes ONE 32-bit word (hi | lo << 16): hi = bf16_rne(x), lo = bf16_rne(x - hi), i.e. x to 16-17 significant bits; a 16-byte
-// unit still holds four channels, so LDS layout, staging and fragment reads are those of the exact fp32 kernel.  An A fragment
-// (8 bf16 per lane) is then (h0, l0, h1, l1, h2, l2, h3, l3) and two MFMAs against the B fragment's (H0, H0, H1, H1, ..) and
-// (L0, L0, L1, L1, ..) forms add all four products (h + l)(H + L) of 16 channels: 2 x 16 cycles instead of 4 x 32 for the four
-// v_mfma_f32_16x16x4_f32, fp32 accumulation.  bf16 x bf16 products are exact in fp32, so the only error is the 2^-17 operand
-// representation (measured on the full-width nets: logits within 3e-5 of the exact fp32 path).
-struct SplitBf16 {
-  static __device__ __forceinline__ u32x4 unit(const u32x4& raw) {  // 4 fp32 -> 4 words (hi | lo << 16)
-    typedef __attribute__((ext_vector_type(2))) float f2;
-    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
-    const f32x4 x = __builtin_bit_cast(f32x4, raw);
+// fp32 tensors on the f16 matrix cores ("split" mode of the fp32 tile kernels, option f32_split, ON by default).  An fp32 value has 24
+// significand bits and an fp16 value 11, so x * 2^e = h + l with h = f16_rne(x * 2^e), l = f16_rne(x * 2^e - h) keeps 22-23 of them
+// (bf16 parts keep 8 each: the same accuracy takes three parts and six products).  Every fp32 operand element becomes ONE 32-bit
+// word (h | l << 16): a 16-byte unit still holds four channels, so LDS layout, staging and fragment reads are those of the exact fp32
+// kernel.  An A fragment (8 f16 per lane) is (h0, l0, h1, l1, h2, l2, h3, l3) and two v_mfma_f32_16x16x32_f16 against the B fragment's
+// (H0, H0, H1, H1, ..) and (L0, L0, L1, L1, ..) forms add all four products (h + l)(H + L) of 16 channels: 2 x 16 matrix cycles instead
+// of 4 x 32 for the four v_mfma_f32_16x16x4_f32.  f16 x f16 products are exact in fp32 and accumulation is fp32.
+// RANGE: fp16 spans 2^-24 .. 65504, so each operand tensor is scaled by a power of two (exact) chosen from its max |x| -- the caller
+// hands the kernels a device pointer to that maximum as an fp32 bit pattern (mia_amax, or a producer kernel's by-product) -- such that
+// the maximum lands in [2^14, 2^15); the accumulators are scaled back by 2^-(ea + eb) (v_ldexp_f32, exact) before bias / statistics /
+// store.  Elements down to 2^-18 of the tensor maximum keep all 22 bits (l stays a normal fp16; the f16 MFMA keeps denormal inputs --
+// tools/probe/mfma_f16_denorm.hip), smaller ones keep an ABSOLUTE error <= 2^-40 of the maximum.  Measured on the full-width nets:
+// logits within ~3e-6 of the fp32 CPU oracle (exact fp32 MFMA kernels: 2.4e-6 .. 5.9e-6; the two-part bf16 split of round 4: 3e-5).
+struct SplitF16 {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+  // power-of-two exponent e with amax * 2^e in [2^14, 2^15) from the fp32 bit pattern of amax (0 / denormal amax: e = 120; inf / NaN:
+  // e = -114, the non-finite values then propagate as they would through fp32 products)
+  static __device__ __forceinline__ int exp_of(unsigned amax_bits) {
+    const int e = 141 - (int)((amax_bits >> 23) & 0xFFu);
+    return e > 120 ? 120 : e;
+  }
+  static __device__ __forceinline__ float pow2(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }  // -126 <= e <= 127
+  static __device__ __forceinline__ u32x4 unit(const u32x4& raw, float s) {  // 4 fp32 -> 4 words (h | l << 16) of x * s
+    const f32x4 x = __builtin_bit_cast(f32x4, raw) * s;
     u32x4 o;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const f2 v = {x[2 * p], x[2 * p + 1]};
-      const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));  // h0 | h1 << 16
-      const f2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xFFFF0000u)};
-      const unsigned lp = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, b2));  // l0 | l1 << 16
+      const h2 hh = __builtin_convertvector(v, h2);  // RNE
+      const h2 ll = __builtin_convertvector(v - __builtin_convertvector(hh, f2), h2);  // the residual is exact in fp32
+      const unsigned hp = __builtin_bit_cast(unsigned, hh), lp = __builtin_bit_cast(unsigned, ll);
       o[2 * p] = __builtin_amdgcn_perm(lp, hp, 0x05040100u);      // h0 | l0 << 16
       o[2 * p + 1] = __builtin_amdgcn_perm(lp, hp, 0x07060302u);  // h1 | l1 << 16
     }
@@ -99,56 +113,12 @@ struct SplitBf16 {
     return o;
   }
   static __device__ __forceinline__ f32x4 mfma(const u32x4& a, const u32x4& b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
   // (h, l) A fragment x expanded B fragment, and expanded A fragment x (h, l) B fragment
   static __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& bh, const u32x4& bl, f32x4 c) { return mfma(a, bl, mfma(a, bh, c)); }
   static __device__ __forceinline__ f32x4 mma_a(const u32x4& ah, const u32x4& al, const u32x4& b, f32x4 c) { return mfma(al, b, mfma(ah, b, c)); }
-};
-
-// Three-way split (option f32_split = 2): x = h + m + l holds all 24 significand bits of an fp32 value in three bf16 parts, and six of
-// the nine part products reach ~2^-24 per product in THREE MFMAs per 16 channels: (xh, xm) x (wh, wh) -> xh wh + xm wh;
-// (xh, xm) x (wm, wm) -> xh wm + xm wm; (xh, xl) x (wl, wh) -> xh wl + xl wh (dropped: xm wl, xl wm, xl wl <= 2^-24 of the product).
-// 48 matrix cycles per 16 channels against 128 for the four v_mfma_f32_16x16x4_f32, at the accuracy of the fp32 kernel.
-struct Split3 {
-  typedef __attribute__((ext_vector_type(2))) float f2;
-  typedef __attribute__((ext_vector_type(2))) __bf16 b2;
-  static __device__ __forceinline__ unsigned cvt2(f2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2)); }
-  static __device__ __forceinline__ f2 up2(unsigned p) { return f2{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xFFFF0000u)}; }
-  // 4 fp32 -> words (h | m << 16) and (h | l << 16) of the same four channels
-  static __device__ __forceinline__ void act(const u32x4& raw, u32x4& hm, u32x4& hl) {
-    const f32x4 x = __builtin_bit_cast(f32x4, raw);
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const f2 v = {x[2 * p], x[2 * p + 1]};
-      const unsigned hp = cvt2(v);
-      const f2 r1 = v - up2(hp);
-      const unsigned mp = cvt2(r1);
-      const unsigned lp = cvt2(r1 - up2(mp));
-      hm[2 * p] = __builtin_amdgcn_perm(mp, hp, 0x05040100u); hm[2 * p + 1] = __builtin_amdgcn_perm(mp, hp, 0x07060302u);
-      hl[2 * p] = __builtin_amdgcn_perm(lp, hp, 0x05040100u); hl[2 * p + 1] = __builtin_amdgcn_perm(lp, hp, 0x07060302u);
-    }
-  }
-  // weights: 4 fp32 -> words (h | m << 16) and the four l parts as two words (l0 | l1 << 16), (l2 | l3 << 16)
-  static __device__ __forceinline__ void wgt(const u32x4& raw, u32x4& hm, unsigned& l01, unsigned& l23) {
-    const f32x4 x = __builtin_bit_cast(f32x4, raw);
-    unsigned lp[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const f2 v = {x[2 * p], x[2 * p + 1]};
-      const unsigned hp = cvt2(v);
-      const f2 r1 = v - up2(hp);
-      const unsigned mp = cvt2(r1);
-      lp[p] = cvt2(r1 - up2(mp));
-      hm[2 * p] = __builtin_amdgcn_perm(mp, hp, 0x05040100u); hm[2 * p + 1] = __builtin_amdgcn_perm(mp, hp, 0x07060302u);
-    }
-    l01 = lp[0]; l23 = lp[1];
-  }
-  // (l | h << 16) words of the B operand from the (h | m) words and the l pairs
-  static __device__ __forceinline__ u32x4 lh(const u32x4& hm, unsigned l01, unsigned l23) {
-    return u32x4{__builtin_amdgcn_perm(hm[0], l01, 0x05040100u), __builtin_amdgcn_perm(hm[1], l01, 0x05040302u),
-                 __builtin_amdgcn_perm(hm[2], l23, 0x05040100u), __builtin_amdgcn_perm(hm[3], l23, 0x05040302u)};
-  }
+  static __device__ __forceinline__ float unscale(float acc, int eo) { return __builtin_ldexpf(acc, eo); }  // eo = -(ea + eb)
 };
 
 // Norm + LeakyReLU backward for one element (reference autograd of blocks.py:98-102): g = dz * lrelu'(scale*y + shift),

@@ -27,7 +27,10 @@ struct ConvArgs {
   int acc_out = 0;
   const void* cr_y = nullptr; const float* cr_scale = nullptr; const float* cr_shift = nullptr;
   const float* cr_xa = nullptr; const float* cr_xb = nullptr; float cr_slope = 0.f;
-  int split = 0;  // fp32 tensors, products on the bf16 matrix cores from two-way split operands (option f32_split; common.h SplitBf16)
+  // fp32 tensors, products on the f16 matrix cores from two-part split operands (option f32_split; common.h SplitF16): max |x| of
+  // each operand tensor as an fp32 bit pattern in device memory (mia_amax); split = all three known and the option on
+  int split = 0;
+  const unsigned* amax_in1 = nullptr; const unsigned* amax_in2 = nullptr; const unsigned* amax_w = nullptr;
 };
 
 __device__ __forceinline__ int pi16(int r) {

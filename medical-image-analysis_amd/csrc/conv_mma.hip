@@ -310,7 +310,8 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
                         int npad, int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2,
                         int o2, float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream,
                         const float* nl_scale, const float* nl_shift, float nl_slope, const void* cr_y = nullptr,
-                        const float* const* cr_coef = nullptr, float cr_slope = 0.f, int acc_out = 0) {
+                        const float* const* cr_coef = nullptr, float cr_slope = 0.f, int acc_out = 0, const void* amax_in1 = nullptr,
+                        const void* amax_in2 = nullptr, const void* amax_w = nullptr) {
   MIA_CHECK_ARG(mode >= 0 && mode <= MODE_G1, "mia_conv_mma: bad mode %d", mode);
   MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_conv_mma: bad dtype %d", dtype);
   MIA_CHECK_ARG(in1 && wpack && out1 && c1 > 0 && o1 > 0 && c2 >= 0 && o2 >= 0, "mia_conv_mma: null/empty operand");
@@ -337,7 +338,10 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
   a.npad = npad; a.kpad = kpad; a.flip = flip_taps;
   a.nl_scale = nl_scale; a.nl_shift = nl_shift; a.nl_slope = nl_slope;
   a.acc_out = acc_out;
-  a.split = dtype == MIA_F32 ? opt.f32_split : 0;  // 0 exact fp32 MFMAs, 1 two-way, 2 three-way split bf16 products
+  // fp32: split f16 products when the caller knows every operand's maximum (otherwise, or with the option off, exact fp32 MFMAs)
+  a.split = (dtype == MIA_F32 && opt.f32_split && amax_in1 != nullptr && amax_w != nullptr && (c2 == 0 || amax_in2 != nullptr)) ? 1 : 0;
+  a.amax_in1 = static_cast<const unsigned*>(amax_in1); a.amax_in2 = static_cast<const unsigned*>(amax_in2);
+  a.amax_w = static_cast<const unsigned*>(amax_w);
   if (cr_y != nullptr) {
     a.cr_y = cr_y; a.cr_scale = cr_coef[0]; a.cr_shift = cr_coef[1]; a.cr_xa = cr_coef[2]; a.cr_xb = cr_coef[3]; a.cr_slope = cr_slope;
   }
@@ -394,14 +398,6 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
     }
     rc = conv64_launch(a, opt.conv64_blocks, opt.reserve_cus, st);
   }
-  else if (nl_scale != nullptr && dtype == MIA_F32) {  // fp32: every stride-1 3x3 launch is the register-staged tile kernel
-    if (!(fast && mode == MODE_G3S1 && c2 == 0 && a.o2 == 0 && !flip_taps && (reinterpret_cast<uintptr_t>(nl_scale) & 15) == 0 &&
-          (reinterpret_cast<uintptr_t>(nl_shift) & 15) == 0)) {
-      mia_set_error("mia_conv_mma_nl: shape outside the fp32 normalise-on-load contract (ask mia_conv_nl_supported first)");
-      return MIA_EUNSUPPORTED;
-    }
-    rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
-  }
   else if (nl_scale != nullptr && opt.conv64_wino && mt == 4 && conv64_wino_eligible(mode, dtype, a)) rc = conv64_wino_launch(a, opt.reserve_cus, st);
   else if (nl_scale != nullptr) {  // normalise-on-load: the register-staged 64-channel kernel is the one consumer that transforms
     if (!(mt == 4 && conv64_eligible(mode, dtype, a))) {
@@ -429,17 +425,16 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
 
 extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const void* in2, int c2, const void* wpack,
                             int npad, int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2,
-                            int o2, float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream) {
+                            int o2, float* stat_partials, int n, int hin, int win, int hout, int wout, const void* amax_in1,
+                            const void* amax_in2, const void* amax_w, void* stream) {
   return conv_mma_run(mode, dtype, in1, c1, in2, c2, wpack, npad, kpad, flip_taps, bias, out1, o1, out2, o2, stat_partials, n, hin,
-                      win, hout, wout, stream, nullptr, nullptr, 0.f);
+                      win, hout, wout, stream, nullptr, nullptr, 0.f, nullptr, nullptr, 0.f, 0, amax_in1, amax_in2, amax_w);
 }
 
 // Normalise-on-load forward conv (the fused PlainBlock, SURVEY 8b export list "conv3x3_nhwc ... optional fused normalise +
 // LeakyReLU on load taking per-(n,c) scale / shift"): see include/mia_hip.h.
 extern "C" int mia_conv_nl_supported(int mode, int dtype, int c1, int nout, int hout, int wout) {
   if (mode != MODE_G3S1) return 0;
-  if (dtype == MIA_F32)  // the branch-free tile kernel's contract (conv_mma_fast_eligible) for one source, one destination
-    return (c1 % 16 == 0 && nout % 4 == 0 && (size_t)hout * wout * (c1 > nout ? c1 : nout) * 4 < ((size_t)1 << 31)) ? 1 : 0;
   return (dtype == MIA_BF16 && c1 == 64 && nout == 64 && hout > 8) ? 1 : 0;
 }
 
@@ -482,8 +477,9 @@ extern "C" int mia_conv_acc_supported(int mode, int dtype, int c1, int nout) {
 }
 
 extern "C" int mia_conv_mma_acc(int mode, int dtype, const void* in1, int c1, const void* wpack, int npad, int kpad, int flip_taps,
-                                void* out_inout, int nout, int n, int hin, int win, int hout, int wout, void* stream) {
+                                void* out_inout, int nout, int n, int hin, int win, int hout, int wout, const void* amax_in,
+                                const void* amax_w, void* stream) {
   MIA_CHECK_ARG(mode == MODE_T3S2 || mode == MODE_G3S1, "mia_conv_mma_acc: mode %d not served", mode);
   return conv_mma_run(mode, dtype, in1, c1, nullptr, 0, wpack, npad, kpad, flip_taps, nullptr, out_inout, nout, nullptr, 0, nullptr, n, hin,
-                      win, hout, wout, stream, nullptr, nullptr, 0.f, nullptr, nullptr, 0.f, 1);
+                      win, hout, wout, stream, nullptr, nullptr, 0.f, nullptr, nullptr, 0.f, 1, amax_in, nullptr, amax_w);
 }

@@ -22,19 +22,12 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 // WC = 2 (stride-2 3x3 forward, bf16): 512 threads, the eight waves are 4 row groups x 2 halves of a 128-channel block on a
 // 16-row tile -- each wave owns 4 x 4 accumulators (8 fragment reads per 16 MFMAs instead of 6 per 8: the 256-thread
 // 8-row shape saturates the LDS pipe), one workgroup per CU.  The statistics stay in the host's 8-row tile layout.
-// SPLIT (T = float only): fp32 tensors, products on the bf16 matrix cores from split operands (common.h).  1 = two-way (SplitBf16):
-// commit() turns every staged fp32 unit into (hi | lo) words, an MFMA step is two 16x16x32 bf16 instructions (operands to 2^-17).
-// 2 = three-way (Split3): the A tile is staged twice ((h | m) and (h | l) words), the weights as (h | m) words plus 8 bytes of l
-// parts, an MFMA step is three instructions covering six part products (~2^-24 per product: the accuracy of the fp32 kernel).
-// NL (T = float, stride-1 3x3, one source): normalise-on-load -- in1 is the RAW conv output of the producing PlainBlock and commit()
-// forms lrelu(nl_scale[n][c] * y + nl_shift[n][c]) (zero outside the image) with the arithmetic of norm_act_fwd_stream_kernel<float>,
-// so that block's normalise + LeakyReLU pass never runs (the fp32 twin of conv64_persist_kernel<NL>; every level, because in fp32 every
-// level's conv is this register-staged kernel).  The eight coefficients of a thread's unit travel with the chunk's prefetch.
-template <typename T, int MODE, int MT, int NT, int WC = 1, int SPLIT = 0, bool NL = false>
+// SPLIT (T = float only): fp32 tensors, products on the f16 matrix cores from two-part split operands (common.h SplitF16): commit()
+// turns every staged fp32 unit, scaled by its tensor's power of two (a.amax_in1 / amax_in2 / amax_w: device pointers to max |x| as fp32
+// bit patterns), into (h | l) words, an MFMA step is two 16x16x32 f16 instructions, the epilogue scales the accumulators back.
+template <typename T, int MODE, int MT, int NT, int WC = 1, bool SPLIT = false>
 __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_mma_fast_kernel(const ConvArgs a) {
-  static_assert(!NL || (sizeof(T) == 4 && MODE == MODE_G3S1 && WC == 1), "normalise-on-load: fp32, stride-1 3x3");
-  static_assert(SPLIT == 0 || sizeof(T) == 4, "split mode is a mode of the fp32 kernel");
-  static_assert(SPLIT != 2 || WC == 1, "three-way split: 256-thread shapes only");
+  static_assert(!SPLIT || sizeof(T) == 4, "split mode is a mode of the fp32 kernel");
   using G = Geo<MODE, MT>;
   constexpr int NTHR = 256 * WC, PL = 64 * WC;  // threads; pixel lanes (x 4 channel groups) of a staging iteration
   constexpr int TH = G::TH, BN = 16 * NT * WC, EPU = Elem<T>::EPU, KB = 4 * EPU, ES = (int)sizeof(T);
@@ -47,15 +40,13 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   constexpr int B_IT = (G::MAXTAPS + TPI - 1) / TPI;
   constexpr int OSTR = BN + EPU;
   constexpr int A_UNITS = 4 * NPA, B_UNITS = B_IT * TPI * 4 * NPB;
-  constexpr int STAGE_BYTES = SPLIT == 2 ? (2 * A_UNITS + B_UNITS) * 16 + B_UNITS * 8 : (A_UNITS + B_UNITS) * 16;
+  constexpr int STAGE_BYTES = (A_UNITS + B_UNITS) * 16;
   constexpr int OUT_BYTES = TH * 16 * OSTR * ES;
   constexpr int LDS_BYTES = STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES;
   static_assert(PL % BN == 0 && TPI >= 1, "weight staging deals whole taps");
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + 2 * 4 * BN * 4];
   u32x4* ldsA = reinterpret_cast<u32x4*>(smem);
-  u32x4* ldsB = ldsA + (SPLIT == 2 ? 2 : 1) * A_UNITS;  // SPLIT 2: [A (h|m)][A (h|l)][B (h|m)][B l pairs, 8 bytes per unit]
-  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-  u32x2_t* ldsBl = reinterpret_cast<u32x2_t*>(ldsB + B_UNITS);
+  u32x4* ldsB = ldsA + A_UNITS;
   T* ldsO = reinterpret_cast<T*>(smem);
   float* ldsR = reinterpret_cast<float*>(smem + LDS_BYTES);
 
@@ -163,12 +154,16 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   }
 
   u32x4 pa[A_IT], pb[B_IT];
-  f32x4 nsc = {0.f, 0.f, 0.f, 0.f}, nsh = {0.f, 0.f, 0.f, 0.f};  // NL: scale / shift of channels c0 + 4g .. + 3 of this image
+  // split mode: operand scales 2^ea (activations: the larger maximum of the two sources, one reduction dimension), 2^eb (weights)
+  float sc_a = 1.f, sc_b = 1.f;
+  int e_out = 0;
+  if constexpr (SPLIT) {
+    unsigned ma = *a.amax_in1;
+    if (a.c2) { const unsigned m2 = *a.amax_in2; ma = m2 > ma ? m2 : ma; }
+    const int ea = SplitF16::exp_of(ma & 0x7FFFFFFFu), eb = SplitF16::exp_of(*a.amax_w & 0x7FFFFFFFu);
+    sc_a = SplitF16::pow2(ea); sc_b = SplitF16::pow2(eb); e_out = -(ea + eb);
+  }
   auto fetch = [&](int c0) {
-    if constexpr (NL) {
-      nsc = *reinterpret_cast<const f32x4*>(a.nl_scale + (size_t)img * a.c1 + c0 + 4 * g);
-      nsh = *reinterpret_cast<const f32x4*>(a.nl_shift + (size_t)img * a.c1 + c0 + 4 * g);
-    }
     const bool second = c0 >= a.c1;  // uniform: chunks never straddle the two sources
     const rsrc_t rs = second ? rs2 : rs1;
     const unsigned cs_es = (unsigned)((second ? a.c2 : a.c1) * ES);
@@ -187,51 +182,29 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
     }
   };
   auto commit = [&]() {
-    if constexpr (NL) {
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        const f32x4 y = __builtin_bit_cast(f32x4, pa[i]);
-        f32x4 z;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = nsc[e] * y[e] + nsh[e];
-          z[e] = ((a_valid >> i) & 1u) ? (v > 0.f ? v : v * a.nl_slope) : 0.f;  // zero padding is padding of z, not of y
-        }
-        pa[i] = __builtin_bit_cast(u32x4, z);
-      }
-    }
-    if constexpr (SPLIT == 2) {
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        u32x4 hm, hl;
-        Split3::act(pa[i], hm, hl);
-        const int at = g * NPA + (S == 2 ? a_lds[i] : p4 + PL * i);
-        ldsA[at] = hm; ldsA[A_UNITS + at] = hl;
-      }
-#pragma unroll
-      for (int i = 0; i < B_IT; ++i) {
-        u32x4 hm; unsigned l01, l23;
-        Split3::wgt(pb[i], hm, l01, l23);
-        const int at = ((i * TPI + tsub) * 4 + g) * NPB + bn_;
-        ldsB[at] = hm; ldsBl[at] = u32x2_t{l01, l23};
-      }
-      return;
+    for (int i = 0; i < A_IT; ++i) {
+      const int at = g * NPA + (S == 2 ? a_lds[i] : p4 + PL * i);
+      if constexpr (SPLIT) ldsA[at] = SplitF16::unit(pa[i], sc_a);
+      else ldsA[at] = pa[i];
     }
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) ldsA[g * NPA + (S == 2 ? a_lds[i] : p4 + PL * i)] = SPLIT == 1 ? SplitBf16::unit(pa[i]) : pa[i];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) ldsB[((i * TPI + tsub) * 4 + g) * NPB + bn_] = SPLIT == 1 ? SplitBf16::unit(pb[i]) : pb[i];
+    for (int i = 0; i < B_IT; ++i) {
+      const int at = ((i * TPI + tsub) * 4 + g) * NPB + bn_;
+      if constexpr (SPLIT) ldsB[at] = SplitF16::unit(pb[i], sc_b);
+      else ldsB[at] = pb[i];
+    }
   };
   // one step of the matrix loop: acc[m][n] += A(m) x B(n) for the wave's MT x NT accumulators.  Split mode forms the (H, H) /
   // (L, L) forms of a B fragment right before its MT MFMA pairs (8 v_perm per 2 * MT MFMAs; kept out of the double buffer:
   // 32 more live registers would spill the 4 x 4 shape)
   auto mma_step = [&](auto&& a_of, const u32x4* bfr) {
-    if constexpr (SPLIT == 1) {
+    if constexpr (SPLIT) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const u32x4 bh = SplitBf16::dup_hi(bfr[n]), bl = SplitBf16::dup_lo(bfr[n]);
+        const u32x4 bh = SplitF16::dup_hi(bfr[n]), bl = SplitF16::dup_lo(bfr[n]);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][n] = SplitBf16::mma(a_of(m), bh, bl, acc[m][n]);
+        for (int m = 0; m < MT; ++m) acc[m][n] = SplitF16::mma(a_of(m), bh, bl, acc[m][n]);
       }
     } else {
 #pragma unroll
@@ -246,35 +219,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
     commit();
     __syncthreads();
     if (c0 + KB < ctot) fetch(c0 + KB);
-    if constexpr (SPLIT == 2) {
-      // three-way split: plain tap loop (fragments read per tap, no register double buffer: the second workgroup of the CU covers
-      // the LDS latency), three MFMAs per (row, channel tile) and tap
-      for (int ta = 0; ta < nth; ++ta) {
-        for (int tb = 0; tb < ntw; ++tb) {
-          const int tl = ta * ntw + tb;
-          const int toff = tap_off(ta, tb);
-          u32x4 a1[MT], a2[MT];
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const int at = q * NPA + S * (wave * MT + m) * PITCH + toff + pr;
-            a1[m] = ldsA[at]; a2[m] = ldsA[A_UNITS + at];
-          }
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            const int bt = (tl * 4 + q) * NPB + n * 16 + pr;
-            const u32x4 whm = ldsB[bt];
-            const u32x2_t wl = ldsBl[bt];
-            const u32x4 bhh = SplitBf16::dup_hi(whm), bmm = SplitBf16::dup_lo(whm), blh = Split3::lh(whm, wl[0], wl[1]);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-              acc[m][n] = SplitBf16::mfma(a1[m], bhh, acc[m][n]);
-              acc[m][n] = SplitBf16::mfma(a1[m], bmm, acc[m][n]);
-              acc[m][n] = SplitBf16::mfma(a2[m], blh, acc[m][n]);
-            }
-          }
-        }
-      }
-    } else if constexpr (MODE == MODE_T3S2) {  // run-time tap count (depends on the output parity)
+    if constexpr (MODE == MODE_T3S2) {  // run-time tap count (depends on the output parity)
       for (int ta = 0; ta < nth; ++ta) {
         for (int tb = 0; tb < ntw; ++tb) {
           const int tl = ta * ntw + tb;
@@ -362,7 +307,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
     for (int n = 0; n < NT; ++n) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = acc[m][n][r] + bv[n];
+        const float v = (SPLIT ? SplitF16::unscale(acc[m][n][r], e_out) : acc[m][n][r]) + bv[n];
         if (a.stats != nullptr) {
           const float vm = full ? v : v * (rm * cmask[r]);
           s1[n] += vm; s2[n] += vm * v;
@@ -451,42 +396,22 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   if (second_part) store_to(true);
 }
 
-template <typename T, int MODE, int MT, int NT, int WC = 1, int SPLIT = 0, bool NL = false>
+template <typename T, int MODE, int MT, int NT, int WC = 1, bool SPLIT = false>
 static void flaunch(const ConvArgs& a, int grid_y, hipStream_t st) {
   int grid_x = a.N * a.tiles_x * a.tiles_y * a.nblk_n;
   if (a.xcd) {  // groups of (channel blocks x parity classes) per tile, tiles rounded up to a multiple of 8
     grid_x = ((a.N * a.tiles_x * a.tiles_y + 7) / 8) * 8 * a.nblk_n * grid_y;
     grid_y = 1;
   }
-  hipLaunchKernelGGL((conv_mma_fast_kernel<T, MODE, MT, NT, WC, SPLIT, NL>), dim3(grid_x, grid_y), dim3(256 * WC), 0, st, a);
-}
-template <typename T, int MODE, int MT, int SPLIT>
-static void flaunch_nl(const ConvArgs& a, int nt, int grid_y, hipStream_t st) {  // fp32 stride-1 3x3 with normalise-on-load
-  if (nt == 4) flaunch<T, MODE, MT, 4, 1, SPLIT, true>(a, grid_y, st);
-  else if (nt == 2) flaunch<T, MODE, MT, 2, 1, SPLIT, true>(a, grid_y, st);
-  else flaunch<T, MODE, MT, 1, 1, SPLIT, true>(a, grid_y, st);
+  hipLaunchKernelGGL((conv_mma_fast_kernel<T, MODE, MT, NT, WC, SPLIT>), dim3(grid_x, grid_y), dim3(256 * WC), 0, st, a);
 }
 template <typename T, int MODE, int MT>
 static void flaunch_nt(const ConvArgs& a, int nt, int grid_y, hipStream_t st) {
-  if constexpr (sizeof(T) == 4 && MODE == MODE_G3S1) {
-    if (a.nl_scale != nullptr) {
-      if (a.split == 2) flaunch_nl<T, MODE, MT, 2>(a, nt, grid_y, st);
-      else if (a.split) flaunch_nl<T, MODE, MT, 1>(a, nt, grid_y, st);
-      else flaunch_nl<T, MODE, MT, 0>(a, nt, grid_y, st);
-      return;
-    }
-  }
   if constexpr (sizeof(T) == 4) {
-    if (a.split == 2) {  // fp32 tensors, three-way split products (fp32 accuracy)
-      if (nt == 4) flaunch<T, MODE, MT, 4, 1, 2>(a, grid_y, st);
-      else if (nt == 2) flaunch<T, MODE, MT, 2, 1, 2>(a, grid_y, st);
-      else flaunch<T, MODE, MT, 1, 1, 2>(a, grid_y, st);
-      return;
-    }
-    if (a.split) {  // fp32 tensors, two-way split products
-      if (nt == 4) flaunch<T, MODE, MT, 4, 1, 1>(a, grid_y, st);
-      else if (nt == 2) flaunch<T, MODE, MT, 2, 1, 1>(a, grid_y, st);
-      else flaunch<T, MODE, MT, 1, 1, 1>(a, grid_y, st);
+    if (a.split) {  // fp32 tensors, two-part split f16 products
+      if (nt == 4) flaunch<T, MODE, MT, 4, 1, true>(a, grid_y, st);
+      else if (nt == 2) flaunch<T, MODE, MT, 2, 1, true>(a, grid_y, st);
+      else flaunch<T, MODE, MT, 1, 1, true>(a, grid_y, st);
       return;
     }
   }

@@ -35,6 +35,8 @@ struct WgArgs {
   // normalise-on-load (mia_conv_wgrad_nl): x1 is the RAW conv output y of the producing PlainBlock; the kernel stages
   // lrelu(nl_scale[n][k] * y + nl_shift[n][k]) (zero outside the image); nullptr = x1 is an ordinary activation
   const float* nl_scale = nullptr; const float* nl_shift = nullptr; float nl_slope = 0.f;
+  // fp32 split mode (common.h SplitF16): max |x| of x1 / x2 / dy as fp32 bit patterns in device memory
+  const unsigned* amax_x1 = nullptr; const unsigned* amax_x2 = nullptr; const unsigned* amax_dy = nullptr;
 };
 
 template <int MODE> struct WGeo {
@@ -1627,15 +1629,14 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgArgs a) {
 // NARROW (32-channel layers: cdy <= 32 and every source <= 32 channels, e.g. al_train's first level): the 64 x 64 block would
 // multiply 75 % zeros (1.22 ms vs 0.41 ms for the forward conv of the same layer).  The four waves become 2 input-channel tiles x 2
 // halves of the tile's pixel rows with 2 output-channel tiles each; the two pixel halves are summed through LDS at the end.
-// SPLIT (option f32_split): the products run on the bf16 matrix cores from two-way split operands (SplitBf16, common.h).
-// LDS holds one (hi | lo << 16) word per element in the exact kernel's layout; the reduction dimension of an MFMA is 16 pixels
+// SPLIT (option f32_split): the products run on the f16 matrix cores from two-part split operands (SplitF16, common.h), each operand
+// tensor scaled by the power of two its maximum dictates (a block's input channels lie in ONE source, so x1 and x2 keep their own scale).
+// LDS holds one (h | l << 16) word per element in the exact kernel's layout; the reduction dimension of an MFMA is 16 pixels
 // (one tile row) x 2 parts: lane group q takes pixels q, q + 4, q + 8, q + 12 (the exact kernel's conflict-free bank pattern),
-// the dy fragment is expanded to its (H, H) and (L, L) forms once per row and meets every tap's (h, l) x fragment in two MFMAs.
-// NL (stride-1 3x3, one source): x1 is the RAW conv output of the producing PlainBlock; lrelu(nl_scale[n][k] * y + nl_shift[n][k]) is
-// formed when the tile is written to LDS (zero outside the image), with the arithmetic of norm_act_fwd_stream_kernel<float>.
-template <int MODE, bool NARROW = false, bool SPLIT = false, bool NL = false>
+// the dy fragment is expanded to its (H, H) and (L, L) forms once per row and meets every tap's (h, l) x fragment in two MFMAs; the
+// accumulators are scaled back when the slab is written.
+template <int MODE, bool NARROW = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
-  static_assert(!NL || MODE == MODE_W3S1, "normalise-on-load: stride-1 3x3");
   using G = WGeo<MODE>;
   constexpr int KS = G::KS, S = G::S, PAD = G::PAD, TAPS = G::TAPS;
   constexpr int TH = (S == 1) ? 4 : 2;
@@ -1677,8 +1678,12 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
     for (int c = 0; c < NC; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 px[X_IT], pd[D_IT];
-  f32x4 nsc = {0.f, 0.f, 0.f, 0.f}, nsh = {0.f, 0.f, 0.f, 0.f};  // NL: coefficients of channels kloc + 4 ch4 .. + 3 of the fetched tile's image
-  unsigned xvalid = 0;                                            //     and which of the thread's X_IT pixels lie inside the image
+  float sc_x = 1.f, sc_d = 1.f;
+  int e_out = 0;
+  if constexpr (SPLIT) {
+    const int ex = SplitF16::exp_of(*(second ? a.amax_x2 : a.amax_x1) & 0x7FFFFFFFu), ed = SplitF16::exp_of(*a.amax_dy & 0x7FFFFFFFu);
+    sc_x = SplitF16::pow2(ex); sc_d = SplitF16::pow2(ed); e_out = -(ex + ed);
+  }
   const int ntiles = a.N * a.tiles_x * a.tiles_y;
   auto fetch = [&](int tile) {
     int tt = tile;
@@ -1689,19 +1694,12 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
     const wrsrc_t rx = wmake_rsrc(xsrc + (size_t)img * xpix * cs, (unsigned)(xpix * cs * 4));
     const wrsrc_t rd = wmake_rsrc(dy + (size_t)img * ypix * a.cdy, (unsigned)(ypix * a.cdy * 4));
-    if constexpr (NL) {
-      const bool cok = kloc + ch4 * 4 < cs;
-      nsc = cok ? *reinterpret_cast<const f32x4*>(a.nl_scale + (size_t)img * cs + kloc + ch4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      nsh = cok ? *reinterpret_cast<const f32x4*>(a.nl_shift + (size_t)img * cs + kloc + ch4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      xvalid = 0;
-    }
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
       const int gy = iy0 + x_iy[i], gx = ix0 + x_ix[i];
       const bool ok = gy >= 0 && gy < a.Hx && gx >= 0 && gx < a.Wx;
       const unsigned voff = (ok && kloc + ch4 * 4 < cs) ? (unsigned)(((gy * a.Wx + gx) * cs + kloc + ch4 * 4) * 4) : WSENT;
       px[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, 0, 0);
-      if constexpr (NL) xvalid |= (ok ? 1u : 0u) << i;
     }
 #pragma unroll
     for (int i = 0; i < D_IT; ++i) {
@@ -1717,23 +1715,10 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
   if (tile < ntiles) fetch(tile);
   for (; tile < ntiles; tile += a.ksplit) {
     __syncthreads();
-    if constexpr (NL) {
 #pragma unroll
-      for (int i = 0; i < X_IT; ++i) {
-        const f32x4 y = __builtin_bit_cast(f32x4, px[i]);
-        f32x4 z;
+    for (int i = 0; i < X_IT; ++i) *reinterpret_cast<u32x4*>(xs + (p16 + 16 * i) * PS + ch4 * 4) = SPLIT ? SplitF16::unit(px[i], sc_x) : px[i];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = nsc[e] * y[e] + nsh[e];
-          z[e] = ((xvalid >> i) & 1u) ? (v > 0.f ? v : v * a.nl_slope) : 0.f;
-        }
-        px[i] = __builtin_bit_cast(u32x4, z);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < X_IT; ++i) *reinterpret_cast<u32x4*>(xs + (p16 + 16 * i) * PS + ch4 * 4) = SPLIT ? SplitBf16::unit(px[i]) : px[i];
-#pragma unroll
-    for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(ds + (p16 + 16 * i) * PS + ch4 * 4) = SPLIT ? SplitBf16::unit(pd[i]) : pd[i];
+    for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(ds + (p16 + 16 * i) * PS + ch4 * 4) = SPLIT ? SplitF16::unit(pd[i], sc_d) : pd[i];
     __syncthreads();
     if (tile + a.ksplit < ntiles) fetch(tile + a.ksplit);
     constexpr int YR = NARROW ? TH / 2 : TH;
@@ -1749,7 +1734,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
           u32x4 w;
 #pragma unroll
           for (int j = 0; j < 4; ++j) w[j] = dw[(y * 16 + 4 * j + q) * PS + c * 16 + i16];
-          ah[c] = SplitBf16::dup_hi(w); al[c] = SplitBf16::dup_lo(w);
+          ah[c] = SplitF16::dup_hi(w); al[c] = SplitF16::dup_lo(w);
         }
 #pragma unroll
         for (int kh = 0; kh < KS; ++kh)
@@ -1759,7 +1744,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = xw[((y * S + kh) * XW + (4 * j + q) * S + kw) * PS + kq * 16 + i16];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) acc[kh * KS + kw][c] = SplitBf16::mma_a(ah[c], al[c], b, acc[kh * KS + kw][c]);
+            for (int c = 0; c < NC; ++c) acc[kh * KS + kw][c] = SplitF16::mma_a(ah[c], al[c], b, acc[kh * KS + kw][c]);
           }
       }
       continue;
@@ -1814,7 +1799,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + c * 16 + 4 * q + r, k = k0 + kq * 16 + i16;
-        if (kloc + kq * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+        if (kloc + kq * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = SPLIT ? SplitF16::unscale(acc[t][c][r], e_out) : acc[t][c][r];
       }
 }
 
@@ -1969,7 +1954,8 @@ extern "C" int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tile
 
 static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const void* x2, int c2, const void* dy,
                           int cdy, float* slabs, int ksplit, int npad, int kpad, int n, int hx, int wx, int hy,
-                          int wy, void* stream, const float* nl_scale, const float* nl_shift, float nl_slope) {
+                          int wy, void* stream, const float* nl_scale, const float* nl_shift, float nl_slope,
+                          const void* amax_x1 = nullptr, const void* amax_x2 = nullptr, const void* amax_dy = nullptr) {
   MIA_CHECK_ARG(mode >= 0 && mode <= MODE_W2S2, "mia_conv_wgrad: bad mode %d", mode);
   MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_conv_wgrad: bad dtype");
   MIA_CHECK_ARG(x1 && dy && slabs && c1 > 0 && c2 >= 0 && cdy > 0, "mia_conv_wgrad: null/empty operand");
@@ -1984,6 +1970,10 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
   a.x1 = x1; a.x2 = x2; a.c1 = c1; a.c2 = c2; a.dy = dy; a.cdy = cdy; a.slabs = slabs;
   a.N = n; a.Hx = hx; a.Wx = wx; a.Hy = hy; a.Wy = wy; a.npad = npad; a.kpad = kpad; a.ksplit = ksplit;
   a.nl_scale = nl_scale; a.nl_shift = nl_shift; a.nl_slope = nl_slope;
+  a.amax_x1 = static_cast<const unsigned*>(amax_x1); a.amax_x2 = static_cast<const unsigned*>(amax_x2);
+  a.amax_dy = static_cast<const unsigned*>(amax_dy);
+  // fp32: split f16 products when the caller knows every operand's maximum (otherwise, or with the option off, exact fp32 MFMAs)
+  const bool split = dtype == MIA_F32 && o.f32_split && amax_x1 != nullptr && amax_dy != nullptr && (c2 == 0 || amax_x2 != nullptr);
   const int epu = dtype == MIA_BF16 ? 8 : 4;
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vec_x = (c1 % epu == 0) && (c2 % epu == 0) && al16(x1) && (x2 == nullptr || al16(x2));
@@ -2000,25 +1990,6 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
   if (fast && o.wgrad_xcd && ksplit % 8 == 0) {  // bf16 fast kernels: 1-D grid in XCD-aware order (a split count below 8 would leave XCDs idle)
     a.opt |= 16;
     fgrid = dim3(fgrid.x * (unsigned)(ceil_div(ksplit, 8) * 8), 1);
-  }
-  if (nl_scale != nullptr && dtype == MIA_F32) {  // fp32 normalise-on-load: the register-staged fp32 kernel, exact or split products
-    const bool f32fast = chan_ok && (size_t)hx * wx * c1 * 4 < lim && (size_t)hy * wy * cdy * 4 < lim;
-    if (!(f32fast && mode == MODE_W3S1 && c2 == 0 && (reinterpret_cast<uintptr_t>(nl_scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(nl_shift) & 15) == 0)) {
-      mia_set_error("mia_conv_wgrad_nl: shape outside the fp32 normalise-on-load contract (ask mia_wgrad_nl_supported first)");
-      return MIA_EUNSUPPORTED;
-    }
-    a.tiles_y = ceil_div(hy, 4);
-    a.tiles_x = ceil_div(wy, 16);
-    const bool narrow = cdy <= 32 && c1 <= 32;
-    if (o.f32_split == 1) {
-      if (narrow) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, true, true, true>), fgrid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, false, true, true>), fgrid, dim3(256), 0, st, a);
-    } else {
-      if (narrow) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, true, false, true>), fgrid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, false, false, true>), fgrid, dim3(256), 0, st, a);
-    }
-    MIA_LAUNCH_CHECK();
-    return MIA_OK;
   }
   if (nl_scale != nullptr) {  // normalise-on-load: the register-staged two-workgroup kernel is the one that transforms
     if (!(fast && mode == MODE_W3S1 && c2 == 0)) {
@@ -2061,7 +2032,7 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
   } else if (dtype == MIA_F32 && chan_ok && (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 4 < lim &&
              (size_t)hy * wy * cdy * 4 < lim) {
     const bool narrow = cdy <= 32 && c1 <= 32 && c2 <= 32;  // 32-channel layers: half-width blocks, all four waves busy
-    if (o.f32_split == 1) {  // fp32 tensors, two-way split-bf16 products (the three-way experiment exists in the conv kernel only)
+    if (split) {  // fp32 tensors, two-part split f16 products
       if (narrow) {
         if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, true, true>), fgrid, dim3(256), 0, st, a);
         else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S2, true, true>), fgrid, dim3(256), 0, st, a);
@@ -2091,14 +2062,14 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
 
 extern "C" int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const void* x2, int c2, const void* dy,
                               int cdy, float* slabs, int ksplit, int npad, int kpad, int n, int hx, int wx, int hy,
-                              int wy, void* stream) {
-  return conv_wgrad_run(mode, dtype, x1, c1, x2, c2, dy, cdy, slabs, ksplit, npad, kpad, n, hx, wx, hy, wy, stream, nullptr, nullptr, 0.f);
+                              int wy, const void* amax_x1, const void* amax_x2, const void* amax_dy, void* stream) {
+  return conv_wgrad_run(mode, dtype, x1, c1, x2, c2, dy, cdy, slabs, ksplit, npad, kpad, n, hx, wx, hy, wy, stream, nullptr, nullptr, 0.f,
+                        amax_x1, amax_x2, amax_dy);
 }
 
 // Weight gradient with normalise-on-load of x (the backward half of the fused PlainBlock): see include/mia_hip.h.
 extern "C" int mia_wgrad_nl_supported(int mode, int dtype, int c1, int cdy) {
   if (mode != MODE_W3S1) return 0;
-  if (dtype == MIA_F32) return (c1 % 4 == 0 && cdy % 4 == 0) ? 1 : 0;
   return (dtype == MIA_BF16 && c1 % 8 == 0 && cdy % 8 == 0) ? 1 : 0;
 }
 

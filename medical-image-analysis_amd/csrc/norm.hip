@@ -374,22 +374,41 @@ extern "C" int mia_norm_stats(const void* y, int dtype, int n, int64_t hw, int c
   return MIA_OK;
 }
 
+// Running max |x| of the values a streaming kernel WRITES (fp32 tensors; the scale source of the split-f16 convs that consume them,
+// common.h SplitF16): a lane folds the fp32 bit patterns of its outputs, a wave folds its lanes, one atomic unsigned maximum per wave
+// and only when the slot does not hold at least that much already.  Every lane of the wave must arrive here (no early return).
+// The caller hands in a ZEROED slot (or a running maximum to fold into): the kernels never reset it.
+extern "C" int mia_amax(const float* x, int64_t n, void* slot, int reset, void* stream);
+template <typename T> __device__ __forceinline__ void amax_fold(unsigned& m, const T* out) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int e = 0; e < Elem<T>::EPU; ++e) { const unsigned b = __builtin_bit_cast(unsigned, out[e]) & 0x7FFFFFFFu; m = b > m ? b : m; }
+  }
+}
+__device__ __forceinline__ void amax_publish(unsigned m, unsigned* __restrict__ slot) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m);
+}
 // ---------------------------------------------------------------- streaming apply kernels (C % EPU == 0)
 // grid = (n * slabs, ceil(UPP / UPB)); a thread owns ONE 16-byte channel unit of image n, keeps that unit's
 // per-(n,c) coefficients in registers and streams its slab's pixels: no per-element coefficient loads or divisions.
 template <typename T>
 __global__ __launch_bounds__(256) void norm_act_fwd_stream_kernel(const T* __restrict__ y, T* __restrict__ z,
                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                  int64_t hw, int c, int slabs, int upb, float slope) {
+                                                                  int64_t hw, int c, int slabs, int upb, float slope,
+                                                                  unsigned* __restrict__ amax) {
   constexpr int EPU = Elem<T>::EPU;
   const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
   const int lanes = 256 / upb;
   const int u = blockIdx.y * upb + threadIdx.x % upb, pl = threadIdx.x / upb;
-  if (u * EPU >= c) return;
-  const int64_t per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  const bool live = u * EPU < c;  // (lanes beyond the channel count idle through the loops: the maximum needs the whole wave at the end)
+  if (!live && (sizeof(T) != 4 || amax == nullptr)) return;
+  const int64_t per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = live ? (r0 + per < hw ? r0 + per : hw) : r0;
   float sc[EPU], sf[EPU];
+  unsigned am = 0;
 #pragma unroll
-  for (int e = 0; e < EPU; ++e) { sc[e] = scale[(size_t)n * c + u * EPU + e]; sf[e] = shift[(size_t)n * c + u * EPU + e]; }
+  for (int e = 0; e < EPU; ++e) { sc[e] = live ? scale[(size_t)n * c + u * EPU + e] : 0.f; sf[e] = live ? shift[(size_t)n * c + u * EPU + e] : 0.f; }
   const size_t base = (size_t)n * hw * c + (size_t)u * EPU;
   auto body = [&](const u32x4& raw, int64_t r) {
     alignas(16) T in[EPU]; alignas(16) T out[EPU];
@@ -399,6 +418,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_stream_kernel(const T* __res
       const float v = sc[e] * Elem<T>::ld(in + e) + sf[e];
       out[e] = Elem<T>::cvt(v > 0.f ? v : v * slope);
     }
+    amax_fold<T>(am, out);
     *reinterpret_cast<u32x4*>(z + base + r * c) = *reinterpret_cast<const u32x4*>(out);
   };
   // (non-temporal loads / stores for the > 256 MB tensors were measured: 0.403 -> 0.396 ms on the 2.1 GB launch, within noise)
@@ -409,6 +429,7 @@ __global__ __launch_bounds__(256) void norm_act_fwd_stream_kernel(const T* __res
     body(a0, r); body(a1, r + lanes); body(a2, r + 2 * lanes); body(a3, r + 3 * lanes);
   }
   for (; r < r1; r += lanes) body(ld(r), r);
+  if constexpr (sizeof(T) == 4) { if (amax != nullptr) amax_publish(am, amax); }
 }
 
 // dy = scale*(g - c1 - xhat*c2) = scale*g + ka*y + kb  with ka = -scale*c2*xa, kb = -scale*(c1 + c2*xb)
@@ -418,17 +439,20 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stream_kernel(const T* __res
                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                                   const float* __restrict__ xa, const float* __restrict__ xb,
                                                                   const float* __restrict__ c1, const float* __restrict__ c2,
-                                                                  int64_t hw, int c, int slabs, int upb, float slope) {
+                                                                  int64_t hw, int c, int slabs, int upb, float slope,
+                                                                  unsigned* __restrict__ amax) {
   constexpr int EPU = Elem<T>::EPU;
   const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
   const int lanes = 256 / upb;
   const int u = blockIdx.y * upb + threadIdx.x % upb, pl = threadIdx.x / upb;
-  if (u * EPU >= c) return;
-  const int64_t per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  const bool live = u * EPU < c;
+  if (!live && (sizeof(T) != 4 || amax == nullptr)) return;
+  const int64_t per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = live ? (r0 + per < hw ? r0 + per : hw) : r0;
   float sc[EPU], sf[EPU], ka[EPU], kb[EPU];
+  unsigned am = 0;
 #pragma unroll
   for (int e = 0; e < EPU; ++e) {
-    const size_t o = (size_t)n * c + u * EPU + e;
+    const size_t o = live ? (size_t)n * c + u * EPU + e : 0;
     sc[e] = scale[o]; sf[e] = shift[o];
     ka[e] = -sc[e] * c2[o] * xa[o];
     kb[e] = -sc[e] * (c1[o] + c2[o] * xb[o]);
@@ -446,6 +470,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stream_kernel(const T* __res
       if (TWO) g += Elem<T>::ld(g2in + e);
       out[e] = Elem<T>::cvt(norm_bwd_dy(g, yv, sc[e], sf[e], ka[e], kb[e], slope));
     }
+    amax_fold<T>(am, out);
     *reinterpret_cast<u32x4*>(dy + base + r * c) = *reinterpret_cast<const u32x4*>(out);
   };
   const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
@@ -457,6 +482,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stream_kernel(const T* __res
     body(g0, h0, y0, r); body(g1, h1, y1, r + lanes);
   }
   for (; r < r1; r += lanes) body(ld(dz, r), TWO ? ld(dz2, r) : zero, ld(y, r), r);
+  if constexpr (sizeof(T) == 4) { if (amax != nullptr) amax_publish(am, amax); }
 }
 
 static void stream_geometry(int n, int64_t hw, int c, int epu, int* slabs, int* upb, int* gy) {
@@ -506,8 +532,9 @@ __global__ void norm_act_fwd_kernel(const T* __restrict__ y, T* __restrict__ z, 
 }
 
 extern "C" int mia_norm_act_fwd(const void* y, void* z, int dtype, const float* scale, const float* shift, int n, int64_t hw,
-                                int c, float slope, void* stream) {
+                                int c, float slope, void* amax_out, void* stream) {
   MIA_CHECK_ARG(y && z && scale && shift && n > 0 && hw > 0 && c > 0, "mia_norm_act_fwd: bad arguments");
+  if (dtype != MIA_F32) amax_out = nullptr;  // the maximum serves fp32 consumers only
   const int epu = dtype == MIA_BF16 ? 8 : 4;
   const bool vec = (c % epu == 0) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(z)) & 15) == 0;
   const int64_t units = (int64_t)n * hw * (vec ? c / epu : c);
@@ -517,9 +544,9 @@ extern "C" int mia_norm_act_fwd(const void* y, void* z, int dtype, const float* 
     int sl, upb, gy;
     stream_geometry(n, hw, c, epu, &sl, &upb, &gy);
     if (dtype == MIA_BF16)
-      hipLaunchKernelGGL(norm_act_fwd_stream_kernel<bf16_t>, dim3(n * sl, gy), dim3(256), 0, st, static_cast<const bf16_t*>(y), static_cast<bf16_t*>(z), scale, shift, hw, c, sl, upb, slope);
+      hipLaunchKernelGGL(norm_act_fwd_stream_kernel<bf16_t>, dim3(n * sl, gy), dim3(256), 0, st, static_cast<const bf16_t*>(y), static_cast<bf16_t*>(z), scale, shift, hw, c, sl, upb, slope, (unsigned*)nullptr);
     else
-      hipLaunchKernelGGL(norm_act_fwd_stream_kernel<float>, dim3(n * sl, gy), dim3(256), 0, st, static_cast<const float*>(y), static_cast<float*>(z), scale, shift, hw, c, sl, upb, slope);
+      hipLaunchKernelGGL(norm_act_fwd_stream_kernel<float>, dim3(n * sl, gy), dim3(256), 0, st, static_cast<const float*>(y), static_cast<float*>(z), scale, shift, hw, c, sl, upb, slope, static_cast<unsigned*>(amax_out));
     MIA_LAUNCH_CHECK();
     return MIA_OK;
   }
@@ -530,6 +557,7 @@ extern "C" int mia_norm_act_fwd(const void* y, void* z, int dtype, const float* 
   else { mia_set_error("mia_norm_act_fwd: bad dtype"); return MIA_EARG; }
 #undef NA
   MIA_LAUNCH_CHECK();
+  if (amax_out) return mia_amax(static_cast<const float*>(z), (int64_t)n * hw * c, amax_out, 0, stream);  // scalar fallback shapes: a separate pass
   return MIA_OK;
 }
 
@@ -713,7 +741,9 @@ static void bwd_reduce_launch(const void* dz, const void* dz2, const void* y, in
 // pass 2: dy from the finalized group means
 static void bwd_apply_launch(const void* dz, const void* dz2, const void* y, void* dy, int dtype, const float* scale, const float* shift,
                              const float* xa, const float* xb, const float* c1, const float* c2, int n, int64_t hw, int c,
-                             float slope, hipStream_t st) {
+                             float slope, hipStream_t st, void* amax_out = nullptr) {
+  // amax_out (fp32 only): max |dy| for the split-f16 convs that consume dy -- folded into the streaming kernel, a separate pass otherwise
+  if (dtype != MIA_F32) amax_out = nullptr;
   const int epu = dtype == MIA_BF16 ? 8 : 4;
   const bool vec = bwd_vec_ok(dz, y, dy, dtype, c);
   const int64_t units = (int64_t)n * hw * (vec ? c / epu : c);
@@ -726,12 +756,15 @@ static void bwd_apply_launch(const void* dz, const void* dz2, const void* y, voi
     stream_geometry(n, hw, c, epu, &sl, &upb, &gy);
 #define BS(T, TWOF) hipLaunchKernelGGL((norm_act_bwd_stream_kernel<T, TWOF>), dim3(n * sl, gy), dim3(256), 0, st, static_cast<const T*>(dz), \
                                        static_cast<const T*>(dz2), static_cast<const T*>(y), static_cast<T*>(dy), scale, shift, xa, xb, \
-                                       c1, c2, hw, c, sl, upb, slope)
+                                       c1, c2, hw, c, sl, upb, slope, static_cast<unsigned*>(amax_out))
     if (dtype == MIA_BF16) { if (dz2) BS(bf16_t, true); else BS(bf16_t, false); }
     else { if (dz2) BS(float, true); else BS(float, false); }
 #undef BS
-  } else if (dtype == MIA_BF16) AP(bf16_t, false);
-  else AP(float, false);
+  } else {
+    if (dtype == MIA_BF16) AP(bf16_t, false);
+    else AP(float, false);
+    if (amax_out) (void)mia_amax(static_cast<const float*>(dy), (int64_t)n * hw * c, amax_out, 0, st);
+  }
 #undef AP
 }
 
@@ -746,7 +779,7 @@ static bool two_piece_ok(const void* dz, const void* dz2, const void* y, const v
 extern "C" int mia_norm_act_bwd(const void* dz, const void* dz2, const void* y, void* dy, int dtype, const float* scale, const float* shift,
                                 const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
                                 int fixed_stats, float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma,
-                                float* dbeta, float* dbias, int accumulate, void* stream) {
+                                float* dbeta, float* dbias, int accumulate, void* amax_out, void* stream) {
   MIA_CHECK_ARG(dz && y && dy && scale && shift && xa && xb && partials && c1 && c2 && dgamma && dbeta,
                 "mia_norm_act_bwd: null pointer");
   MIA_CHECK_ARG(n > 0 && hw > 0 && c > 0 && slabs > 0, "mia_norm_act_bwd: bad shape");
@@ -757,7 +790,7 @@ extern "C" int mia_norm_act_bwd(const void* dz, const void* dz2, const void* y, 
   bwd_reduce_launch(dz, dz2, y, dtype, scale, shift, xa, xb, n, hw, c, slope, slabs, partials, c1, c2, st, !inline_sums);
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, mode, fixed_stats, scale, xa,
                      xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate, nullptr, inline_sums ? partials : nullptr, slabs);
-  bwd_apply_launch(dz, dz2, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st);
+  bwd_apply_launch(dz, dz2, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st, amax_out);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -786,7 +819,7 @@ extern "C" int mia_norm_bwd_sums(const void* dz, const void* dz2, const void* y,
 extern "C" int mia_norm_act_bwd_pre(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
                                     const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
                                     int fixed_stats, float slope, int parts, const float* partials, float* c1, float* c2,
-                                    float* dgamma, float* dbeta, float* dbias, int accumulate, void* stream) {
+                                    float* dgamma, float* dbeta, float* dbias, int accumulate, void* amax_out, void* stream) {
   MIA_CHECK_ARG(scale && shift && xa && xb && partials && c1 && c2 && dgamma && dbeta, "mia_norm_act_bwd_pre: null pointer");
   MIA_CHECK_ARG(n > 0 && hw > 0 && c > 0 && parts > 0, "mia_norm_act_bwd_pre: bad shape");
   MIA_CHECK_ARG(dy == nullptr || (dz && y), "mia_norm_act_bwd_pre: the apply pass needs dz and y");
@@ -795,7 +828,7 @@ extern "C" int mia_norm_act_bwd_pre(const void* dz, const void* y, void* dy, int
   hipLaunchKernelGGL(norm_bwd_sum_kernel, dim3(n, ceil_div(c, 16)), dim3(256), 0, st, partials, parts, c, c1, c2);
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, mode, fixed_stats, scale, xa,
                      xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate, nullptr, nullptr, 0);
-  if (dy != nullptr) bwd_apply_launch(dz, nullptr, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st);
+  if (dy != nullptr) bwd_apply_launch(dz, nullptr, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st, amax_out);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -835,7 +868,7 @@ extern "C" int mia_norm_act_bwd_reduce(const void* dz, const void* dz2, const vo
 extern "C" int mia_norm_act_bwd_apply_sync(const void* dz, const void* dz2, const void* y, void* dy, int dtype, const float* scale,
                                            const float* shift, const float* xa, const float* xb, const float* ysum, int n,
                                            int64_t hw, int c, float slope, float* c1, float* c2, const float* group_tot,
-                                           float* dgamma, float* dbeta, float* dbias, int accumulate, void* stream) {
+                                           float* dgamma, float* dbeta, float* dbias, int accumulate, void* amax_out, void* stream) {
   MIA_CHECK_ARG(dz && y && dy && scale && shift && xa && xb && c1 && c2 && group_tot && dgamma && dbeta,
                 "mia_norm_act_bwd_apply_sync: null pointer");
   MIA_CHECK_ARG(n > 0 && hw > 0 && c > 0, "mia_norm_act_bwd_apply_sync: bad shape");
@@ -844,7 +877,7 @@ extern "C" int mia_norm_act_bwd_apply_sync(const void* dz, const void* dz2, cons
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(ceil_div(c, 16)), dim3(256), 0, st, n, c, hw, NORM_BATCH, 0, scale, xa, xb,
                      ysum, c1, c2, dgamma, dbeta, dbias, accumulate, group_tot, nullptr, 0);
   MIA_CHECK_ARG(two_piece_ok(dz, dz2, y, dy, dtype, c), "mia_norm_act_bwd_apply_sync: two-piece gradient needs c %% 32 == 0 and aligned tensors");
-  bwd_apply_launch(dz, dz2, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st);
+  bwd_apply_launch(dz, dz2, y, dy, dtype, scale, shift, xa, xb, c1, c2, n, hw, c, slope, st, amax_out);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -985,22 +1018,24 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stream_head_kernel(const flo
                                                                        const float* __restrict__ xa, const float* __restrict__ xb,
                                                                        const float* __restrict__ c1, const float* __restrict__ c2,
                                                                        int hw, int c, int slabs, int upb, float slope, int64_t gsn,
-                                                                       int64_t gsp, int64_t gsk) {
+                                                                       int64_t gsp, int64_t gsk, unsigned* __restrict__ amax) {
   constexpr int EPU = Elem<T>::EPU;
   const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
   const int lanes = 256 / upb;
   const int u = blockIdx.y * upb + threadIdx.x % upb, pl = threadIdx.x / upb;
-  if (u * EPU >= c) return;
-  const int per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
+  const bool live = u * EPU < c;
+  if (!live && (sizeof(T) != 4 || amax == nullptr)) return;
+  const int per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = live ? (r0 + per < hw ? r0 + per : hw) : r0;
   float sc[EPU], sf[EPU], ka[EPU], kb[EPU], wr[K1][EPU];
+  unsigned am = 0;
 #pragma unroll
   for (int e = 0; e < EPU; ++e) {
-    const size_t o = (size_t)n * c + u * EPU + e;
+    const size_t o = live ? (size_t)n * c + u * EPU + e : 0;
     sc[e] = scale[o]; sf[e] = shift[o];
     ka[e] = -sc[e] * c2[o] * xa[o];
     kb[e] = -sc[e] * (c1[o] + c2[o] * xb[o]);
 #pragma unroll
-    for (int k = 0; k < K1; ++k) wr[k][e] = w[k * c + u * EPU + e];
+    for (int k = 0; k < K1; ++k) wr[k][e] = live ? w[k * c + u * EPU + e] : 0.f;
   }
   const size_t base = (size_t)n * hw * c + (size_t)u * EPU;
   const float* gb = dl + (int64_t)n * gsn;
@@ -1016,6 +1051,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stream_head_kernel(const flo
       if (!(sc[e] * yv + sf[e] > 0.f)) g *= slope;
       out[e] = Elem<T>::cvt(sc[e] * g + ka[e] * yv + kb[e]);
     }
+    amax_fold<T>(am, out);
     *reinterpret_cast<u32x4*>(dy + base + (size_t)r * c) = *reinterpret_cast<const u32x4*>(out);
   };
   int r = r0 + pl;
@@ -1037,6 +1073,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_stream_head_kernel(const flo
     for (int k = 0; k < K1; ++k) gv[k] = gb[(int64_t)r * gsp + k * gsk];
     body(*reinterpret_cast<const u32x4*>(y + base + (size_t)r * c), gv, r);
   }
+  if constexpr (sizeof(T) == 4) { if (amax != nullptr) amax_publish(am, amax); }
 }
 
 // mia_norm_act_bwd with dz = W^T dl recomputed on the fly (w: [k1][c] fp32, dl: fp32 logits gradient with element strides
@@ -1045,7 +1082,8 @@ static int norm_act_bwd_head_run(const float* dlogits, const float* w, int k1, i
                                  const void* y, void* dy, int dtype, const float* scale, const float* shift, const float* xa,
                                  const float* xb, const float* ysum, int n, int64_t hw, int c, int mode, int fixed_stats,
                                  float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta,
-                                 float* dbias, int accumulate, void* stream, float* wpart, float* dwh, float* dbh, int acc_head) {
+                                 float* dbias, int accumulate, void* stream, float* wpart, float* dwh, float* dbh, int acc_head,
+                                 void* amax_out) {
   MIA_CHECK_ARG(dlogits && w && y && dy && scale && shift && xa && xb && partials && c1 && c2 && dgamma && dbeta,
                 "mia_norm_act_bwd_head: null pointer");
   MIA_CHECK_ARG(n > 0 && hw > 0 && hw < ((int64_t)1 << 31) && c > 0 && slabs > 0 && k1 >= 2 && k1 <= 4 && c % 32 == 0,
@@ -1071,9 +1109,10 @@ static int norm_act_bwd_head_run(const float* dlogits, const float* w, int k1, i
                      xb, ysum, c1, c2, dgamma, dbeta, dbias, accumulate, nullptr, inline_sums ? partials : nullptr, slabs);
   int sl, upb, gy;
   stream_geometry(n, hw, c, epu, &sl, &upb, &gy);
+  if (dtype != MIA_F32) amax_out = nullptr;
 #define BSH(T, K) hipLaunchKernelGGL((norm_act_bwd_stream_head_kernel<T, K>), dim3(n * sl, gy), dim3(256), 0, st, dlogits, w, \
                                      static_cast<const T*>(y), static_cast<T*>(dy), scale, shift, xa, xb, c1, c2, (int)hw, c, sl, upb, \
-                                     slope, gsn, gsp, gsk)
+                                     slope, gsn, gsp, gsk, static_cast<unsigned*>(amax_out))
 #define BSHK(T) do { if (k1 == 2) BSH(T, 2); else if (k1 == 3) BSH(T, 3); else BSH(T, 4); } while (0)
   if (dtype == MIA_BF16) BSHK(bf16_t); else BSHK(float);
 #undef BSHK
@@ -1086,9 +1125,9 @@ extern "C" int mia_norm_act_bwd_head(const float* dlogits, const float* w, int k
                                      const void* y, void* dy, int dtype, const float* scale, const float* shift, const float* xa,
                                      const float* xb, const float* ysum, int n, int64_t hw, int c, int mode, int fixed_stats,
                                      float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta,
-                                     float* dbias, int accumulate, void* stream) {
+                                     float* dbias, int accumulate, void* amax_out, void* stream) {
   return norm_act_bwd_head_run(dlogits, w, k1, gsn, gsk, gsp, y, dy, dtype, scale, shift, xa, xb, ysum, n, hw, c, mode, fixed_stats, slope,
-                               slabs, partials, c1, c2, dgamma, dbeta, dbias, accumulate, stream, nullptr, nullptr, nullptr, 0);
+                               slabs, partials, c1, c2, dgamma, dbeta, dbias, accumulate, stream, nullptr, nullptr, nullptr, 0, amax_out);
 }
 
 // mia_norm_act_bwd_head + mia_head_norm_wgrad in one reduction pass: the head's dW / db are accumulated by the kernel that computes the
@@ -1101,10 +1140,10 @@ extern "C" int mia_norm_act_bwd_head_w(const float* dlogits, const float* w, int
                                        const float* xb, const float* ysum, int n, int64_t hw, int c, int mode, int fixed_stats,
                                        float slope, int slabs, float* partials, float* c1, float* c2, float* dgamma, float* dbeta,
                                        float* dbias, int accumulate, float* head_workspace, float* dw_head, float* db_head,
-                                       int accumulate_head, void* stream) {
+                                       int accumulate_head, void* amax_out, void* stream) {
   MIA_CHECK_ARG(head_workspace && dw_head && db_head, "mia_norm_act_bwd_head_w: null head-gradient pointer");
   MIA_CHECK_ARG(mia_head_w_supported(dtype, c, k1), "mia_norm_act_bwd_head_w: unsupported shape (c=%d k1=%d)", c, k1);
   return norm_act_bwd_head_run(dlogits, w, k1, gsn, gsk, gsp, y, dy, dtype, scale, shift, xa, xb, ysum, n, hw, c, mode, fixed_stats, slope,
                                slabs, partials, c1, c2, dgamma, dbeta, dbias, accumulate, stream, head_workspace, dw_head, db_head,
-                               accumulate_head);
+                               accumulate_head, amax_out);
 }

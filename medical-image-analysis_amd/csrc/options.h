@@ -34,7 +34,7 @@ struct MiaOptions {
   int stem_mfma;      // matrix-core stem kernel for fp32 images                               env MIA_STEM_MFMA     default 1
   int conv_t3_wide;   // stride-2 3x3 INPUT GRADIENT (transposed mode), bf16, 128-multiples of output channels, on the 512-thread 128-channel-block shape of conv_s2_wide   env MIA_CONV_T3_WIDE  default 0
   int wgrad_narrow;   // LDS-DMA weight gradient: launches with channel counts that are not multiples of 64 skip their empty 16-channel tiles (cfg5's 96-channel level; measured: no gain, those launches are not MFMA-bound)   env MIA_WGRAD_NARROW  default 0
-  int f32_split;      // fp32 convs / weight gradients of the tile kernels on the bf16 matrix cores from two-way split operands (1: x = hi + lo, 4 products, fp32 accumulate: operands to 2^-17 instead of 2^-24; common.h SplitBf16.  2: EXPERIMENT, conv kernel only -- three parts, six products in three MFMAs: the fp32 kernel's accuracy, 1.25x on the conv launches at one workgroup per CU; weight gradients stay exact)   env MIA_F32_SPLIT     default 0
+  int f32_split;      // fp32 convs / weight gradients of the branch-free tile kernels on the f16 matrix cores from two-part split operands scaled per tensor (common.h SplitF16: x * 2^e = h + l in fp16, 22-23 significand bits, fp32 accumulate) whenever the caller passes the operands' maxima; 0 = always the exact fp32 MFMA kernels   env MIA_F32_SPLIT   default 1
   int reserve_cus;    // CUs the persistent kernels leave free (grids of conv_bt / conv_pw / conv64 / conv64_dma, split-K target of the weight gradients): room for RCCL's ring kernels under data parallelism   env MIA_RESERVE_CUS   default 0
 };
 

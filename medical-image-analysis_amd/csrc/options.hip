@@ -31,7 +31,7 @@ Entry g_table[] = {
     {"reserve_cus", "MIA_RESERVE_CUS", 0, 0, 64, {0}},
     {"conv_t3_wide", "MIA_CONV_T3_WIDE", 0, 0, 1, {0}},
     {"wgrad_narrow", "MIA_WGRAD_NARROW", 0, 0, 1, {0}},
-    {"f32_split", "MIA_F32_SPLIT", 0, 0, 2, {0}},
+    {"f32_split", "MIA_F32_SPLIT", 1, 0, 1, {1}},
     {"conv_pw_t3", "MIA_CONV_PW_T3", 0, 0, 1, {0}},
     {"conv64_wino", "MIA_CONV64_WINO", 0, 0, 1, {0}},
 };

@@ -417,3 +417,76 @@ extern "C" int mia_gather_f32(const float* src, int64_t stride, float* dst, int 
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
+
+// ---- max |x| of an fp32 tensor as an fp32 bit pattern (the scale source of the split-f16 convs, common.h SplitF16).  Non-negative fp32
+// values order like their bit patterns, so the maximum is an unsigned integer maximum and the cross-block fold is an atomicMax, whose
+// result does not depend on the order of arrival (deterministic).  NaN patterns order above infinity: a NaN in the tensor stays
+// visible in the result.  Blocks skip the atomic when the slot already holds at least their maximum.
+__device__ __forceinline__ unsigned amax_block(unsigned m, unsigned* red /* >= 4 words of LDS */) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[w] = m;
+  __syncthreads();
+  unsigned r = red[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = red[i] > r ? red[i] : r;
+  return r;
+}
+__device__ __forceinline__ unsigned amax_span(const float* __restrict__ x, int64_t n, int64_t first, int64_t stride) {
+  // 16-byte loads over the aligned body, scalar head / tail (first / stride in threads)
+  unsigned m = 0;
+  const int64_t head = ((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) / 4;
+  const int64_t h = head < n ? head : n;
+  const int64_t n4 = (n - h) / 4;
+  const u32x4* v = reinterpret_cast<const u32x4*>(x + h);
+  for (int64_t i = first; i < n4; i += stride) {
+    const u32x4 q = v[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const unsigned b = q[e] & 0x7FFFFFFFu; m = b > m ? b : m; }
+  }
+  const unsigned* xu = reinterpret_cast<const unsigned*>(x);
+  for (int64_t i = first; i < h; i += stride) { const unsigned b = xu[i] & 0x7FFFFFFFu; m = b > m ? b : m; }
+  for (int64_t i = h + 4 * n4 + first; i < n; i += stride) { const unsigned b = xu[i] & 0x7FFFFFFFu; m = b > m ? b : m; }
+  return m;
+}
+__global__ void amax_slots_zero_kernel(unsigned* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ slot) {
+  __shared__ unsigned red[4];
+  const unsigned m = amax_block(amax_span(x, n, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256), red);
+  if (threadIdx.x == 0 && m > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m);
+}
+extern "C" int mia_amax(const float* x, int64_t n, void* slot, int reset, void* stream) {
+  MIA_CHECK_ARG(x && slot && n > 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0 && (reinterpret_cast<uintptr_t>(slot) & 3) == 0, "mia_amax: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // (the slot is zeroed by a kernel, not hipMemsetAsync: a captured train step that held memset nodes on graph-pool memory replayed
+  // wrongly once a second graph had been captured -- round 5, tools/probe/graph_diverge.py)
+  if (reset) hipLaunchKernelGGL(amax_slots_zero_kernel, dim3(1), dim3(64), 0, st, static_cast<unsigned*>(slot), 1);
+  const int64_t want = (n / 4 + 255) / 256 / 8;  // ~8 sixteen-byte loads per thread
+  const int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, st, x, n, static_cast<unsigned*>(slot));
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// Batched form: the maxima of `count` tensors (device table of {pointer, element count}) into slots[0 .. count) in ONE launch --
+// every weight of a model right after the optimizer step (ops.PackPlan).  The slots are zeroed first.
+struct MiaAmaxDesc { const float* src; int64_t n; };
+__global__ __launch_bounds__(256) void amax_batch_kernel(const MiaAmaxDesc* __restrict__ descs, unsigned* __restrict__ slots) {
+  __shared__ unsigned red[4];
+  const MiaAmaxDesc d = descs[blockIdx.y];
+  if ((int64_t)blockIdx.x * 1024 >= d.n && blockIdx.x > 0) return;  // small tensors leave most of their row of blocks empty
+  const unsigned m = amax_block(amax_span(d.src, d.n, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256), red);
+  if (threadIdx.x == 0 && m > __hip_atomic_load(slots + blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slots + blockIdx.y, m);
+}
+extern "C" int mia_amax_desc_bytes(void) { return (int)sizeof(MiaAmaxDesc); }
+extern "C" int mia_amax_batch(const void* descs_dev, int count, void* slots, void* stream) {
+  MIA_CHECK_ARG(descs_dev && slots && count > 0 && count <= 65535, "mia_amax_batch: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(amax_slots_zero_kernel, dim3((count + 255) / 256), dim3(256), 0, st, static_cast<unsigned*>(slots), count);
+  hipLaunchKernelGGL(amax_batch_kernel, dim3(64, count), dim3(256), 0, st, static_cast<const MiaAmaxDesc*>(descs_dev), static_cast<unsigned*>(slots));
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}

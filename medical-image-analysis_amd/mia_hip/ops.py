@@ -51,6 +51,85 @@ def _kb(dtype: int) -> int:
     return 32 if dtype == BF16 else 16
 
 
+# ------------------------------------------------------------------ operand maxima (fp32 convs on the f16 matrix cores)
+# The fp32 tile kernels multiply on the f16 matrix cores from two-part split operands (csrc/common.h SplitF16); each operand tensor is
+# scaled by a power of two taken from its max |x|, which the kernels read from a 4-byte device slot.  A slot travels with its
+# tensor as a Python attribute (`_mia_amax` = (slot, tensor version)): the forward conv, the weight gradient that contracts the same
+# activation in backward, and the two consumers of one gradient tensor share one reduction.  An attribute cannot outlive its tensor
+# (unlike a table keyed by address), and a version change (in-place edit) makes the next consumer measure again.
+F32_SPLIT_MIN_MACS = int(__import__('os').environ.get('MIA_F32_SPLIT_MIN_MACS', str(1 << 26)))  # below this many multiply-adds the exact kernel is as fast as the reduction + split
+
+
+class _SlotArena:
+    """Zeroed 4-byte slots, carved from chunks that ONE launch zeroes (a slot per norm / activation pass and per measured tensor
+    would otherwise cost a zeroing launch each).  A slot is a view of its chunk, so the chunk lives as long as any of its slots.
+    A chunk started outside a stream capture is never used inside one and vice versa: the zeroing launch must be part of the
+    graph that uses the slots, or replays would fold into the previous replay's maxima (still safe -- a larger maximum only
+    costs precision -- but no longer the eager step's arithmetic)."""
+    CHUNK = 128
+
+    def __init__(self):
+        self.chunk, self.used, self.capturing, self.device = None, 0, False, None
+
+    def reset(self) -> None:
+        self.chunk = None
+
+    def take(self, device) -> torch.Tensor:
+        cap = torch.cuda.is_current_stream_capturing()
+        if self.chunk is None or self.used >= self.CHUNK or cap != self.capturing or device != self.device:
+            self.chunk = torch.empty(self.CHUNK, device=device, dtype=torch.int32)
+            call("mia_zero", _p(self.chunk), _c_i64(self.CHUNK * 4), _stream())
+            self.used, self.capturing, self.device = 0, cap, device
+        self.used += 1
+        return self.chunk[self.used - 1:self.used]
+
+
+_ARENA = _SlotArena()
+
+
+def amax_arena_reset() -> None:
+    """Start a fresh chunk at the next request (training/engine.py: at both ends of a graph capture)."""
+    _ARENA.reset()
+
+
+def amax_slot(t: torch.Tensor) -> torch.Tensor:
+    """Device slot (int32[1]) with max |t| as an fp32 bit pattern; measured once per tensor version (`mia_amax`)."""
+    hit = getattr(t, "_mia_amax", None)
+    if hit is not None and hit[1] == t._version:
+        return hit[0]
+    slot = _ARENA.take(t.device)
+    tc = t if t.is_contiguous() else t.contiguous()
+    call("mia_amax", _p(tc), _c_i64(tc.numel()), _p(slot), 0, _stream())
+    try:
+        t._mia_amax = (slot, t._version)
+    except (AttributeError, RuntimeError):
+        pass
+    return slot
+
+
+def _amax_new(t: torch.Tensor) -> Optional[torch.Tensor]:
+    """A fresh slot, attached to `t`, that the kernel about to WRITE t fills as a by-product (`amax_out` of the norm / activation
+    passes): the convs that consume t then need no reduction pass of their own.  fp32 tensors only."""
+    if t.dtype != torch.float32:
+        return None
+    slot = _ARENA.take(t.device)
+    t._mia_amax = (slot, t._version)
+    return slot
+
+
+def _dup_view(z: torch.Tensor) -> torch.Tensor:
+    """Second handle on z (PlainBlockFn dup=True) that carries the same maximum slot."""
+    v = z.view(z.shape)
+    h = getattr(z, "_mia_amax", None)
+    if h is not None:
+        v._mia_amax = (h[0], v._version)
+    return v
+
+
+def _split_ok(x: torch.Tensor, macs: int) -> bool:
+    return x.dtype == torch.float32 and macs >= F32_SPLIT_MIN_MACS
+
+
 # ------------------------------------------------------------------ weight packing (cached per parameter version)
 PARAM_EPOCH = 0
 
@@ -84,6 +163,11 @@ class PackCache:
         if not wc.is_contiguous():
             wc = wc.contiguous()
         call("mia_pack_weight", _p(wc), _p(buf), dtype, d0, d1, taps, npad, kpad, int(n_from_d0), _stream())
+        if dtype == F32:  # the split-f16 kernels scale the weights by their maximum (amax_slot docstring); slot rides on the packed buffer
+            slot = getattr(buf, "_mia_amax", None)
+            slot = slot[0] if slot is not None else torch.empty(1, device=w.device, dtype=torch.int32)
+            call("mia_amax", _p(wc), _c_i64(wc.numel()), _p(slot), 1, _stream())
+            buf._mia_amax = (slot, buf._version)
         self._store[key] = (ver, buf, npad, kpad)
         return buf, npad, kpad
 
@@ -130,14 +214,29 @@ class PackPlan:
         self.total_bricks = bricks
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.descs = host.to(self.entries[0][0].device)
+        self.amax_descs = None
+        if dtype == F32:  # maxima of every packed parameter in one launch; slot i rides on entry i's packed buffer
+            class ADesc(C.Structure):
+                _fields_ = [("src", C.c_void_p), ("n", C.c_int64)]
+
+            assert C.sizeof(ADesc) == lib().mia_amax_desc_bytes()
+            aarr = (ADesc * len(self.entries))()
+            for i, (w, *_rest) in enumerate(self.entries):
+                aarr[i] = ADesc(w.data_ptr(), w.numel())
+            self.amax_descs = torch.frombuffer(bytearray(bytes(aarr)), dtype=torch.uint8).to(self.entries[0][0].device)
+            self.amax_slots = torch.zeros(len(self.entries), device=self.entries[0][0].device, dtype=torch.int32)
 
     def valid(self) -> bool:
         return all(w.data_ptr() == ptr for w, _, _, _, _, _, ptr in self.entries)
 
     def repack(self) -> None:
         call("mia_pack_weight_batch", _p(self.descs), len(self.entries), self.total_bricks, self.max_taps, self.dtype, _stream())
-        for w, pc, key, buf, npad, kpad, _ in self.entries:
+        if self.amax_descs is not None:
+            call("mia_amax_batch", _p(self.amax_descs), len(self.entries), _p(self.amax_slots), _stream())
+        for i, (w, pc, key, buf, npad, kpad, _) in enumerate(self.entries):
             pc._store[key] = ((w._version, w.data_ptr(), PARAM_EPOCH), buf, npad, kpad)
+            if self.amax_descs is not None:
+                buf._mia_amax = (self.amax_slots[i:i + 1], buf._version)
 
 
 _caches = {}
@@ -237,6 +336,13 @@ def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: tor
     stats = None
     if want_stats or cr is not None:
         stats = torch.empty((n, conv_tiles(mode, hout, wout), nout, 2), device=x1.device, dtype=torch.float32)
+    # fp32: operand maxima for the split-f16 products (None -> the library runs its exact fp32 kernels)
+    am1 = am2 = amw = None
+    if cr is None and nl is None and _split_ok(x1, n * hout * wout * nout * (c1 + c2)):
+        wh = getattr(wpack, "_mia_amax", None)
+        if wh is not None:
+            amw, am1 = wh[0], amax_slot(x1)
+            am2 = None if x2 is None else amax_slot(x2)
     tag = PROBE.match(mode, c1, c2, nout, hin, win, bool(flip)) if (PROBE is not None and PROBE.enabled) else None
     probe = PROBE if tag else None
     if probe is not None:
@@ -253,7 +359,7 @@ def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: tor
              _p(bias), _p(out1), o1, _p(stats), n, hin, win, hout, wout, _stream())
     else:
         call("mia_conv_mma", mode, _dt(x1), _p(x1), c1, _p(x2), c2, _p(wpack), npad, kpad, int(flip), _p(bias), _p(out1), o1,
-             _p(out2), o2, _p(stats), n, hin, win, hout, wout, _stream())
+             _p(out2), o2, _p(stats), n, hin, win, hout, wout, _p(am1), _p(am2), _p(amw), _stream())
     if probe is not None:
         e1.record()
         probe.pairs.append((e0, e1, tag, (mode, c1 + c2, nout, n, hout, wout)))
@@ -291,8 +397,12 @@ def conv_wgrad(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], dy: torc
         call("mia_conv_wgrad_nl", mode, dtype, _p(x1), c1, _p(nl[0][2]), _p(nl[0][3]), _c_float(nl[1]), _p(dy), cdy, _p(slabs),
              ksplit, npad, kpad, n, hx, wx, hy, wy, _stream())
     else:
+        am1 = am2 = amd = None
+        if _split_ok(x1, n * hy * wy * cdy * (c1 + c2)) and dy.dtype == torch.float32:
+            am1, amd = amax_slot(x1), amax_slot(dy)
+            am2 = None if x2 is None else amax_slot(x2)
         call("mia_conv_wgrad", mode, dtype, _p(x1), c1, _p(x2), c2, _p(dy), cdy, _p(slabs), ksplit, npad, kpad, n, hx, wx, hy,
-             wy, _stream())
+             wy, _p(am1), _p(am2), _p(amd), _stream())
     grad = out if out is not None else torch.empty(grad_shape, device=x1.device, dtype=torch.float32)
     call("mia_wgrad_reduce", _p(slabs), ksplit, taps, npad, kpad, _p(grad), nn, kk, 0, _stream())
     return grad
@@ -549,7 +659,7 @@ class LazyMaterializeFn(torch.autograd.Function):
     def forward(ctx, y, coefs, slope):
         n, h, w, c = y.shape
         z = torch.empty_like(y)
-        call("mia_norm_act_fwd", _p(y), _p(z), _dt(y), _p(coefs[2]), _p(coefs[3]), n, _c_i64(h * w), c, _c_float(slope), _stream())
+        call("mia_norm_act_fwd", _p(y), _p(z), _dt(y), _p(coefs[2]), _p(coefs[3]), n, _c_i64(h * w), c, _c_float(slope), _p(_amax_new(z)), _stream())
         return z
 
     @staticmethod
@@ -560,17 +670,17 @@ class LazyMaterializeFn(torch.autograd.Function):
 FUSE_HEAD_W = __import__('os').environ.get('MIA_FUSE_HEAD_W', '1') != '0'  # A/B knob: head dW / db in the norm-backward reduction pass
 FUSE_STEM_BWD = __import__('os').environ.get('MIA_FUSE_STEM_BWD', '1') != '0'  # A/B knob: the stem's backward apply pass folded into its weight gradient
 FUSE_NL = __import__('os').environ.get('MIA_FUSE_NL', '1') != '0'  # A/B knob: 0 = every block materialises its activation
-FUSE_NL_F32 = __import__('os').environ.get('MIA_FUSE_NL_F32', '0') != '0'  # normalise-on-load pairs in fp32 models (every level; bit-identical; measured +-0 on cfg2 / cfg4: off)
 
 
 def nl_supported(dtype, cin: int, cout: int, h: int, w: int, train: bool) -> bool:
-    """Can a stride-1 3x3 block with these shapes consume its predecessor's raw output (normalise-on-load)?"""
-    if not FUSE_NL or dtype not in (torch.bfloat16, torch.float32) or (dtype == torch.float32 and not FUSE_NL_F32):
+    """Can a stride-1 3x3 block with these shapes consume its predecessor's raw output (normalise-on-load)?  bf16 only: the 64 -> 64
+    register-staged kernels (the fp32 form of round 4 measured +-0 and is gone: the split-f16 products need the maximum of the
+    NORMALISED tensor, which nobody has computed when the raw output is loaded)."""
+    if not FUSE_NL or dtype != torch.bfloat16:
         return False
-    dtc = _dt(dtype)  # bf16: the 64 -> 64 register-staged kernels; fp32: every shape of the branch-free tile kernels (all levels)
-    if not lib().mia_conv_nl_supported(CONV_G3S1, dtc, cin, cout, h, w):
+    if not lib().mia_conv_nl_supported(CONV_G3S1, BF16, cin, cout, h, w):
         return False
-    return (not train) or bool(lib().mia_wgrad_nl_supported(WGRAD_3S1, dtc, cin, cout))
+    return (not train) or bool(lib().mia_wgrad_nl_supported(WGRAD_3S1, BF16, cin, cout))
 
 
 class PlainBlockFn(torch.autograd.Function):
@@ -605,7 +715,7 @@ class PlainBlockFn(torch.autograd.Function):
             z = PlainBlockFn._stem_forward(ctx, x1, weight, bias, gamma, beta, cfg, out_dtype, slope, lazy)
             if lazy:
                 return z
-            return (z, z.view(z.shape)) if dup else z
+            return (z, _dup_view(z)) if dup else z
         if x1.dtype != out_dtype:
             x1 = cast_nhwc(x1, out_dtype)
         if x2 is not None and (x2.shape[:3] != x1.shape[:3] or x2.dtype != x1.dtype):
@@ -637,9 +747,9 @@ class PlainBlockFn(torch.autograd.Function):
             return y, coefs
         z = torch.empty_like(y)
         call("mia_norm_act_fwd", _p(y), _p(z), dtype, _p(coefs[2]), _p(coefs[3]), n, _c_i64(ho * wo), cout,
-             _c_float(slope), _stream())
+             _c_float(slope), _p(_amax_new(z)), _stream())
         ctx.save_for_backward(x1, x2, y, coefs, weight, gamma, nl_coefs)
-        return (z, z.view(z.shape)) if dup else z
+        return (z, _dup_view(z)) if dup else z
 
     @staticmethod
     def _norm_act(ctx, y, stats, gamma, beta, cfg, n, cout, hw, slope=LRELU_SLOPE):
@@ -648,7 +758,7 @@ class PlainBlockFn(torch.autograd.Function):
         ctx.sync = _norm_finalize(cfg, stats, gamma, beta, n, cout, hw, coefs)
         z = torch.empty_like(y)
         call("mia_norm_act_fwd", _p(y), _p(z), _dt(y), _p(coefs[2]), _p(coefs[3]), n, _c_i64(hw), cout, _c_float(slope),
-             _stream())
+             _p(_amax_new(z)), _stream())
         return z, coefs
 
     @staticmethod
@@ -703,7 +813,7 @@ class PlainBlockFn(torch.autograd.Function):
             if pre is not None:
                 call("mia_norm_act_bwd_pre", None, None, None, dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
                      _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope),
-                     pre.shape[1], _p(pre), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
+                     pre.shape[1], _p(pre), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, None, _stream())
             else:
                 call("mia_norm_bwd_sums", _p(dz), _p(dz2), _p(y), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
                      _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs,
@@ -721,11 +831,11 @@ class PlainBlockFn(torch.autograd.Function):
         if pre is not None:
             call("mia_norm_act_bwd_pre", _p(dz), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
                  _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope),
-                 pre.shape[1], _p(pre), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
+                 pre.shape[1], _p(pre), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _p(_amax_new(dy)), _stream())
         elif ctx.sync is None:
             call("mia_norm_act_bwd", _p(dz), _p(dz2), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
                  _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs,
-                 _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
+                 _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta), _p(dbias), 0, _p(_amax_new(dy)), _stream())
         else:  # synchronised batch norm: the group means of g and g*xhat cover every rank's shard
             tot = torch.empty((3, cout), device=dev, dtype=torch.float32)
             call("mia_norm_act_bwd_reduce", _p(dz), _p(dz2), _p(y), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]), n,
@@ -733,7 +843,7 @@ class PlainBlockFn(torch.autograd.Function):
             ctx.sync.all_reduce_sum(tot)
             call("mia_norm_act_bwd_apply_sync", _p(dz), _p(dz2), _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]),
                  _p(coefs[1]), _p(coefs[4]), n, _c_i64(hw), cout, _c_float(ctx.slope), _p(cc[0]), _p(cc[1]), _p(tot),
-                 _p(dgamma), _p(dbeta), _p(dbias), 0, _stream())
+                 _p(dgamma), _p(dbeta), _p(dbias), 0, _p(_amax_new(dy)), _stream())
         cin = weight.shape[1]
         if ctx.stem:
             ws = torch.empty(lib().mia_stem_wgrad_workspace(cout), device=dev, dtype=torch.float32)
@@ -754,8 +864,9 @@ class PlainBlockFn(torch.autograd.Function):
                 other = _take_acc(x1) if (x2 is None and ctx.dup_in) else None
                 if other is not None and lib().mia_conv_acc_supported(CONV_T3S2, dtype, cout, cin):
                     # the other consumer of x1 (a skip tensor) has already written its gradient piece: add ours into it
+                    amw = getattr(wb, "_mia_amax", None) if _split_ok(dy, n * ho * wo * cout * cin) else None
                     call("mia_conv_mma_acc", CONV_T3S2, dtype, _p(dy), cout, _p(wb), npad, kpad, 0, _p(other), cin, n, ho, wo,
-                         x1.shape[1], x1.shape[2], _stream())
+                         x1.shape[1], x1.shape[2], _p(None if amw is None else amax_slot(dy)), _p(None if amw is None else amw[0]), _stream())
                     return (None, None, dw, dbias, dgamma, dbeta) + (None,) * 8
                 dx1, dx2, _ = conv_mma(CONV_T3S2, dy, None, wb, npad, kpad, False, None, cin, (x1.shape[1], x1.shape[2]),
                                        out_split=split)
@@ -857,7 +968,7 @@ class PlainBlockHeadFn(torch.autograd.Function):
             call("mia_norm_act_bwd_head_w", _p(dl), _p(w2), k1, _c_i64(st[0]), _c_i64(st[1]), _c_i64(st[2]), _p(y), _p(dy), dtype,
                  _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]), _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout,
                  ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs, _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta),
-                 _p(dbias), 0, _p(ws), _p(dwh), _p(dbh), 0, _stream())
+                 _p(dbias), 0, _p(ws), _p(dwh), _p(dbh), 0, _p(_amax_new(dy)), _stream())
         else:
             ws = torch.empty(lib().mia_head_bwd_workspace(cout, k1), device=dev, dtype=torch.float32)
             call("mia_head_norm_wgrad", _p(dl), _p(y), dtype, _p(coefs[2]), _p(coefs[3]), _c_float(ctx.slope), _p(dwh), _p(dbh),
@@ -866,7 +977,7 @@ class PlainBlockHeadFn(torch.autograd.Function):
             call("mia_norm_act_bwd_head", _p(dl), _p(w2), k1, _c_i64(st[0]), _c_i64(st[1]), _c_i64(st[2]), _p(y), _p(dy), dtype,
                  _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]), _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout,
                  ctx.mode, int(ctx.fixed), _c_float(ctx.slope), slabs, _p(part), _p(cc[0]), _p(cc[1]), _p(dgamma), _p(dbeta),
-                 _p(dbias), 0, _stream())
+                 _p(dbias), 0, _p(_amax_new(dy)), _stream())
         dw = conv_wgrad(WGRAD_3S1, x1, None, dy, weight.shape, cout, cin, out=grad_dest(weight),
                         nl=None if nl_coefs is None else (nl_coefs, ctx.nl_slope))
         dx1 = None
@@ -1145,7 +1256,7 @@ class PointwiseNormFn(torch.autograd.Function):
         dy = torch.empty_like(y)
         call("mia_norm_act_bwd", _p(dz), None, _p(y), _p(dy), dtype, _p(coefs[2]), _p(coefs[3]), _p(coefs[0]), _p(coefs[1]),
              _p(None if ctx.fixed else coefs[4]), n, _c_i64(hw), cout, ctx.mode, int(ctx.fixed), _c_float(1.0), slabs, _p(part),
-             _p(cc[0]), _p(cc[1]), _p(dgb[0]), _p(dgb[1]), _p(dgb[2]), 0, _stream())
+             _p(cc[0]), _p(cc[1]), _p(dgb[0]), _p(dgb[1]), _p(dgb[2]), 0, _p(_amax_new(dy)), _stream())
         w4 = PointwiseNormFn._as_taps(weight, ctx.stride)
         if ctx.stride == 2:
             g4 = conv_wgrad(WGRAD_2S2, x, None, dy, w4.shape, cout, cin)
@@ -1178,7 +1289,7 @@ class ScaleLReLUFn(torch.autograd.Function):
         else:
             coef[0].copy_(m)
         z = torch.empty_like(v)
-        call("mia_norm_act_fwd", _p(v), _p(z), _dt(v), _p(coef[0]), _p(coef[1]), n, _c_i64(h * w), c, _c_float(slope), _stream())
+        call("mia_norm_act_fwd", _p(v), _p(z), _dt(v), _p(coef[0]), _p(coef[1]), n, _c_i64(h * w), c, _c_float(slope), _p(_amax_new(z)), _stream())
         ctx.save_for_backward(v, coef)
         ctx.slope = slope
         return z
@@ -1197,7 +1308,7 @@ class ScaleLReLUFn(torch.autograd.Function):
         # frozen statistics: dv = scale * dz * lrelu'(scale*v)
         call("mia_norm_act_bwd", _p(dz), None, _p(v), _p(dv), _dt(v), _p(coef[0]), _p(coef[1]), _p(coef[0]), _p(coef[1]), None, n,
              _c_i64(h * w), c, NORM_INSTANCE, 1, _c_float(ctx.slope), slabs, _p(part), _p(cc[0]), _p(cc[1]), _p(junk[0]), _p(junk[1]),
-             None, 0, _stream())
+             None, 0, _p(_amax_new(dv)), _stream())
         return dv, None, None
 
 

@@ -346,6 +346,7 @@ class TrainEngine:
         torch.cuda.synchronize()
         g.graph = torch.cuda.CUDAGraph()
         ops._STEP_DYN = g.dyn
+        ops.amax_arena_reset()  # the slots this capture uses come from chunks zeroed INSIDE it
         try:
             with torch.cuda.graph(g.graph, capture_error_mode="thread_local"):
                 output = self.model(g.img)
@@ -356,6 +357,7 @@ class TrainEngine:
                 g.loss = loss.detach()
         finally:
             ops._STEP_DYN = None
+            ops.amax_arena_reset()
             opt.step_count, opt.stepped = saved
         return g
 

@@ -209,18 +209,24 @@ def test_cfg1_tiny_fp32_engine_step_vs_oracle():
     assert (got.argmax(1)[safe] == want.argmax(1)[safe]).all()
 
 
+@pytest.mark.parametrize("split,min_macs", [(0, None), (1, 0)])
 @pytest.mark.parametrize("channels,size,n", [([16, 32, 64], 128, 4), ([32, 64, 128, 256, 512], 128, 2), ([64, 128, 256, 512, 1024], 128, 2)])
-def test_f32_split_train_step_meets_the_fp32_gates(channels, size, n):
-    """Option f32_split (fp32 tensors, split-bf16 products on the matrix cores: csrc/common.h SplitBf16) under the SAME gates as
-    the exact fp32 path: cfg1's, cfg4's and cfg2's networks, one train step against oracle/train_ref -- logits / loss 1e-4, label
-    maps exact off ties, gradients by `_check_grads_vs_exact`, clip norm, post-AdamW state."""
+def test_f32_exact_and_split_everywhere_train_steps_meet_the_fp32_gates(channels, size, n, split, min_macs):
+    """The fp32 path's two extremes under the SAME gates (cfg1's, cfg4's and cfg2's networks, one train step against
+    oracle/train_ref: logits / loss 1e-4, label maps exact off ties, gradients by `_check_grads_vs_exact`, clip norm, post-AdamW state):
+    option f32_split = 0 (every product an exact fp32 MFMA) and split-f16 products in EVERY tile-kernel launch (size gate lifted).
+    The default -- split products in the launches above the size gate -- is what every other fp32 test in this file runs."""
     import mia_hip
-    old = mia_hip.get_option("f32_split")
-    mia_hip.set_option("f32_split", 1)
+    from mia_hip import ops
+    old, old_gate = mia_hip.get_option("f32_split"), ops.F32_SPLIT_MIN_MACS
+    mia_hip.set_option("f32_split", split)
+    if min_macs is not None:
+        ops.F32_SPLIT_MIN_MACS = min_macs
     try:
         _fp32_step_vs_oracle(channels, "instance", size, n, seed=5)
     finally:
         mia_hip.set_option("f32_split", old)
+        ops.F32_SPLIT_MIN_MACS = old_gate
 
 
 def test_full_width_bf16_train_step_vs_fp32_oracle():

@@ -47,7 +47,7 @@ def main():
 
         def hbm_job(stream):
             for _ in range(a.passes):
-                call("mia_norm_act_fwd", _p(y), _p(z), BF16, _p(sc), _p(sh), n, _c_i64(s * s), c, _c_float(0.01), stream.cuda_stream)
+                call("mia_norm_act_fwd", _p(y), _p(z), BF16, _p(sc), _p(sh), n, _c_i64(s * s), c, _c_float(0.01), None, stream.cuda_stream)
 
         main_s = torch.cuda.current_stream()
 
