@@ -125,11 +125,13 @@ int mia_get_option(const char* name, int* value);
 int mia_conv_mma_tiles(int mode, int hout, int wout, int* tiles_y, int* tiles_x, int* tile_h);
 /* amax_in1 / amax_in2 / amax_w (optional, fp32 tensors only): device pointers to max |x| of in1 / in2 / the weight tensor as fp32
  * bit patterns (mia_amax / mia_amax_batch).  All present (amax_in2 only when c2 > 0) and option f32_split on: the products run on the
- * f16 matrix cores from two-part split operands (see f32_split above); any of them NULL: exact fp32 MFMAs. */
+ * f16 matrix cores from two-part split operands (see f32_split above); any of them NULL: exact fp32 MFMAs.
+ * amax_out1 / amax_out2 (optional, fp32): ZEROED 4-byte slots that receive max |out1| / max |out2| as a by-product (epilogue of the
+ * tile kernel, a separate pass for generic shapes) -- for outputs another conv consumes directly (unet.py:142 -> :213 and back). */
 int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const void* in2, int c2, const void* wpack, int npad,
                  int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2, int o2,
                  float* stat_partials, int n, int hin, int win, int hout, int wout, const void* amax_in1, const void* amax_in2,
-                 const void* amax_w, void* stream);
+                 const void* amax_w, void* amax_out1, void* amax_out2, void* stream);
 /* max |x| of an fp32 tensor of n elements, folded (atomic unsigned maximum of the fp32 bit pattern: order-independent, deterministic)
  * into *slot; reset != 0 zeroes the slot first (stream-ordered, by a kernel: hipMemsetAsync nodes on graph-pool memory were seen to
  * replay wrongly inside a captured step).  The batched form takes a device table of `count`

@@ -288,6 +288,8 @@ static int dispatch(int mode, const ConvArgs& a, int mt, int nt, int grid_y, hip
   return MIA_OK;
 }
 
+extern "C" int mia_amax(const float* x, int64_t n, void* slot, int reset, void* stream);
+
 // Tile-domain geometry shared with the host (stats buffer sizing): see include/mia_hip.h.
 static void conv_tiles(const MiaOptions& opt, int mode, int hout, int wout, int* tiles_y, int* tiles_x, int* tile_h) {
   const bool tmode = (mode == MODE_T3S2 || mode == MODE_T2S2);
@@ -311,7 +313,7 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
                         int o2, float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream,
                         const float* nl_scale, const float* nl_shift, float nl_slope, const void* cr_y = nullptr,
                         const float* const* cr_coef = nullptr, float cr_slope = 0.f, int acc_out = 0, const void* amax_in1 = nullptr,
-                        const void* amax_in2 = nullptr, const void* amax_w = nullptr) {
+                        const void* amax_in2 = nullptr, const void* amax_w = nullptr, void* amax_out1 = nullptr, void* amax_out2 = nullptr) {
   MIA_CHECK_ARG(mode >= 0 && mode <= MODE_G1, "mia_conv_mma: bad mode %d", mode);
   MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_conv_mma: bad dtype %d", dtype);
   MIA_CHECK_ARG(in1 && wpack && out1 && c1 > 0 && o1 > 0 && c2 >= 0 && o2 >= 0, "mia_conv_mma: null/empty operand");
@@ -342,6 +344,7 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
   a.split = (dtype == MIA_F32 && opt.f32_split && amax_in1 != nullptr && amax_w != nullptr && (c2 == 0 || amax_in2 != nullptr)) ? 1 : 0;
   a.amax_in1 = static_cast<const unsigned*>(amax_in1); a.amax_in2 = static_cast<const unsigned*>(amax_in2);
   a.amax_w = static_cast<const unsigned*>(amax_w);
+  if (dtype != MIA_F32) amax_out1 = amax_out2 = nullptr;
   if (cr_y != nullptr) {
     a.cr_y = cr_y; a.cr_scale = cr_coef[0]; a.cr_shift = cr_coef[1]; a.cr_xa = cr_coef[2]; a.cr_xb = cr_coef[3]; a.cr_slope = cr_slope;
   }
@@ -416,19 +419,26 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
   // conv_pw_s2 = 1 stops at 256 input channels, = 2 always)
   else if (opt.conv_pw && mode != MODE_T3S2 && (mode != MODE_G3S2 || opt.conv_pw_s2 >= 2 || (opt.conv_pw_s2 == 1 && c1 <= 256)) && conv_pw_eligible(mode, dtype, a))
     rc = conv_pw_launch(mode, a, opt.reserve_cus, st);
-  else if (fast) rc = conv_mma_fast_launch(mode, dtype, a, t3_wide ? 16 : mt, nt, grid_y, st);
+  else if (fast) {
+    if (dtype == MIA_F32) { a.amax_out1 = static_cast<unsigned*>(amax_out1); a.amax_out2 = static_cast<unsigned*>(amax_out2); amax_out1 = amax_out2 = nullptr; }
+    rc = conv_mma_fast_launch(mode, dtype, a, t3_wide ? 16 : mt, nt, grid_y, st);
+  }
   else rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);
   if (rc != MIA_OK) return rc;
   MIA_LAUNCH_CHECK();
+  // output maxima the launched kernel did not fold in its epilogue (generic shapes): a separate pass each
+  if (amax_out1 != nullptr) { rc = mia_amax(static_cast<const float*>(out1), (int64_t)n * hout * wout * o1, amax_out1, 0, stream); if (rc) return rc; }
+  if (amax_out2 != nullptr && out2 != nullptr) { rc = mia_amax(static_cast<const float*>(out2), (int64_t)n * hout * wout * o2, amax_out2, 0, stream); if (rc) return rc; }
   return MIA_OK;
 }
 
 extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const void* in2, int c2, const void* wpack,
                             int npad, int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2,
                             int o2, float* stat_partials, int n, int hin, int win, int hout, int wout, const void* amax_in1,
-                            const void* amax_in2, const void* amax_w, void* stream) {
+                            const void* amax_in2, const void* amax_w, void* amax_out1, void* amax_out2, void* stream) {
   return conv_mma_run(mode, dtype, in1, c1, in2, c2, wpack, npad, kpad, flip_taps, bias, out1, o1, out2, o2, stat_partials, n, hin,
-                      win, hout, wout, stream, nullptr, nullptr, 0.f, nullptr, nullptr, 0.f, 0, amax_in1, amax_in2, amax_w);
+                      win, hout, wout, stream, nullptr, nullptr, 0.f, nullptr, nullptr, 0.f, 0, amax_in1, amax_in2, amax_w, amax_out1,
+                      amax_out2);
 }
 
 // Normalise-on-load forward conv (the fused PlainBlock, SURVEY 8b export list "conv3x3_nhwc ... optional fused normalise +

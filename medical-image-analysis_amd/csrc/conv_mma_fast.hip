@@ -49,6 +49,9 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   u32x4* ldsB = ldsA + A_UNITS;
   T* ldsO = reinterpret_cast<T*>(smem);
   float* ldsR = reinterpret_cast<float*>(smem + LDS_BYTES);
+  __shared__ unsigned ldsM[2];  // block maxima of |out1| / |out2| (a.amax_out*)
+  const bool want_amax = sizeof(T) == 4 && (a.amax_out1 != nullptr || a.amax_out2 != nullptr);  // uniform
+  if (want_amax && threadIdx.x < 2) ldsM[threadIdx.x] = 0u;  // (the K loop's barriers order this before the epilogue's atomics)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = (tid >> 6) & 3, wc = tid >> 8;  // row group; channel half (WC == 2)
@@ -155,14 +158,12 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
 
   u32x4 pa[A_IT], pb[B_IT];
   // split mode: operand scales 2^ea (activations: the larger maximum of the two sources, one reduction dimension), 2^eb (weights)
+  // (the three scalar loads are issued here, their arithmetic sits behind the first tile's vector loads: a workgroup lives for one
+  // tile, ~10 us, and a scalar round trip in front of its first fetch was 8 % of the launch)
   float sc_a = 1.f, sc_b = 1.f;
   int e_out = 0;
-  if constexpr (SPLIT) {
-    unsigned ma = *a.amax_in1;
-    if (a.c2) { const unsigned m2 = *a.amax_in2; ma = m2 > ma ? m2 : ma; }
-    const int ea = SplitF16::exp_of(ma & 0x7FFFFFFFu), eb = SplitF16::exp_of(*a.amax_w & 0x7FFFFFFFu);
-    sc_a = SplitF16::pow2(ea); sc_b = SplitF16::pow2(eb); e_out = -(ea + eb);
-  }
+  unsigned raw_a = 0u, raw_a2 = 0u, raw_w = 0u;
+  if constexpr (SPLIT) { raw_a = *a.amax_in1; raw_a2 = a.c2 ? *a.amax_in2 : 0u; raw_w = *a.amax_w; }
   auto fetch = [&](int c0) {
     const bool second = c0 >= a.c1;  // uniform: chunks never straddle the two sources
     const rsrc_t rs = second ? rs2 : rs1;
@@ -215,6 +216,11 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   };
 
   fetch(0);
+  if constexpr (SPLIT) {
+    const unsigned ma = raw_a2 > raw_a ? raw_a2 : raw_a;
+    const int ea = SplitF16::exp_of(ma & 0x7FFFFFFFu), eb = SplitF16::exp_of(raw_w & 0x7FFFFFFFu);
+    sc_a = SplitF16::pow2(ea); sc_b = SplitF16::pow2(eb); e_out = -(ea + eb);
+  }
   for (int c0 = 0; c0 < ctot; c0 += KB) {
     commit();
     __syncthreads();
@@ -300,6 +306,33 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   float s1[NT], s2[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) { s1[n] = 0.f; s2[n] = 0.f; }
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][n][r] = SplitF16::unscale(acc[m][n][r], e_out);
+  }
+  unsigned am1 = 0u, am2 = 0u;
+  if constexpr (sizeof(T) == 4) {
+    if (want_amax) {  // ONE uniform branch around the whole pass (inside the store loop below it became a branch per element).
+      // Stored elements only: rows / pixels beyond the image and channels beyond nout do not count.
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const bool rok = oy0 + wave * MT + m < hd;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int col = n0 + (wc * NT + n) * 16 + pr;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned b = (rok && cmask[r] != 0.f && col < nout) ? (__builtin_bit_cast(unsigned, acc[m][n][r] + bv[n]) & 0x7FFFFFFFu) : 0u;
+            if (col < a.o1) am1 = b > am1 ? b : am1; else am2 = b > am2 ? b : am2;
+          }
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const float rm = (oy0 + wave * MT + m < hd) ? 1.f : 0.f;
@@ -307,7 +340,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
     for (int n = 0; n < NT; ++n) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = (SPLIT ? SplitF16::unscale(acc[m][n][r], e_out) : acc[m][n][r]) + bv[n];
+        const float v = acc[m][n][r] + bv[n];
         if (a.stats != nullptr) {
           const float vm = full ? v : v * (rm * cmask[r]);
           s1[n] += vm; s2[n] += vm * v;
@@ -325,7 +358,24 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
       if (q == 0) { ldsR[(0 * 4 + wave) * BN + (wc * NT + n) * 16 + pr] = t1; ldsR[(1 * 4 + wave) * BN + (wc * NT + n) * 16 + pr] = t2; }
     }
   }
+  if constexpr (sizeof(T) == 4) {
+    if (want_amax) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t1 = (unsigned)__shfl_xor((int)am1, o, 64), t2 = (unsigned)__shfl_xor((int)am2, o, 64);
+        am1 = t1 > am1 ? t1 : am1; am2 = t2 > am2 ? t2 : am2;
+      }
+      if (lane == 0) { if (am1) atomicMax(&ldsM[0], am1); if (am2) atomicMax(&ldsM[1], am2); }
+    }
+  }
   __syncthreads();
+  if constexpr (sizeof(T) == 4) {
+    if (want_amax && tid < 2) {
+      unsigned* dst = tid == 0 ? a.amax_out1 : a.amax_out2;
+      const unsigned b = ldsM[tid];
+      if (dst != nullptr && b > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, b);
+    }
+  }
   typedef __attribute__((address_space(1))) float gfloat;  // global (not flat) stores: a flat access makes the compiler drain every outstanding memory operation around it
   if constexpr (WC == 1) {
     if (a.stats != nullptr && tid < BN && n0 + tid < nout) {

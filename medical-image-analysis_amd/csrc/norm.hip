@@ -376,7 +376,7 @@ extern "C" int mia_norm_stats(const void* y, int dtype, int n, int64_t hw, int c
 
 // Running max |x| of the values a streaming kernel WRITES (fp32 tensors; the scale source of the split-f16 convs that consume them,
 // common.h SplitF16): a lane folds the fp32 bit patterns of its outputs, a wave folds its lanes, one atomic unsigned maximum per wave
-// and only when the slot does not hold at least that much already.  Every lane of the wave must arrive here (no early return).
+// and only when the slot does not hold at least that much already.  Every thread of the BLOCK must arrive here (no early return).
 // The caller hands in a ZEROED slot (or a running maximum to fold into): the kernels never reset it.
 extern "C" int mia_amax(const float* x, int64_t n, void* slot, int reset, void* stream);
 template <typename T> __device__ __forceinline__ void amax_fold(unsigned& m, const T* out) {
@@ -386,10 +386,21 @@ template <typename T> __device__ __forceinline__ void amax_fold(unsigned& m, con
   }
 }
 __device__ __forceinline__ void amax_publish(unsigned m, unsigned* __restrict__ slot) {
+  // lanes -> wave (DPP) -> block (LDS) -> ONE coherent load + conditional atomic per block: with one per wave (131 k waves per launch
+  // on one address) the forward apply pass ran 50 % slower (rocprofv3, cfg2: 70 -> 108 us average)
+  __shared__ unsigned blk;
+  if (threadIdx.x == 0) blk = 0u;
+  __syncthreads();
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
-  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m);
+  if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(&blk, m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned b = blk;
+    if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, b);
+  }
 }
+
 // ---------------------------------------------------------------- streaming apply kernels (C % EPU == 0)
 // grid = (n * slabs, ceil(UPP / UPB)); a thread owns ONE 16-byte channel unit of image n, keeps that unit's
 // per-(n,c) coefficients in registers and streams its slab's pixels: no per-element coefficient loads or divisions.

@@ -233,6 +233,11 @@ class PackPlan:
         call("mia_pack_weight_batch", _p(self.descs), len(self.entries), self.total_bricks, self.max_taps, self.dtype, _stream())
         if self.amax_descs is not None:
             call("mia_amax_batch", _p(self.amax_descs), len(self.entries), _p(self.amax_slots), _stream())
+        self.plant()
+
+    def plant(self) -> None:
+        """Mark the plan's packed copies as current (host bookkeeping only): after `repack`, and after a graph replay whose
+        captured re-pack launch rewrote them while the host-side keys stayed where the capture left them."""
         for i, (w, pc, key, buf, npad, kpad, _) in enumerate(self.entries):
             pc._store[key] = ((w._version, w.data_ptr(), PARAM_EPOCH), buf, npad, kpad)
             if self.amax_descs is not None:
@@ -358,8 +363,11 @@ def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: tor
         call("mia_conv_mma_nl", mode, _dt(x1), _p(x1), c1, _p(nl[0][2]), _p(nl[0][3]), _c_float(nl[1]), _p(wpack), npad, kpad,
              _p(bias), _p(out1), o1, _p(stats), n, hin, win, hout, wout, _stream())
     else:
+        # outputs that another conv consumes as they are (ConvTranspose output; the decoder conv's gradient w.r.t. it): maximum in the epilogue
+        ao1 = _amax_new(out1) if (mode == CONV_T2S2 and x1.dtype == torch.float32) else None
+        ao2 = _amax_new(out2) if (out2 is not None and x1.dtype == torch.float32) else None
         call("mia_conv_mma", mode, _dt(x1), _p(x1), c1, _p(x2), c2, _p(wpack), npad, kpad, int(flip), _p(bias), _p(out1), o1,
-             _p(out2), o2, _p(stats), n, hin, win, hout, wout, _p(am1), _p(am2), _p(amw), _stream())
+             _p(out2), o2, _p(stats), n, hin, win, hout, wout, _p(am1), _p(am2), _p(amw), _p(ao1), _p(ao2), _stream())
     if probe is not None:
         e1.record()
         probe.pairs.append((e0, e1, tag, (mode, c1 + c2, nout, n, hout, wout)))
@@ -514,6 +522,15 @@ def _hint_acc(x: torch.Tensor, dx: torch.Tensor) -> None:
 def _take_acc(x: torch.Tensor) -> Optional[torch.Tensor]:
     h = _ACC_HINT.pop(x.data_ptr(), None)
     return h[0] if (h is not None and h[1] == tuple(x.shape) and h[0].dtype == x.dtype) else None
+
+
+def clear_hints() -> None:
+    """Drop every producer -> consumer hint and gradient-destination claim (a step that was recorded but never ran -- a failed graph
+    capture -- leaves them pointing at tensors nobody wrote)."""
+    _COLSUM_HINT.clear()
+    _CR_HINT.clear()
+    _ACC_HINT.clear()
+    _GRAD_CLAIMED.clear()
 
 
 def cr_supported(dtype, cin: int, cout: int, h: int, w: int) -> bool:

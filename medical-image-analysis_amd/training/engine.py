@@ -265,6 +265,28 @@ class _CapturedStep:
     __slots__ = ("img", "lab", "dyn", "graph", "loss")
 
 
+class _ReservedCUs:
+    """`with _ReservedCUs(k):` -- library option reserve_cus = k inside, the previous value restored on the way out.  The option is
+    process-wide and also moves the weight gradients' split-K count: left set, every later kernel of the process (single-rank
+    validation, selectors, another engine, the tests) would inherit it."""
+
+    def __init__(self, k):
+        self.k, self.prev = k, None
+
+    def __enter__(self):
+        if self.k is not None:
+            import mia_hip
+            self.prev = mia_hip.get_option("reserve_cus")
+            mia_hip.set_option("reserve_cus", int(self.k))
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            import mia_hip
+            mia_hip.set_option("reserve_cus", self.prev)
+        return False
+
+
 class TrainEngine:
     """One object = model + loss + flat optimizer + poly LR (+ DP reducer).  ``train_step`` returns the loss
     TENSOR (no host sync); call ``.item()`` only when you log."""
@@ -293,10 +315,7 @@ class TrainEngine:
         world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         if dp_reserve_cus is None:
             dp_reserve_cus = DP_RESERVE_CUS if world > 1 else None
-        self.dp_reserve_cus = dp_reserve_cus
-        if dp_reserve_cus is not None and next(model.parameters()).is_cuda:
-            import mia_hip
-            mia_hip.set_option("reserve_cus", int(dp_reserve_cus))
+        self.dp_reserve_cus = dp_reserve_cus if next(model.parameters()).is_cuda else None  # applied around each train_step, then restored
         if world > 1:
             from models.unet.blocks import PlainBlock, ResidualBlock, convert_sync_batchnorm
             # ResidualBlock counts too: convert_sync_batchnorm raises NotImplementedError for it, which is the honest
@@ -330,6 +349,7 @@ class TrainEngine:
         self.graph_mode = bool(graph)
         self._graphs: Dict[tuple, "_CapturedStep"] = {}
         self._eager_steps = 0
+        self._graph_epoch = None  # ops.PARAM_EPOCH as the last capture / replay left it
 
     GRAPH_WARMUP = 3  # eager steps before capture: lazy module loads, PackPlan creation (step 2), allocator warm-up
 
@@ -367,6 +387,7 @@ class TrainEngine:
         if g is None:
             try:
                 g = self._graphs[key] = self._capture(image, label)
+                self._graph_epoch = ops.PARAM_EPOCH
             except Exception as e:  # capture errors surface as RuntimeError from torch / MiaError from a launch
                 raise _CaptureFailed() from e
         opt = self.optimizer
@@ -380,11 +401,25 @@ class TrainEngine:
         g.dyn.set(float(pg["lr"]), 1.0 - b1 ** opt.step_count, 1.0 - b2 ** opt.step_count, opt.step_count == 1, seed, off)
         g.img.copy_(image, non_blocking=True)
         g.lab.copy_(label, non_blocking=True)
+        if self._graph_epoch != ops.PARAM_EPOCH and opt._pack_plan is not None:
+            # parameters changed outside the graphs (load_state_dict, a checkpoint restore, an in-place edit: they bump the epoch):
+            # the captured forward holds no pack launch -- at capture time every packed copy was current -- so rebuild them here
+            opt._pack_plan.repack()
         g.graph.replay()
+        # the replay's optimizer rewrote the parameters and its captured re-pack rewrote the plan's copies: new epoch (a packed
+        # copy made outside the plan must miss next time), plan copies marked current
+        ops.bump_param_epoch()
+        if opt._pack_plan is not None:
+            opt._pack_plan.plant()
+        self._graph_epoch = ops.PARAM_EPOCH
         opt.stepped.update(id(p) for p in opt.params if p.grad is not None)
         return g.loss.clone()
 
     def train_step(self, sampled_batch) -> torch.Tensor:
+        with _ReservedCUs(self.dp_reserve_cus):
+            return self._train_step(sampled_batch)
+
+    def _train_step(self, sampled_batch) -> torch.Tensor:
         self.model.train()
         if self.lr_scheduler:
             self.lr_scheduler.step(self.current_iter)
@@ -397,11 +432,17 @@ class TrainEngine:
                 self.current_iter += 1
                 return loss
             except _CaptureFailed as e:
-                # nothing has executed (a capture records, it does not run): drop to the eager step for good, from a clean slate
+                # no kernel has executed (a capture records, it does not run), but the HOST side of the recorded part did: packed
+                # copies were marked current for pack launches that never ran, producer -> consumer hints and gradient-slice claims
+                # point at unwritten tensors.  Invalidate all of it, then drop to the eager step for good.
                 import warnings
                 warnings.warn(f"TrainEngine: hipGraph capture of the train step failed ({e.__cause__!r}); continuing with eager steps")
                 self.graph_mode = False
                 self._graphs.clear()
+                ops.bump_param_epoch()
+                ops.clear_hints()
+                ops.amax_arena_reset()
+                self.optimizer._pack_plan = None
                 self.optimizer.zero_grad()
         self._eager_steps += 1
         output = self.model(image)

@@ -303,6 +303,7 @@ def main():
     gen_unet(ref, "res", "instance", [4, 8, 16], 32, block_type="res")
     gen_losses(ref)
     gen_poly(ref)
+    gen_transforms(ref)
     gen_selectors(ref)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden total", tot // 1024, "KiB")

@@ -1531,6 +1531,75 @@ def test_f32_split_transposed_conv_has_fp32_accuracy(case, split_everywhere):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+@pytest.mark.parametrize("c1,c2,cout", [(32, 0, 96), (64, 32, 64), (16, 0, 24)])
+def test_amax_by_products_equal_the_tensors_maxima(c1, c2, cout, norm, split_everywhere):
+    """The maxima the split-f16 convs scale by are by-products of the kernels that WRITE the operands: the forward apply pass (z), the
+    backward apply pass (dy), the ConvTranspose epilogue (its output) and the two-destination input gradient (dx2).  Each slot must
+    hold exactly the bit pattern of max |tensor| (96 and 24 channels leave idle lanes / scalar fallbacks in the streaming kernels),
+    and a full block forward + backward must launch NO standalone `mia_amax` for them."""
+    import mia_hip
+    from mia_hip import ops, NORM_BATCH, NORM_INSTANCE, CONV_T2S2
+    dev = _dev()
+    g = torch.Generator().manual_seed(c1 + cout)
+    n, h, w = 2, 20, 36
+    x1 = (torch.randn(n, h, w, c1, generator=g) * 3.0).to(dev).requires_grad_(True)
+    x2 = (torch.randn(n, h, w, c2, generator=g) * 0.02).to(dev).requires_grad_(True) if c2 else None
+    wt = torch.nn.Parameter((torch.randn(cout, c1 + c2, 3, 3, generator=g) / math.sqrt(9 * (c1 + c2))).to(dev))
+    b, gm, bt = (torch.nn.Parameter(torch.randn(cout, generator=g).to(dev)) for _ in range(3))
+    cfg = ops.NormCfg(NORM_BATCH if norm == "batch" else NORM_INSTANCE, True, running_mean=torch.zeros(cout, device=dev),
+                      running_var=torch.ones(cout, device=dev), num_batches=torch.zeros((), dtype=torch.long, device=dev))
+    seen = {}
+    raw = ops.call
+
+    def spy(name, *a):
+        if name == "mia_amax":
+            seen["amax"] = seen.get("amax", 0) + 1
+        return raw(name, *a)
+
+    def bits(t):
+        return t.detach().abs().max().view(torch.int32).item()
+
+    ops.amax_slot(x1), ops.amax_slot(wt)  # (inputs of the test itself: measured up front, outside the count)
+    if x2 is not None:
+        ops.amax_slot(x2)
+    ops.pack_cache(wt).get(wt, mia_hip.F32, True), ops.pack_cache(wt).get(wt, mia_hip.F32, False)
+    ops.call = spy
+    try:
+        z = ops.PlainBlockFn.apply(x1, x2, wt, b, gm, bt, 1, cfg)
+        assert z._mia_amax[0].item() == bits(z) and z._mia_amax[1] == z._version
+        dz = torch.randn(z.shape, generator=g).to(dev) * 1e-5
+        captured = {}
+        orig_wgrad = ops.conv_wgrad
+
+        def wgrad_spy(mode, xa, xb, dy, *a, **k):
+            captured["dy"] = dy
+            return orig_wgrad(mode, xa, xb, dy, *a, **k)
+
+        ops.conv_wgrad = wgrad_spy
+        try:
+            z.backward(dz)
+        finally:
+            ops.conv_wgrad = orig_wgrad
+        dy = captured["dy"]
+        assert dy._mia_amax[0].item() == bits(dy)
+        assert seen.get("amax", 0) == 0, seen
+    finally:
+        ops.call = raw
+    # ConvTranspose epilogue and the second destination of an input gradient
+    xt = torch.randn(n, 9, 13, 64, generator=g).to(dev)
+    wT = (torch.randn(64, 32, 2, 2, generator=g) / 8.0).to(dev)
+    wf, nf, kf = ops.PackCache().get(wT, mia_hip.F32, False)
+    up, _, _ = ops.conv_mma(CONV_T2S2, xt, None, wf, nf, kf, False, torch.randn(32, generator=g).to(dev), 32, (18, 26))
+    assert up._mia_amax[0].item() == bits(up)
+    if c2:
+        from mia_hip import CONV_G3S1
+        wb, npb, kpb = ops.pack_cache(wt).get(wt, mia_hip.F32, False)
+        d1, d2, _ = ops.conv_mma(CONV_G3S1, dy, None, wb, npb, kpb, True, None, c1 + c2, (h, w), out_split=c1)
+        assert d2._mia_amax[0].item() == bits(d2)
+
+
+@pytest.mark.gpu
 def test_f32_split_wide_dynamic_range_inside_one_tensor(split_everywhere):
     """One operand tensor whose images differ by 2^-16 in magnitude (one sample's activations / gradients dwarf another's): the
     per-tensor scale is set by the largest, the small image's elements keep >= 17 significand bits (fp16 denormal low parts; the f16

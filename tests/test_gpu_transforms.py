@@ -334,16 +334,22 @@ def test_train_engine_matches_golden_step():
         assert abs(eng.optimizer.last_norm[0].item() - float(d["train/grad_norm"])) / float(d["train/grad_norm"]) < 1e-3
         lr = float(d["train/lr"])
         assert eng.optimizer.param_groups[0]["lr"] == lr
+        pinned = total = 0
         for k, v in m.state_dict().items():
             ref, got = d["post/" + k], v.cpu().numpy()
             if ref.dtype.kind == "f":
-                np.testing.assert_allclose(got, ref, atol=2.5 * lr + 1e-6, err_msg=k)
+                # Adam's first step is +-lr: the blanket bound (2 lr: a sign flip of a rounding-noise gradient) pins nothing by itself;
+                # what pins the optimizer is the masked check -- where the reference gradient is clearly non-zero the state must agree
+                # to 5e-7 (a skipped step would be off by lr = 4e-6, a wrong sign by 2 lr) -- and it must cover most of the model
+                np.testing.assert_allclose(got, ref, atol=2.02 * lr + 1e-6, err_msg=k)
                 g = d.get("grad/" + k)
                 if g is not None:
                     msk = np.abs(g) > 1e-4
                     np.testing.assert_allclose(got[msk], ref[msk], atol=5e-7, err_msg=k)
+                    pinned += int(msk.sum()); total += msk.size
             else:
                 assert (got == ref).all(), k
+        assert pinned > 0.5 * total, (pinned, total)
         # prediction path (valid_slices core)
         pred = eng.predict(torch.from_numpy(d["x"]))
         assert pred.shape == (2, 32, 32) and pred.dtype == torch.long

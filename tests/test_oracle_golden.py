@@ -38,16 +38,20 @@ def test_unet_train_step(tag, norm, k1):
     np.testing.assert_allclose(r["logits"].numpy(), d["train/logits"], atol=1e-6)
     np.testing.assert_allclose(r["loss"].numpy(), d["train/loss"], atol=1e-6)
     np.testing.assert_allclose(r["grad_norm"].numpy(), d["train/grad_norm"], rtol=1e-5)
+    pinned = total = 0
     for k, v in d.items():
         if k.startswith("post/"):
             got = p[k[5:]].detach().numpy()
-            # Adam's first step is lr*g/(|g|+eps): where the reference gradient is rounding
-            # noise (conv bias in front of a norm layer: analytically 0) only |delta| <= lr holds.
-            np.testing.assert_allclose(got, v, atol=2.5 * lr, err_msg=k)
+            # Adam's first step is lr*g/(|g|+eps) ~ +-lr: where the reference gradient is rounding noise (conv bias in front of a norm
+            # layer: analytically 0) only |delta| <= 2 lr holds (a sign flip); that blanket bound pins nothing by itself -- the masked
+            # check below does (a skipped optimizer step would be off by lr = 4e-6 there, a wrong sign by 2 lr)
+            np.testing.assert_allclose(got, v, atol=2.02 * lr, err_msg=k)
             g = d.get("grad/" + k[5:])
             if g is not None and v.dtype.kind == "f":
                 m = np.abs(g) > 1e-5
                 np.testing.assert_allclose(got[m], v[m], atol=2e-7, err_msg=k)
+                pinned += int(m.sum()); total += m.size
+    assert pinned > 0.5 * total, (pinned, total)
 
 
 def test_unet_grads_match():
