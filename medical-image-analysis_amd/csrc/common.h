@@ -130,6 +130,18 @@ __device__ __forceinline__ float norm_bwd_dy(float g, float yv, float sc, float 
   return __builtin_fmaf(sc, g, __builtin_fmaf(ka, yv, kb));
 }
 
+// Two extra wait states behind a 12- / 16-byte vector store whose data registers the compiler may recycle at once (store-data hazard:
+// tools/check_store_hazard.py, profiles/r05_store_hazard.txt -- hipcc's own 2 wait states were not enough next to a dozen in-flight
+// loads; 2 more always were).  VALU instructions may not cross (mask 0x3AC lets SALU, MFMA, vector loads and LDS instructions through, so
+// loads and LDS reads of later iterations still overlap; vector STORES may not cross either, or the store itself would sink past the pad): put it right behind the store.
+// (store_data_fence() in FRONT of the store keeps the VALU work that precedes it in the source from being scheduled behind it.)
+__device__ __forceinline__ void store_data_fence() { __builtin_amdgcn_sched_barrier(0x3AC); }
+__device__ __forceinline__ void store_data_pad() {
+  __builtin_amdgcn_sched_barrier(0x3AC);
+  asm volatile("s_nop 1" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0x3AC);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -396,8 +396,20 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
           // 16-byte store reads its data in four lane phases AFTER issue -- lanes {12-15, 28-31, 44-47, 60-63} of ~5 % of the
           // tiles then stored the new value.  hipcc's own rule (one wait state after a >= 12-byte store) does not cover it
           // while the vector-memory path is busy; 16 wait states do (8 stores per tile: ~130 cycles of an ~8000-cycle tile).
+          // (-DCR_PAD=0 / 2 / 4 / 8 builds of this line are the measurement: tools/r5_store_hazard.sh -> profiles/r05_store_hazard.txt)
           __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // (-DCR_PAD builds of this line measured 0 / 2 / 4 / 8 wait states: tools/probe/diag_cr4.py)
+#ifndef CR_PAD
+#define CR_PAD 16
+#endif
+#if CR_PAD >= 16
+          asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#elif CR_PAD >= 8
+          asm volatile("s_nop 7" ::: "memory");
+#elif CR_PAD >= 4
+          asm volatile("s_nop 3" ::: "memory");
+#elif CR_PAD >= 2
+          asm volatile("s_nop 1" ::: "memory");
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -412,7 +424,15 @@ __global__ __launch_bounds__(256, 2) void conv64_persist_kernel(const ConvArgs a
         typedef __attribute__((address_space(1))) f32x4 gf32x4;  // global (not flat) store: see conv_mma_fast.hip
         gf32x4* dst = (gf32x4*)(a.stats + (tile * (size_t)(a.o1 + a.o2) + n_base + 16 * wave + 4 * q) * 2);
         dst[0] = f32x4{s1[0], s2[0], s1[1], s2[1]};
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         dst[1] = f32x4{s1[2], s2[2], s1[3], s2[3]};
+        // store-data hazard (tools/check_store_hazard.py): hipcc re-used these data registers for the next tile's sums at its own
+        // minimum distance, the distance that failed in the column-reduce epilogue above; two more wait states were always enough
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     STAMP(ts3);
