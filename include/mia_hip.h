@@ -139,6 +139,14 @@ int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const void* in2, 
  * launch after the optimizer step.  These maxima are the scale source of the split-f16 products (no reference counterpart: the
  * reference multiplies in fp32, blocks.py:83-90). */
 int mia_amax(const float* x, int64_t n, void* slot, int reset, void* stream);
+/* dst[i] = src[i], uint8 -> int64: label maps travel host -> device as bytes (1/8 of the int64 tensor `label.to(device)` moves,
+ * al_trainer.py:1368) and are widened here for the loss kernels; src 8-byte, dst 16-byte aligned (training/feed.py). */
+int mia_widen_u8_i64(const void* src, void* dst, int64_t n, void* stream);
+/* HOST helper of the same feed (no device work): dst[i] = (uint8) src[i] over host memory in one multi-threaded pass; returns 1 when
+ * every label lies in 0 .. 255 (dst valid), 0 when some label does not fit (ship the int64 tensor instead), < 0 on bad arguments.
+ * threads <= 0: 8. */
+int mia_host_narrow_labels(const int64_t* src, uint8_t* dst, int64_t n, int threads);
+int mia_host_copy(void* dst, const void* src, int64_t bytes, int threads); /* pageable -> pinned memcpy on `threads` (<= 0: 4) plain threads */
 int mia_amax_desc_bytes(void);
 int mia_amax_batch(const void* descs_dev, int count, void* slots, void* stream);
 

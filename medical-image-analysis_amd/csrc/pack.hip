@@ -490,3 +490,77 @@ extern "C" int mia_amax_batch(const void* descs_dev, int count, void* slots, voi
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
+
+// ---- labels shipped over PCIe as bytes and widened on the device (training/feed.py): dst[i] = src[i], uint8 -> int64.  A thread
+// turns two labels (one 16-bit load) into one 16-byte store, so a wave reads 128 contiguous bytes and writes 1 KB contiguous.
+__global__ __launch_bounds__(256) void widen_u8_i64_kernel(const uint8_t* __restrict__ src, long long* __restrict__ dst, int64_t n) {
+  const int64_t n2 = n / 2;
+  const unsigned short* s2 = reinterpret_cast<const unsigned short*>(src);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned w = s2[i];
+    const u32x4 d = {w & 0xFFu, 0u, w >> 8, 0u};
+    store_data_fence();
+    *reinterpret_cast<u32x4*>(dst + 2 * i) = d;
+    store_data_pad();  // tools/check_store_hazard.py
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = (long long)src[n - 1];
+}
+extern "C" int mia_widen_u8_i64(const void* src, void* dst, int64_t n, void* stream) {
+  MIA_CHECK_ARG(src && dst && n > 0 && (reinterpret_cast<uintptr_t>(src) & 7) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0, "mia_widen_u8_i64: bad arguments");
+  const int64_t want = (n / 2 + 255) / 256 / 4;  // ~4 stores per thread
+  const int blocks = (int)(want < 1 ? 1 : (want > 16384 ? 16384 : want));
+  hipLaunchKernelGGL(widen_u8_i64_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint8_t*>(src),
+                     static_cast<long long*>(dst), n);
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}
+
+// ---- host side of the label feed: int64 -> uint8 in ONE pass over host memory, with the range check folded in (returns 1 when every
+// label lies in 0 .. 255 and dst is valid, 0 otherwise -- the caller then ships the int64 tensor as it is).  Plain threads: the torch
+// CPU ops this replaces (aminmax + a converting copy_) cost 5 .. 50 ms per 77 MB batch on the GPU box's host, depending on what the
+// OpenMP pool had just been doing (tools/probe/feed_cfg4.py).
+#include <atomic>
+#include <thread>
+#include <vector>
+extern "C" int mia_host_narrow_labels(const int64_t* src, uint8_t* dst, int64_t n, int threads) {
+  if (!src || !dst || n <= 0) { mia_set_error("mia_host_narrow_labels: bad arguments"); return MIA_EARG; }
+  int nt = threads > 0 ? threads : 8;
+  const unsigned hc = std::thread::hardware_concurrency();
+  if (hc > 0 && (unsigned)nt > hc) nt = (int)hc;
+  if (n < (int64_t)1 << 16) nt = 1;
+  std::atomic<int> ok{1};
+  auto work = [&](int64_t b, int64_t e) {
+    uint64_t bad = 0;
+    for (int64_t i = b; i < e; ++i) { const uint64_t v = (uint64_t)src[i]; bad |= v; dst[i] = (uint8_t)v; }
+    if (bad >> 8) ok.store(0, std::memory_order_relaxed);
+  };
+  if (nt == 1) { work(0, n); return ok.load(); }
+  std::vector<std::thread> th;
+  const int64_t per = ((n + nt - 1) / nt + 63) & ~(int64_t)63;
+  for (int t = 0; t < nt; ++t) {
+    const int64_t b = t * per, e = b + per < n ? b + per : n;
+    if (b < e) th.emplace_back(work, b, e);
+  }
+  for (auto& t : th) t.join();
+  return ok.load();
+}
+
+// ---- host side of the image feed: pageable -> pinned copy on a few plain threads.  (torch's CPU copy_ runs on its OpenMP pool, which
+// a GPU box sizes by the MACHINE's core count -- 128 threads on a 16-core share -- and a 38 MB copy then took 0.1 .. 35 ms depending on
+// what the pool had just been doing; tools/probe/feed_cfg4.py.)
+extern "C" int mia_host_copy(void* dst, const void* src, int64_t bytes, int threads) {
+  if (!src || !dst || bytes <= 0) { mia_set_error("mia_host_copy: bad arguments"); return MIA_EARG; }
+  int nt = threads > 0 ? threads : 4;
+  const unsigned hc = std::thread::hardware_concurrency();
+  if (hc > 0 && (unsigned)nt > hc) nt = (int)hc;
+  if (bytes < ((int64_t)1 << 20)) nt = 1;
+  if (nt == 1) { memcpy(dst, src, (size_t)bytes); return MIA_OK; }
+  std::vector<std::thread> th;
+  const int64_t per = ((bytes + nt - 1) / nt + 4095) & ~(int64_t)4095;
+  for (int t = 0; t < nt; ++t) {
+    const int64_t b = t * per, e = b + per < bytes ? b + per : bytes;
+    if (b < e) th.emplace_back([=]() { memcpy(static_cast<char*>(dst) + b, static_cast<const char*>(src) + b, (size_t)(e - b)); });
+  }
+  for (auto& t : th) t.join();
+  return MIA_OK;
+}

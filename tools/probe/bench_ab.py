@@ -22,7 +22,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "medical-image-analysis_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -242,7 +242,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"])
@@ -401,40 +401,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Warm-up steps are fed the way the reference's loop feeds every step -- the batch starts in HOST memory and goes through
-    # image.to(device) / label.to(device) (al_trainer.py:1366-1368; here training.feed.HostFeed) -- the timed steps then run on the batch
-    # resident in HBM.  Round 5 found that this matters beyond fidelity: once a host -> device transfer has overlapped
-    # compute in a process, the board runs every matrix-bound kernel at a ~13 % higher shader clock for the rest of the process
-    # (same cycle counts, rocprofv3 --pmc; cfg3 step 42.4 -> 37.7 ms; profiles/r05_ab_boost_state.txt).  Training never runs outside
-    # that state (every step of al_train is host-fed); a benchmark whose batch never left HBM would.  MIA_BENCH_WARM=resident keeps the
-    # old behaviour for the A/B.
-    warm_host = os.environ.get("MIA_BENCH_WARM", "host") == "host"
-    host_warm_batch = {"image": img.clone(), "label": lab.clone()} if (warm_host and aug is None) else None
-    warm_feed = None
-    if warm_host and aug is not None:
-        from training.feed import HostFeed
-        warm_feed, warm_nat = HostFeed(dev), (aug_in[0].cpu(), aug_in[1].cpu())
-
-    def warm_step(i):
-        if host_warm_batch is not None:
-            return eng.train_step(host_warm_batch)
-        if warm_feed is not None:  # native-resolution batch from host memory -> on-GPU pipeline -> step (same rule as TrainEngine: plain .to() first)
-            staged = warm_feed.stage(*warm_nat) if i >= TrainEngine.FEED_AFTER else (warm_nat[0].to(dev), warm_nat[1].to(dev))
-            return eng.train_step(aug(*staged))
-        return one_step()
-
-    n_warm = max(args.warmup, TrainEngine.GRAPH_WARMUP + 1) if args.graph else args.warmup  # graph mode: past the capture
-    for i in range(n_warm):  # (TrainEngine sends the first FEED_AFTER = 3 host batches through plain .to(), the later ones through HostFeed)
-        loss = warm_step(i)
+    for _ in range(max(args.warmup, TrainEngine.GRAPH_WARMUP + 1) if args.graph else args.warmup):  # graph mode: past the capture
+        loss = one_step()
     sync()
     probes = not args.graph and os.environ.get("MIA_BENCH_PROBES", "1") != "0"  # (0: A/B of what the instrumentation itself costs)
     probe.enabled = probes
     stream_on[0] = probes
     t0 = time.perf_counter()
+    evs, hts = [], []
     for _ in range(args.steps):
+        e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
+        th = time.perf_counter()
         loss = one_step()
+        hts.append(1e3 * (time.perf_counter() - th))
+    e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
     sync()
     elapsed = time.perf_counter() - t0
+    print("[ab] first loop: host issue ms/step", " ".join("%.1f" % h for h in hts), "| GPU span ms/step", " ".join("%.1f" % evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)), file=sys.stderr)
     if not args.graph:  # two extra steps, outside the timed region, with every conv / stream launch bracketed (roofline sub-records)
         sweep_on[0] = True
         sweep_from[0] = len(probe.pairs)
@@ -481,6 +464,17 @@ def main():
             loss3 = host_step()
         sync()
         elapsed_host = time.perf_counter() - t2
+        if os.environ.get("MIA_BENCH_AB"):
+            sync(); t3 = time.perf_counter()
+            for _ in range(args.steps):
+                one_step()
+            sync()
+            print("[ab] resident loop again: %.3f ms/step" % (1e3 * (time.perf_counter() - t3) / args.steps), file=sys.stderr)
+            sync(); t3 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.train_step({"image": batch_d["image"].clone(), "label": batch_d["label"].clone()})
+            sync()
+            print("[ab] resident, cloned inputs: %.3f ms/step" % (1e3 * (time.perf_counter() - t3) / args.steps), file=sys.stderr)
         host_bytes = (eng._feed.bytes_h2d if aug is None else hf.bytes_h2d)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -613,8 +607,6 @@ def main():
                                       f"dropout {drop}, Dice+CE, Adam(wd 5e-4), clip 10 ({args.config})",
                           "global_batch": world * batch, "parallelism": f"dp{world}"},
                "final_loss": round(loss_v, 6), "roofline": roof}
-        out["config"]["warmup_feed"] = ("host memory -> HostFeed (pinned ring, side-stream H2D), like every step of the reference's loop; the timed "
-                                        "steps run on the HBM-resident batch") if warm_host else "HBM-resident batch (MIA_BENCH_WARM=resident)"
         if args.graph:
             out["config"]["graph"] = "train step replayed from one captured hipGraph"
         if dt == "f32":  # fp32 tensors either way; 1 = conv / weight-gradient products from split-f16 operands (DESIGN: fp32 on the f16 matrix cores)
