@@ -306,7 +306,7 @@ def main():
                                                                  batch=False, squared=False),
                             ce_loss=torch.nn.CrossEntropyLoss, ce_kwargs={})
     eng = TrainEngine(model, loss_fn, "adam", {"weight_decay": 5e-4}, start_lr=1e-3, num_iters=4000, lr_warmup_iter=250,
-                      graph=bool(args.graph))
+                      graph=True if args.graph else None)  # None: the engine's auto mode (replay when its first steps are host-bound)
     img, lab = synth_batch(batch, size, 1337 + rank)
     batch_d = {"image": img.to(dev), "label": lab.to(dev)}  # resident in HBM before timing
     aug = aug_in = None
@@ -426,8 +426,14 @@ def main():
     n_warm = max(args.warmup, TrainEngine.GRAPH_WARMUP + 1) if args.graph else args.warmup  # graph mode: past the capture
     for i in range(n_warm):  # (TrainEngine sends the first FEED_AFTER = 3 host batches through plain .to(), the later ones through HostFeed)
         loss = warm_step(i)
+    # the engine's auto graph mode decides (and captures) within its first steps: let it settle before the timed region
+    extra = 0
+    while extra < 8 and ((eng.graph_mode and not eng._graphs) or (eng.graph_auto and not eng.graph_mode)):
+        loss = warm_step(n_warm + extra)
+        extra += 1
     sync()
-    probes = not args.graph and os.environ.get("MIA_BENCH_PROBES", "1") != "0"  # (0: A/B of what the instrumentation itself costs)
+    replaying = bool(eng.graph_mode)  # --graph, or the engine's auto mode found the warm-up steps host-bound
+    probes = not replaying and os.environ.get("MIA_BENCH_PROBES", "1") != "0"  # (0: A/B of what the instrumentation itself costs)
     probe.enabled = probes
     stream_on[0] = probes
     t0 = time.perf_counter()
@@ -435,7 +441,7 @@ def main():
         loss = one_step()
     sync()
     elapsed = time.perf_counter() - t0
-    if not args.graph:  # two extra steps, outside the timed region, with every conv / stream launch bracketed (roofline sub-records)
+    if not replaying:  # two extra steps, outside the timed region, with every conv / stream launch bracketed (roofline sub-records)
         sweep_on[0] = True
         sweep_from[0] = len(probe.pairs)
         for v in stream_log.values():
@@ -461,7 +467,7 @@ def main():
     # output, al_trainer.py:1366-1368): pageable CPU tensors in, staged by training.feed.HostFeed (pinned ring, side-stream H2D, labels
     # as bytes), everything inside the timed region.  Reported beside `value`, never as `value` (inputs resident in HBM).
     elapsed_host = host_bytes = None
-    if world == 1 and not args.graph:
+    if world == 1:
         if aug is None:
             host_batch = {"image": img.clone(), "label": lab.clone()}
             host_step = lambda: eng.train_step(host_batch)
@@ -615,8 +621,9 @@ def main():
                "final_loss": round(loss_v, 6), "roofline": roof}
         out["config"]["warmup_feed"] = ("host memory -> HostFeed (pinned ring, side-stream H2D), like every step of the reference's loop; the timed "
                                         "steps run on the HBM-resident batch") if warm_host else "HBM-resident batch (MIA_BENCH_WARM=resident)"
-        if args.graph:
-            out["config"]["graph"] = "train step replayed from one captured hipGraph"
+        if replaying:
+            out["config"]["graph"] = ("train step replayed from one captured hipGraph" + ("" if args.graph else " (TrainEngine auto mode: the warm-up steps were host-bound)")
+                                      + "; per-launch roofline probes cannot see into a replay")
         if dt == "f32":  # fp32 tensors either way; 1 = conv / weight-gradient products from split-f16 operands (DESIGN: fp32 on the f16 matrix cores)
             out["config"]["f32_split"] = int(mia_hip.get_option("f32_split"))
             if out["config"]["f32_split"] and roof is not None:

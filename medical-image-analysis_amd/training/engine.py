@@ -301,7 +301,11 @@ class TrainEngine:
         (`torch.cuda.CUDAGraph`) after `GRAPH_WARMUP` eager steps -- for small models whose step is launch-bound (cfg1: ~117
         launches for 1.1 ms of kernels).  Same kernels, same order, same arithmetic as the eager step: the values that change per
         iteration (poly LR, Adam bias corrections, Dropout2d Philox offsets) are read from device memory (`ops.StepDyn`).
-        Single-rank only (the RCCL reducer is not captured); one graph per input shape; None = env MIA_ENGINE_GRAPH (default 0).
+        Single-rank only (the RCCL reducer is not captured); one graph per input shape.  None = env MIA_ENGINE_GRAPH if set, else AUTO
+        (round 5): a single-rank engine on a HIP device switches to replay by itself when its first eager steps are HOST-bound -- the
+        host needed at least 0.6 of the time the device spent between the step's first and last launch to issue them, in at least two
+        steps (HIP events around the eager step, read back without blocking) -- and stays eager otherwise (cfg2 / cfg3 / cfg5 are device-bound; cfg1 and al_train-sized models are not: 3.4-4.1 -> 1.06 ms per step).
+        In auto mode a third distinct input shape, or a failed capture, returns the engine to eager steps for good.
         dp_reserve_cus: CUs the persistent conv / weight-gradient kernels leave free for RCCL's ring kernels (library option
         `reserve_cus`, include/mia_hip.h).  None (default) = DP_RESERVE_CUS (8: one CU per XCD) when the group has more than
         one rank, else untouched; 0 = never reserve.  Why: the persistent kernels take one 512-thread workgroup per CU on a
@@ -342,11 +346,18 @@ class TrainEngine:
         self.reducer = GradBucketReducer(self.optimizer, process_group, force=force_reducer)
         self.current_iter = 0
         self._one = None
+        can_graph = not (self.reducer.world > 1 or self.reducer.force or not next(model.parameters()).is_cuda)
+        self.graph_auto = False
         if graph is None:
-            graph = os.environ.get("MIA_ENGINE_GRAPH", "0") != "0"
-        if graph and (self.reducer.world > 1 or self.reducer.force or not next(model.parameters()).is_cuda):
+            env = os.environ.get("MIA_ENGINE_GRAPH")
+            if env is None or env == "auto":
+                graph, self.graph_auto = False, can_graph
+            else:
+                graph = env != "0"
+        if graph and not can_graph:
             raise ValueError("TrainEngine(graph=True) captures a single-rank step on a HIP device (the RCCL reducer is not captured)")
         self.graph_mode = bool(graph)
+        self._auto_votes, self._auto_seen, self._auto_pending = 0, 0, []  # auto mode: host-bound steps, judged steps, (start, end, host ms) not yet read
         self._graphs: Dict[tuple, "_CapturedStep"] = {}
         self._eager_steps = 0
         self._graph_epoch = None  # ops.PARAM_EPOCH as the last capture / replay left it
@@ -439,6 +450,9 @@ class TrainEngine:
         else:
             image = image.to(dev, dtype=torch.float32, non_blocking=True)
             label = label.to(dev, dtype=torch.long, non_blocking=True)
+        if self.graph_mode and self.graph_auto and len(self._graphs) >= 2 and (tuple(image.shape), tuple(label.shape)) not in self._graphs:
+            self.graph_mode = self.graph_auto = False  # auto mode: input shapes keep changing -- a capture per shape would cost more than it saves
+            self._graphs.clear()
         if self.graph_mode and self._eager_steps >= self.GRAPH_WARMUP:
             try:
                 loss = self._train_step_graph(image.contiguous(), label.contiguous())
@@ -450,7 +464,7 @@ class TrainEngine:
                 # point at unwritten tensors.  Invalidate all of it, then drop to the eager step for good.
                 import warnings
                 warnings.warn(f"TrainEngine: hipGraph capture of the train step failed ({e.__cause__!r}); continuing with eager steps")
-                self.graph_mode = False
+                self.graph_mode = self.graph_auto = False
                 self._graphs.clear()
                 ops.bump_param_epoch()
                 ops.clear_hints()
@@ -458,6 +472,11 @@ class TrainEngine:
                 self.optimizer._pack_plan = None
                 self.optimizer.zero_grad()
         self._eager_steps += 1
+        watch = self.graph_auto and not self.graph_mode and self._eager_steps >= 2
+        if watch:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            t_host = time.perf_counter()
         output = self.model(image)
         loss = self.loss_fn(output, label)
         self.optimizer.zero_grad()
@@ -468,7 +487,35 @@ class TrainEngine:
         self.reducer.finish()
         self.optimizer.step(max_grad_norm=self.grad_norm, grad_scale=self.reducer.grad_scale)
         self.current_iter += 1
+        if watch:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            self._auto_pending.append((ev0, ev1, 1e3 * (time.perf_counter() - t_host)))
+        if self.graph_auto and not self.graph_mode:
+            self._auto_decide(loss)
         return loss.detach()
+
+    AUTO_GIVE_UP = 8  # eager steps after which auto mode stops looking
+
+    def _auto_decide(self, loss: torch.Tensor) -> None:
+        """Auto graph mode: is this engine host-bound?  No synchronisation: every watched eager step left (start event, end event,
+        host milliseconds spent issuing it); records whose end event has completed are read back.  Device-bound: the device reaches the
+        start event late and works through the step's kernels -- its span is the kernel time, many times the host's issue time.
+        Host-bound: the device executes each launch as it arrives -- its span IS the host's issue time."""
+        if loss.dim() != 0 or not loss.is_cuda:
+            self.graph_auto = False
+            return
+        while self._auto_pending and self._auto_pending[0][1].query():
+            ev0, ev1, host_ms = self._auto_pending.pop(0)
+            self._auto_seen += 1
+            if host_ms >= 0.6 * ev0.elapsed_time(ev1):
+                self._auto_votes += 1
+        if self._eager_steps >= self.GRAPH_WARMUP and self._auto_votes >= 2:
+            self.graph_mode = True
+            self._auto_pending = []
+        elif self._auto_seen >= 3 and self._auto_votes == 0 or self._eager_steps >= self.AUTO_GIVE_UP:
+            self.graph_auto = False
+            self._auto_pending = []
 
     def loss_value(self, loss: torch.Tensor) -> float:
         """`loss.item()` for logging (al_trainer.py:1381) -- the one host sync of a logged step -- plus the label-range check
