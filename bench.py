@@ -225,17 +225,20 @@ def parity_gate_trained(dev, channels, dt, steps=60, size=128, nimg=16, batch=8,
 
 
 def pmc_traffic(config, batch, dt):
-    """Measured HBM bytes per launch of every kernel of the canonical block, from the committed rocprofv3 PMC passes
-    (profiles/r04_pmc_canonical_block.json, written by tools/r4_pmc_block.sh + tools/r4_pmc_block.py: FETCH_SIZE and WRITE_SIZE in
-    separate --pmc passes; bytes = (2 x FETCH_SIZE -- gfx950 half-count correction -- + WRITE_SIZE) x 1024).  {kernel: bytes} or None."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_canonical_block.json")
+    """HBM bytes per launch of the canonical block's kernels as measured with the PMC counters
+    (profiles/r05_pmc_canonical_block_<cfg>.json, written by tools/r5_pmc_block.sh + tools/r5_pmc_block.py: FETCH_SIZE and WRITE_SIZE in
+    separate --pmc passes; bytes = (2 x FETCH_SIZE -- gfx950 half-count correction -- + WRITE_SIZE) x 1024).  {kernel role: bytes} or None."""
+    path = os.path.join(ROOT, "profiles", f"r05_pmc_canonical_block_{config}.json")
     try:
         rec = json.load(open(path))
     except Exception:
         return None
     if rec.get("config") != config or rec.get("batch") != batch or rec.get("dtype") != dt:
         return None
-    return {k: v["hbm_bytes"] for k, v in rec["kernels"].items() if "hbm_bytes" in v}
+    out = {k: v["hbm_bytes"] for k, v in rec["kernels"].items() if "hbm_bytes" in v}
+    if "conv" in out:
+        out["conv_or_dgrad"] = out["conv"]
+    return out
 
 
 def main():
