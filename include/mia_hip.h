@@ -77,7 +77,6 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
  *   conv64_dma (MIA_CONV64_DMA, 1) the 512-thread LDS-DMA 64-channel kernel: 1 = the 64 -> (64 | 64) two-destination input
  *                                  gradient in one pass (measured 7 % faster than two conv64 passes), 2 = also plain
  *                                  64 -> 64 launches (measured 6-11 % slower than conv64_persist_kernel), 0 = never
- *   conv64_blocks (MIA_CONV64_BLOCKS, 0 = 512)   its workgroup count (diagnostics)
  *   conv_s2_wide (MIA_CONV_S2_WIDE, 1)   stride-2 3x3 bf16 forward with 128-multiples of output channels on 512-thread
  *                                  workgroups / 16-row tiles: 1 = from 128 input channels on, 2 = always, 0 = never
  *   conv_pw (MIA_CONV_PW, 1)       ConvTranspose 2x2 / stride 2 forward and input gradient (bf16) as one pointwise GEMM on the
@@ -85,21 +84,12 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
  *   conv_pw_s2 (MIA_CONV_PW_S2, 1) stride-2 3x3 bf16 forward as a tap-gathered GEMM on the same ring (needs conv_pw; 1: up to 256
  *                                  input channels, 2: always, 0: tile kernels -- default: -0.16 ms per step in isolation, none inside the step)
  *   conv_xcd / wgrad_xcd (MIA_CONV_XCD / MIA_WGRAD_XCD, 1)   blocks sharing an input tile run on one XCD (0: plain grid order)
- *   conv_mt8 (MIA_CONV_MT8, 0)     32-row tiles of the tile kernel (experiment)
  *   wgrad_bt (MIA_WGRAD_BT, 1)     bf16 3x3 stride-1 weight gradients with >= 128 output channels on the 512-thread 128 x 64 block kernel
  *   wgrad_t2 (MIA_WGRAD_T2, 1)     ConvTranspose 2x2 weight gradient (bf16, >= 128 coarse channels) on the 512-thread three-stage ring
- *   wgrad_dma (MIA_WGRAD_DMA, 1)   bf16 3x3 stride-1 weight gradients on the LDS-DMA ring kernel; with 0, wgrad_w8
- *                                  (MIA_WGRAD_W8, 1) picks the register-staged two-workgroups-per-CU kernel (wgrad_tab: its
- *                                  LDS staging table) and 0 the one-workgroup-per-CU kernel
+ *   wgrad_dma (MIA_WGRAD_DMA, 1)   bf16 3x3 stride-1 weight gradients on the LDS-DMA ring kernel; 0: the register-staged
+ *                                  two-workgroups-per-CU kernel
  *   stream_blocks (MIA_STREAM_BLOCKS, 32768)   target block count of the norm / activation streaming passes
  *   stem_mfma (MIA_STEM_MFMA, 1)   matrix-core stem kernel for fp32 images
- *   conv_t3_wide (MIA_CONV_T3_WIDE, 0)   input gradient of the stride-2 3x3 conv (bf16, output channels % 128 == 0) on 512-thread
- *                                  workgroups with 128-channel blocks (the conv_s2_wide shape); bit-identical results
- *   wgrad_narrow (MIA_WGRAD_NARROW, 0)   3x3 stride-1 bf16 weight gradient with channel counts that are not multiples of 64: blocks
- *                                  with <= 32 valid channels skip their empty 16-channel tiles and re-deal the waves (same sums)
- *   conv_pw_t3 (MIA_CONV_PW_T3, 0)    input gradient of the stride-2 3x3 conv (bf16) as exact-tap GEMMs per output-parity class on the
- *                                  conv_pw ring (also the accumulating form of mia_conv_mma_acc); fp32 summation order differs
- *                                  from the tile kernel's; slower than the tile kernel on the benchmarked shapes: off
  *   f32_split (MIA_F32_SPLIT, 1)      fp32 convs / weight gradients of the branch-free tile kernels on the f16 matrix cores: every
  *                                  operand element, scaled by a per-tensor power of two taken from the tensor's max |x| (the amax_*
  *                                  arguments below), enters as h + l (two fp16: 22-23 significand bits), four exact products, fp32
@@ -112,6 +102,9 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
  *                                  (different split-K count: deterministic, not bit-identical across settings).  Set by
  *                                  the data-parallel trainer (training/engine.py) so that RCCL's ring kernels find CUs
  *                                  while a persistent kernel runs (all-reduce overlapped with backward)
+ * (16 options.  The measured-and-rejected experiments of rounds 3-4 -- Winograd conv64, conv_pw T3S2, conv_t3_wide, wgrad_narrow, conv_mt8, the
+ * column-reduce epilogue -- are no longer in the shipping library: records under profiles/, entry points of the ones a probe still builds in
+ * include/mia_hip_experiments.h, compiled with -DMIA_EXPERIMENTS.)
  * Do not change wgrad_* between mia_wgrad_geometry and the mia_conv_wgrad it sizes.  The Python loader applies
  * MIA_OPTIONS="name=value,..." through mia_set_option.  Unknown name: MIA_EARG. */
 int mia_set_option(const char* name, int value);
@@ -180,10 +173,6 @@ int mia_conv_mma_acc(int mode, int dtype, const void* in1, int c1, const void* w
                      void* out_inout, int nout, int n, int hin, int win, int hout, int wout, const void* amax_in, const void* amax_w,
                      void* stream);
 
-int mia_conv_cr_supported(int mode, int dtype, int c1, int nout, int hout, int wout);
-int mia_conv_mma_cr(int mode, int dtype, const void* in1, int c1, const void* wpack, int npad, int kpad, int flip_taps,
-                    void* out, int nout, const void* y_prod, const float* scale, const float* shift, const float* xa,
-                    const float* xb, float slope, float* partials, int n, int hin, int win, int hout, int wout, void* stream);
 
 /* Stem: Conv2d(1, C0, 3, padding=1) (first encoder block, unet.py:54-66 with input_channels=1): HBM-streaming VALU
  * kernels (9 FMAs per output; MFMA would idle 31/32 of its K).  x is the [N][H][W] image in x_dtype (fp32 or bf16),
@@ -261,10 +250,6 @@ int mia_norm_bwd_sums(const void* dz, const void* dz2, const void* y, int dtype,
                       float* dbeta, float* dbias, int accumulate, void* stream);
 /* mia_norm_act_bwd with the reduction already done: partials [n][parts][c][2] come from mia_conv_mma_cr.  Sums + finalize; the
  * apply pass (dy = ...) runs only when dy != NULL (NULL: the consumer forms dy on load, mia_stem_wgrad_fused). */
-int mia_norm_act_bwd_pre(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
-                         const float* xa, const float* xb, const float* ysum, int n, int64_t hw, int c, int mode,
-                         int fixed_stats, float slope, int parts, const float* partials, float* c1, float* c2,
-                         float* dgamma, float* dbeta, float* dbias, int accumulate, void* amax_out, void* stream);
 
 /* Synchronised batch norm for data-parallel runs (build-side addition; SURVEY.md 8e: "a second, small collective"):
  * the caller moves 3*C floats (forward, all-gather) and 2*C floats (backward, all-reduce sum) per layer over RCCL and

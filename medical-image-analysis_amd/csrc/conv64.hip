@@ -485,10 +485,14 @@ int conv64_launch(const ConvArgs& a, int blocks_override, int reserve, hipStream
     hipLaunchKernelGGL((conv64_persist_kernel<true, false>), dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, 0);
     return MIA_OK;
   }
+#ifdef MIA_EXPERIMENTS  // the column-reduce epilogue (round 4: correct, +-0 in the step; the store-data hazard was found in it -- probe builds keep it)
   if (a.cr_y != nullptr) {
     hipLaunchKernelGGL((conv64_persist_kernel<false, true>), dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, 0);
     return MIA_OK;
   }
+#else
+  if (a.cr_y != nullptr) { mia_set_error("column-reduce epilogue: experiment build only (-DMIA_EXPERIMENTS)"); return MIA_EUNSUPPORTED; }
+#endif
   hipLaunchKernelGGL((conv64_persist_kernel<false, false>), dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, 0);
   if (a.o2 == C)  // second destination (e.g. the up-sampled half of a decoder block's input gradient): same input, next 64 filters
     hipLaunchKernelGGL((conv64_persist_kernel<false, false>), dim3(nblk), dim3(256), 0, st, a, total, tiles_per_img, run, C);

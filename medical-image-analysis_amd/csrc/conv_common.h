@@ -86,9 +86,6 @@ int conv_mma_fast_launch(int mode, int dtype, const ConvArgs& a, int mt, int nt,
 // launch of the benchmark and its input gradient); false = shape outside its contract.
 bool conv64_eligible(int mode, int dtype, const ConvArgs& a);
 int conv64_launch(const ConvArgs& a, int blocks_override, int reserve_cus, hipStream_t st);
-// conv64w.hip: the same conv as Winograd F(2x2, 3x3) (experiment, option conv64_wino)
-bool conv64_wino_eligible(int mode, int dtype, const ConvArgs& a);
-int conv64_wino_launch(const ConvArgs& a, int reserve_cus, hipStream_t st);
 
 // conv_bt.hip: 512-thread "big tile" LDS-DMA kernel for the stride-1 3x3 bf16 convs with >= 64-channel blocks (levels >= 1
 // of the network, the decoder's two-source convs, cfg5's 96-multiples); false = shape outside its contract.

@@ -295,7 +295,6 @@ static void conv_tiles(const MiaOptions& opt, int mode, int hout, int wout, int*
   const bool tmode = (mode == MODE_T3S2 || mode == MODE_T2S2);
   const int hd = tmode ? (hout + 1) / 2 : hout, wd = tmode ? (wout + 1) / 2 : wout;
   int mt = (mode == MODE_G3S2 || mode == MODE_G2S2) ? 2 : (hd > 8 ? 4 : 2);
-  if (opt.conv_mt8 && mode == MODE_G3S1 && hd >= 32) mt = 8;
   const int th = 4 * mt;
   if (tiles_y) *tiles_y = ceil_div(hd, th);
   if (tiles_x) *tiles_x = ceil_div(wd, 16);
@@ -373,55 +372,39 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
     a.tiles_y = ceil_div(hout, 16);
     a.nblk_n = nout / 128;
   }
-  // the same 512-thread shape for the strided conv's INPUT GRADIENT (transposed mode, four output-parity classes per tile):
-  // a 128-channel block shares one staged dy tile (option conv_t3_wide; measured per level in tools/s2_levels.py)
-  bool t3_wide = false;
-  if (opt.conv_t3_wide && !acc_out && fast && mode == MODE_T3S2 && dtype == MIA_BF16 && nout % 128 == 0 && a.o2 == 0 && mt == 4) {
-    t3_wide = true;
-    a.nblk_n = nout / 128;
-  }
-  if (mt == 8 && !(fast && dtype == MIA_BF16 && nt == 4 && mode == MODE_G3S1)) {
-    mia_set_error("mia_conv_mma: MIA_CONV_MT8 tiles need the bf16 fast path with >= 64 output channels");
-    return MIA_EUNSUPPORTED;
-  }
   // conv64_dma: 1 = the one-pass two-destination input gradient only (measured faster there), 2 = every 64 -> 64 launch
-  const bool pw_t3 = opt.conv_pw && opt.conv_pw_t3 && mode == MODE_T3S2 && conv_pw_eligible(mode, dtype, a);  // exact-tap GEMMs on the ring
-  if (acc_out) {  // out += result: the kernels whose epilogue reads the previous values
-    if (pw_t3) rc = conv_pw_launch(mode, a, opt.reserve_cus, st);
-    else {
-      if (!fast || t3_wide) { mia_set_error("mia_conv_mma_acc: shape outside the accumulating kernel's contract"); return MIA_EUNSUPPORTED; }
-      rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
-    }
+  if (acc_out) {  // out += result: the tile kernel's epilogue reads the previous values
+    if (!fast) { mia_set_error("mia_conv_mma_acc: shape outside the accumulating kernel's contract"); return MIA_EUNSUPPORTED; }
+    rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
   }
-  else if (pw_t3) rc = conv_pw_launch(mode, a, opt.reserve_cus, st);
+#ifdef MIA_EXPERIMENTS
   else if (cr_y != nullptr) {  // column-reduce epilogue: the 64-channel register kernel (its epilogue overlaps the co-resident workgroup)
     if (!(mt == 4 && conv64_eligible(mode, dtype, a))) {
       mia_set_error("mia_conv_mma_cr: shape outside the column-reduce kernel's contract (ask mia_conv_cr_supported first)");
       return MIA_EUNSUPPORTED;
     }
-    rc = conv64_launch(a, opt.conv64_blocks, opt.reserve_cus, st);
+    rc = conv64_launch(a, 0, opt.reserve_cus, st);
   }
-  else if (nl_scale != nullptr && opt.conv64_wino && mt == 4 && conv64_wino_eligible(mode, dtype, a)) rc = conv64_wino_launch(a, opt.reserve_cus, st);
+#endif
   else if (nl_scale != nullptr) {  // normalise-on-load: the register-staged 64-channel kernel is the one consumer that transforms
     if (!(mt == 4 && conv64_eligible(mode, dtype, a))) {
       mia_set_error("mia_conv_mma_nl: shape outside the normalise-on-load kernel's contract (ask mia_conv_nl_supported first)");
       return MIA_EUNSUPPORTED;
     }
-    rc = conv64_launch(a, opt.conv64_blocks, opt.reserve_cus, st);
+    rc = conv64_launch(a, 0, opt.reserve_cus, st);
   }
-  else if (opt.conv64_wino && mt == 4 && conv64_wino_eligible(mode, dtype, a)) rc = conv64_wino_launch(a, opt.reserve_cus, st);
   else if (opt.conv64 && opt.conv64_dma && (opt.conv64_dma >= 2 || a.o2 != 0) && mt == 4 && conv64_dma_eligible(mode, dtype, a)) rc = conv64_dma_launch(a, opt.reserve_cus, st);
-  else if (opt.conv64 && mt == 4 && conv64_eligible(mode, dtype, a)) rc = conv64_launch(a, opt.conv64_blocks, opt.reserve_cus, st);
+  else if (opt.conv64 && mt == 4 && conv64_eligible(mode, dtype, a)) rc = conv64_launch(a, 0, opt.reserve_cus, st);
   else if (opt.conv_bt && mt == 4 && conv_bt_eligible(mode, dtype, a)) rc = conv_bt_launch(a, opt.conv_bt_order, opt.reserve_cus, st);
   // (strided 3x3 forward as a tap-gathered GEMM: measured 0.62 -> 0.51, 0.44 -> 0.40, 0.37 -> 0.35 ms at 64 / 128 / 256 input channels,
   // 0.30 -> 0.30 at 512 in isolation (tools/s2_levels.py); step-time A/Bs could not resolve it (+-0.1 ms box noise), the per-kernel sums of
   // two interleaved rocprofv3 pairs inside the cfg3 step can: 36.90 / 36.91 -> 36.77 / 36.77 ms of kernels, so it is on;
   // conv_pw_s2 = 1 stops at 256 input channels, = 2 always)
-  else if (opt.conv_pw && mode != MODE_T3S2 && (mode != MODE_G3S2 || opt.conv_pw_s2 >= 2 || (opt.conv_pw_s2 == 1 && c1 <= 256)) && conv_pw_eligible(mode, dtype, a))
+  else if (opt.conv_pw && (mode != MODE_G3S2 || opt.conv_pw_s2 >= 2 || (opt.conv_pw_s2 == 1 && c1 <= 256)) && conv_pw_eligible(mode, dtype, a))
     rc = conv_pw_launch(mode, a, opt.reserve_cus, st);
   else if (fast) {
     if (dtype == MIA_F32) { a.amax_out1 = static_cast<unsigned*>(amax_out1); a.amax_out2 = static_cast<unsigned*>(amax_out2); amax_out1 = amax_out2 = nullptr; }
-    rc = conv_mma_fast_launch(mode, dtype, a, t3_wide ? 16 : mt, nt, grid_y, st);
+    rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
   }
   else rc = dtype == MIA_BF16 ? dispatch<bf16_t>(mode, a, mt, nt, grid_y, st) : dispatch<float>(mode, a, mt, nt, grid_y, st);
   if (rc != MIA_OK) return rc;
@@ -459,6 +442,7 @@ extern "C" int mia_conv_mma_nl(int mode, int dtype, const void* y_in, int c1, co
                       hout, wout, stream, in_scale, in_shift, slope);
 }
 
+#ifdef MIA_EXPERIMENTS  // probe builds only (tools/r5_store_hazard.sh): include/mia_hip_experiments.h
 // Input gradient with the producing block's norm-backward reduction in its epilogue: see include/mia_hip.h.
 extern "C" int mia_conv_cr_supported(int mode, int dtype, int c1, int nout, int hout, int wout) {
   (void)wout;
@@ -479,6 +463,8 @@ extern "C" int mia_conv_mma_cr(int mode, int dtype, const void* in1, int c1, con
   return conv_mma_run(mode, dtype, in1, c1, nullptr, 0, wpack, npad, kpad, flip_taps, nullptr, out, nout, nullptr, 0, partials, n, hin,
                       win, hout, wout, stream, nullptr, nullptr, 0.f, y_prod, coef, slope);
 }
+
+#endif
 
 // out += conv(in): see include/mia_hip.h.
 extern "C" int mia_conv_acc_supported(int mode, int dtype, int c1, int nout) {

@@ -477,12 +477,6 @@ static void flaunch_mt(const ConvArgs& a, int mt, int nt, int grid_y, hipStream_
     }
     flaunch_nt<T, MODE, 2>(a, nt, grid_y, st);
   } else {
-    if constexpr (MODE == MODE_G3S1 && sizeof(T) == 2) {
-      if (mt == 8 && nt == 4) { flaunch<T, MODE, 8, 4>(a, grid_y, st); return; }
-    }
-    if constexpr (MODE == MODE_T3S2 && sizeof(T) == 2) {
-      if (mt == 16) { flaunch<T, MODE, 4, 4, 2>(a, grid_y, st); return; }  // mt = 16: the host's tag for the 512-thread 128-channel-block shape
-    }
     if (mt >= 4) flaunch_nt<T, MODE, 4>(a, nt, grid_y, st);
     else flaunch_nt<T, MODE, 2>(a, nt, grid_y, st);
   }

@@ -393,7 +393,9 @@ __global__ __launch_bounds__(512, 2) void conv_pw_kernel(const ConvArgs a, int m
 }
 
 bool conv_pw_eligible(int mode, int dtype, const ConvArgs& a) {
-  if (dtype != MIA_BF16 || (mode != MODE_T2S2 && mode != MODE_G2S2 && mode != MODE_G3S2 && mode != MODE_T3S2)) return false;
+  // (MODE_T3S2, the strided conv's input gradient as exact-tap GEMMs, round 4: correct, slower than the tile kernel at every level --
+  // profiles/r04_ab_conv_pw_t3.txt -- and no longer instantiated; its branches stay in the kernel template as documentation of the attempt)
+  if (dtype != MIA_BF16 || (mode != MODE_T2S2 && mode != MODE_G2S2 && mode != MODE_G3S2)) return false;
   if (a.c2 != 0 || a.o2 != 0 || !a.vec_in || !a.vec_out) return false;
   if (a.c1 % 64 != 0 || a.kpad != a.c1 || a.npad != a.o1) return false;
   const int ntot = (mode == MODE_T2S2 || mode == MODE_T3S2) ? 4 * a.o1 : a.o1;
@@ -434,7 +436,7 @@ int conv_pw_launch(int mode, const ConvArgs& a, int reserve, hipStream_t st) {
   const int tile_major = t3 ? nblocks : ((nblocks > 1 && mtiles % 8 == 0) ? nblocks : 0);
   const int ncu = reserve > 0 ? persistent_cus(pw_num_cus(), reserve) : pw_num_cus();
   const dim3 grid(t3 ? (mtiles < ncu ? mtiles : ncu) : (nwork < ncu ? nwork : ncu));  // t3: one workgroup per pixel tile at most
-  if (t3) hipLaunchKernelGGL(conv_pw_kernel<MODE_T3S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
+  if (t3) { mia_set_error("conv_pw: MODE_T3S2 is not built"); return MIA_EUNSUPPORTED; }
   else if (mode == MODE_G3S2) hipLaunchKernelGGL(conv_pw_kernel<MODE_G3S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
   else if (tr) hipLaunchKernelGGL(conv_pw_kernel<MODE_T2S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);
   else hipLaunchKernelGGL(conv_pw_kernel<MODE_G2S2>, grid, dim3(512), 0, st, a, mtot, wco, nk, mtiles, nwork, tile_major);

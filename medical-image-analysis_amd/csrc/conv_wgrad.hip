@@ -1915,8 +1915,9 @@ static int wgrad_tile_h(const MiaOptions& o, int mode, int dtype, int hy, bool f
   return s == 1 ? 8 : 4;
 }
 
-static bool wgrad_two_wg(const MiaOptions& o, int mode, int dtype) {  // option wgrad_w8 = 0: the one-workgroup-per-CU kernel (A/B knob)
-  return o.wgrad_w8 && mode == MODE_W3S1 && dtype == MIA_BF16;
+static bool wgrad_two_wg(const MiaOptions& o, int mode, int dtype) {
+  (void)o;
+  return mode == MODE_W3S1 && dtype == MIA_BF16;
 }
 
 /* split-K workgroups to aim for: one per CU, or two where the kernel is built for two workgroups per CU */
@@ -1925,7 +1926,7 @@ extern "C" int mia_wgrad_target_blocks(int mode, int dtype) {
   int per_cu = 1;
   if (wgrad_two_wg(o, mode, dtype)) per_cu = 2;
   else if (mode == MODE_W3S2 && dtype == MIA_BF16 && o.wgrad_bt && o.wgrad_dma) per_cu = 2;  // 128 n x 64 k blocks: half as many column blocks
-  else if (mode == MODE_W2S2 && dtype == MIA_BF16 && o.wgrad_w8 != 0) per_cu = 2;  // 4 taps: 172 registers, 40 KB LDS -> two workgroups fit a CU
+  else if (mode == MODE_W2S2 && dtype == MIA_BF16) per_cu = 2;  // 4 taps: 172 registers, 40 KB LDS -> two workgroups fit a CU
   // option reserve_cus: the split count follows the CUs left to the persistent kernels (a different split count is a
   // different -- still fixed -- fp32 summation order of the slabs: deterministic per setting, not bit-identical across settings)
   const int cus = o.reserve_cus > 0 ? ((256 - o.reserve_cus) & ~7) : 256;
@@ -1978,7 +1979,7 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   a.vec_x = (c1 % epu == 0) && (c2 % epu == 0) && al16(x1) && (x2 == nullptr || al16(x2));
   a.vec_dy = (cdy % epu == 0) && al16(dy);
-  a.opt = o.wgrad_tab ? 1 : 0;
+  a.opt = 1;
   dim3 grid((npad / 64) * (kpad / 64), ksplit);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t lim = (size_t)1 << 31;
@@ -2016,12 +2017,9 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
     dim3 bgrid(fgrid.x / 2, fgrid.y);
     hipLaunchKernelGGL(wgrad_bf16_bt_t2_kernel, bgrid, dim3(512), 0, st, a);
   } else if (fast && th == 4 && mode == MODE_W3S1) {
-    {
-      // narrow blocks (channels not a multiple of 64 on either side): the kernel that skips empty 16-channel tiles
-      const bool narrow = o.wgrad_narrow && ((c1 % 64 != 0) || (c2 % 64 != 0) || (cdy % 64 != 0));
-      if (narrow) hipLaunchKernelGGL(wgrad_bf16_dma_kernel<true>, fgrid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL(wgrad_bf16_dma_kernel<false>, fgrid, dim3(256), 0, st, a);
-    }
+    // (wgrad_bf16_dma_kernel<true>, the form that skips a narrow block's empty 16-channel tiles, round 4: same sums, no gain --
+    // profiles/r04_ab_wgrad_narrow.txt -- and no longer instantiated)
+    hipLaunchKernelGGL(wgrad_bf16_dma_kernel<false>, fgrid, dim3(256), 0, st, a);
   } else if (fast && wgrad_two_wg(o, mode, dtype)) {  // stride-2 / transposed shapes stay on the one-workgroup-per-CU kernel
     hipLaunchKernelGGL(wgrad_bf16_2wg_kernel<8>, fgrid, dim3(256), 0, st, a);
   } else if (fast) {

@@ -829,6 +829,7 @@ extern "C" int mia_norm_bwd_sums(const void* dz, const void* dz2, const void* y,
   return MIA_OK;
 }
 
+#ifdef MIA_EXPERIMENTS  // consumer side of the column-reduce epilogue (probe builds only)
 // mia_norm_act_bwd whose reduction pass already ran somewhere else: `partials` [n][parts][c][2] were filled by the epilogue of the
 // input-gradient conv that produced dz (mia_conv_mma_cr).  Sums + finalize here; the apply pass only when dy != nullptr.
 extern "C" int mia_norm_act_bwd_pre(const void* dz, const void* y, void* dy, int dtype, const float* scale, const float* shift,
@@ -847,6 +848,8 @@ extern "C" int mia_norm_act_bwd_pre(const void* dz, const void* y, void* dy, int
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
+
+#endif
 
 // local batch totals tot[3][C] = (sum g, sum g*xhat, pixel count) over this rank's images, from the per-(n,c) sums in c1 / c2
 __global__ void bn_bwd_local_tot_kernel(int n_img, int c, int64_t hw, const float* __restrict__ c1, const float* __restrict__ c2,

@@ -1,4 +1,7 @@
-// Library options (kernel-selection / launch-shape knobs for A/B measurements; never numerics contracts).
+// Library options (kernel-selection / launch-shape knobs for A/B measurements; never numerics contracts).  16 of them since round 5: the
+// measured-and-rejected experiments of rounds 3-4 (Winograd conv64, conv_pw T3S2, conv_t3_wide, wgrad_narrow, conv_mt8, the column-reduce
+// epilogue, the register-staged two-workgroup weight gradient as an alternative to the LDS-DMA ring) left the shipping library; their
+// records stay under profiles/, their kernels are compiled only with -DMIA_EXPERIMENTS (tools/probe/).
 //
 // ONE table, read from the environment ONCE (first use, std::call_once), changed only through mia_set_option; every C-ABI
 // entry point takes ONE snapshot (`const MiaOptions o = mia_options();`) and passes it down, so a call never sees two values
@@ -6,8 +9,8 @@
 // getenv or keeps a lazily-initialised knob.
 //
 // Geometry queries (mia_conv_mma_tiles, mia_wgrad_geometry, mia_wgrad_target_blocks) size the caller's statistics / slab
-// buffers in a SEPARATE call from the launch that fills them.  The options that change that geometry (conv_mt8, wgrad_dma,
-// wgrad_bt, wgrad_t2, wgrad_w8) are A/B knobs: mia_set_option on them must not race with compute calls of another thread
+// buffers in a SEPARATE call from the launch that fills them.  The options that change that geometry (wgrad_dma, wgrad_bt,
+// wgrad_t2, reserve_cus) are A/B knobs: mia_set_option on them must not race with compute calls of another thread
 // (set them between steps; the Python side does -- tools/ab_option.py).  Everything else may change at any time.
 #pragma once
 
@@ -20,20 +23,12 @@ struct MiaOptions {
   int conv_s2_wide;   // stride-2 3x3 bf16 forward with 128-multiples of output channels on 512-thread 16-row tiles (1: from 128 input channels on, 2: always)   env MIA_CONV_S2_WIDE  default 1
   int conv_pw;        // ConvTranspose 2x2 stride 2 forward / input gradient (bf16) as one pointwise GEMM on the LDS-DMA ring   env MIA_CONV_PW       default 1
   int conv_pw_s2;     // stride-2 3x3 bf16 forward as a tap-gathered GEMM on the conv_pw ring (needs conv_pw; 1: up to 256 input channels, 2: always; -0.13 ms of kernel time per cfg3 step measured INSIDE the step with rocprofv3, two interleaved pairs)   env MIA_CONV_PW_S2    default 1
-  int conv_pw_t3;     // stride-2 3x3 INPUT GRADIENT (bf16, >= 64 output channels, >= 128 dy channels) as exact-tap GEMMs per output-parity class on the conv_pw ring, incl. the accumulating form (needs conv_pw; measured SLOWER than the tile kernel at every cfg3 level, profiles/r04_ab_conv_pw_t3.txt)   env MIA_CONV_PW_T3    default 0
-  int conv64_wino;    // EXPERIMENT: the 64 -> 64 3x3 stride-1 bf16 conv (plain and normalise-on-load) as Winograd F(2x2, 3x3) (conv64w.hip): 2.25x fewer MFMAs, bf16-rounded transforms   env MIA_CONV64_WINO   default 0
-  int conv_mt8;       // 32-row tiles of the tile kernel (experiment)                          env MIA_CONV_MT8      default 0
-  int conv64_blocks;  // workgroups of conv64_persist_kernel, 0 = library default (512)        env MIA_CONV64_BLOCKS default 0
   int wgrad_xcd;      // XCD-aware block order of the bf16 weight-gradient kernels             env MIA_WGRAD_XCD     default 1
   int wgrad_dma;      // LDS-DMA ring weight-gradient kernel (3x3 stride 1 bf16)               env MIA_WGRAD_DMA     default 1
   int wgrad_bt;       // 512-thread 128 n x 64 k weight-gradient kernel (3x3 stride 1 bf16, >= 128 output channels)   env MIA_WGRAD_BT      default 1
   int wgrad_t2;       // ConvTranspose 2x2 weight gradient (bf16, >= 128 coarse channels) on the 512-thread three-stage ring kernel   env MIA_WGRAD_T2      default 1
-  int wgrad_tab;      // table-driven staging of wgrad_bf16_2wg_kernel                         env MIA_WGRAD_TAB     default 1
-  int wgrad_w8;       // two-workgroups-per-CU weight-gradient kernels                         env MIA_WGRAD_W8      default 1
   int stream_blocks;  // target block count of the norm / activation streaming passes          env MIA_STREAM_BLOCKS default 32768
   int stem_mfma;      // matrix-core stem kernel for fp32 images                               env MIA_STEM_MFMA     default 1
-  int conv_t3_wide;   // stride-2 3x3 INPUT GRADIENT (transposed mode), bf16, 128-multiples of output channels, on the 512-thread 128-channel-block shape of conv_s2_wide   env MIA_CONV_T3_WIDE  default 0
-  int wgrad_narrow;   // LDS-DMA weight gradient: launches with channel counts that are not multiples of 64 skip their empty 16-channel tiles (cfg5's 96-channel level; measured: no gain, those launches are not MFMA-bound)   env MIA_WGRAD_NARROW  default 0
   int f32_split;      // fp32 convs / weight gradients of the branch-free tile kernels on the f16 matrix cores from two-part split operands scaled per tensor (common.h SplitF16: x * 2^e = h + l in fp16, 22-23 significand bits, fp32 accumulate) whenever the caller passes the operands' maxima; 0 = always the exact fp32 MFMA kernels   env MIA_F32_SPLIT   default 1
   int reserve_cus;    // CUs the persistent kernels leave free (grids of conv_bt / conv_pw / conv64 / conv64_dma, split-K target of the weight gradients): room for RCCL's ring kernels under data parallelism   env MIA_RESERVE_CUS   default 0
 };

@@ -13,12 +13,8 @@ Entry g_table[] = {
     {"conv_xcd", "MIA_CONV_XCD", 1, 0, 1, {1}},
     {"conv64", "MIA_CONV64", 1, 0, 1, {1}},
     {"conv_bt", "MIA_CONV_BT", 1, 0, 1, {1}},
-    {"conv_mt8", "MIA_CONV_MT8", 0, 0, 1, {0}},
-    {"conv64_blocks", "MIA_CONV64_BLOCKS", 0, 0, 1 << 20, {0}},
     {"wgrad_xcd", "MIA_WGRAD_XCD", 1, 0, 1, {1}},
     {"wgrad_dma", "MIA_WGRAD_DMA", 1, 0, 1, {1}},
-    {"wgrad_tab", "MIA_WGRAD_TAB", 1, 0, 1, {1}},
-    {"wgrad_w8", "MIA_WGRAD_W8", 1, 0, 1, {1}},
     {"stream_blocks", "MIA_STREAM_BLOCKS", 32768, 256, 1 << 24, {32768}},
     {"stem_mfma", "MIA_STEM_MFMA", 1, 0, 1, {1}},
     {"conv_bt_order", "MIA_CONV_BT_ORDER", 1, 0, 1, {1}},
@@ -29,11 +25,7 @@ Entry g_table[] = {
     {"conv_pw_s2", "MIA_CONV_PW_S2", 1, 0, 2, {1}},
     {"wgrad_t2", "MIA_WGRAD_T2", 1, 0, 1, {1}},
     {"reserve_cus", "MIA_RESERVE_CUS", 0, 0, 64, {0}},
-    {"conv_t3_wide", "MIA_CONV_T3_WIDE", 0, 0, 1, {0}},
-    {"wgrad_narrow", "MIA_WGRAD_NARROW", 0, 0, 1, {0}},
     {"f32_split", "MIA_F32_SPLIT", 1, 0, 1, {1}},
-    {"conv_pw_t3", "MIA_CONV_PW_T3", 0, 0, 1, {0}},
-    {"conv64_wino", "MIA_CONV64_WINO", 0, 0, 1, {0}},
 };
 constexpr int N_OPT = (int)(sizeof(g_table) / sizeof(g_table[0]));
 std::once_flag g_env_once;
@@ -56,14 +48,27 @@ Entry* find(const char* name) {
 
 int get(int i) { return g_table[i].value.load(std::memory_order_relaxed); }
 
+int idx(const char* name) {
+  for (int i = 0; i < N_OPT; ++i)
+    if (strcmp(name, g_table[i].name) == 0) return i;
+  return -1;
+}
+
 }  // namespace
 
 MiaOptions mia_options() {
   std::call_once(g_env_once, read_env);
+  // table positions resolved once (the table is small and fixed)
+  static const int i_conv_xcd = idx("conv_xcd"), i_conv64 = idx("conv64"), i_conv_bt = idx("conv_bt"), i_wgrad_xcd = idx("wgrad_xcd"),
+                   i_wgrad_dma = idx("wgrad_dma"), i_stream_blocks = idx("stream_blocks"), i_stem_mfma = idx("stem_mfma"),
+                   i_conv_bt_order = idx("conv_bt_order"), i_wgrad_bt = idx("wgrad_bt"), i_conv64_dma = idx("conv64_dma"),
+                   i_conv_s2_wide = idx("conv_s2_wide"), i_conv_pw = idx("conv_pw"), i_conv_pw_s2 = idx("conv_pw_s2"), i_wgrad_t2 = idx("wgrad_t2"),
+                   i_reserve_cus = idx("reserve_cus"), i_f32_split = idx("f32_split");
   MiaOptions o;
-  o.conv_xcd = get(0); o.conv64 = get(1); o.conv_bt = get(2); o.conv_mt8 = get(3); o.conv64_blocks = get(4);
-  o.wgrad_xcd = get(5); o.wgrad_dma = get(6); o.wgrad_tab = get(7); o.wgrad_w8 = get(8); o.stream_blocks = get(9);
-  o.stem_mfma = get(10); o.conv_bt_order = get(11); o.wgrad_bt = get(12); o.conv64_dma = get(13); o.conv_s2_wide = get(14); o.conv_pw = get(15); o.conv_pw_s2 = get(16); o.wgrad_t2 = get(17); o.reserve_cus = get(18); o.conv_t3_wide = get(19); o.wgrad_narrow = get(20); o.f32_split = get(21); o.conv_pw_t3 = get(22); o.conv64_wino = get(23);
+  o.conv_xcd = get(i_conv_xcd); o.conv64 = get(i_conv64); o.conv_bt = get(i_conv_bt); o.wgrad_xcd = get(i_wgrad_xcd);
+  o.wgrad_dma = get(i_wgrad_dma); o.stream_blocks = get(i_stream_blocks); o.stem_mfma = get(i_stem_mfma); o.conv_bt_order = get(i_conv_bt_order);
+  o.wgrad_bt = get(i_wgrad_bt); o.conv64_dma = get(i_conv64_dma); o.conv_s2_wide = get(i_conv_s2_wide); o.conv_pw = get(i_conv_pw);
+  o.conv_pw_s2 = get(i_conv_pw_s2); o.wgrad_t2 = get(i_wgrad_t2); o.reserve_cus = get(i_reserve_cus); o.f32_split = get(i_f32_split);
   return o;
 }
 

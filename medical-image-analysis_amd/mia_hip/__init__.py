@@ -82,6 +82,13 @@ def lib() -> ctypes.CDLL:
             fn = getattr(l, name)
             fn.restype = ret
             fn.argtypes = args
+        exp = os.path.join(os.path.dirname(HEADER), "mia_hip_experiments.h")  # probe builds (-DMIA_EXPERIMENTS) export a few more
+        if os.path.exists(exp):
+            for name, (ret, args) in parse_header(exp).items():
+                if hasattr(l, name):
+                    fn = getattr(l, name)
+                    fn.restype = ret
+                    fn.argtypes = args
         # A/B knobs (kernel selection only, never numerics contracts): MIA_OPTIONS="wgrad_dma=0,conv64=1" -> mia_set_option
         for item in filter(None, os.environ.get("MIA_OPTIONS", "").split(",")):
             key, _, val = item.partition("=")

@@ -492,7 +492,8 @@ def _take_colsum(t: torch.Tensor) -> Optional[torch.Tensor]:
 # Norm-backward partial sums computed by the epilogue of the input-gradient conv that produced a dz tensor (mia_conv_mma_cr):
 # keyed by that tensor's storage address; the producing block's backward takes them and skips its own reduction pass.
 _CR_HINT = {}
-FUSE_CR = __import__('os').environ.get('MIA_FUSE_CR', '0') != '0'  # A/B knob; OFF by default: measured +-0 on the cfg3 step (DESIGN, round 4)
+# (experiment of round 4, measured +-0 on the cfg3 step; the kernels exist only in probe builds of the library, -DMIA_EXPERIMENTS)
+FUSE_CR = __import__('os').environ.get('MIA_FUSE_CR', '0') != '0'
 
 
 def _hint_cr(dz: torch.Tensor, partials: torch.Tensor) -> None:
@@ -534,7 +535,8 @@ def clear_hints() -> None:
 
 
 def cr_supported(dtype, cin: int, cout: int, h: int, w: int) -> bool:
-    return FUSE_CR and dtype == torch.bfloat16 and bool(lib().mia_conv_cr_supported(CONV_G3S1, BF16, cout, cin, h, w))
+    return (FUSE_CR and dtype == torch.bfloat16 and hasattr(lib(), "mia_conv_mma_cr")
+            and bool(lib().mia_conv_cr_supported(CONV_G3S1, BF16, cout, cin, h, w)))
 
 
 _COL_SLABS = int(__import__('os').environ.get('MIA_COL_SLABS', '64'))

@@ -12,6 +12,19 @@ pytestmark = pytest.mark.gpu
 TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
 
 
+def _has_experiments():
+    try:
+        import mia_hip
+        return hasattr(mia_hip.lib(), "mia_conv_mma_cr")
+    except Exception:
+        return False
+
+
+# round-4 experiments that left the shipping library in round 5 (column-reduce epilogue): their tests run against probe builds only
+# (hipcc -DMIA_EXPERIMENTS, MIA_HIP_LIB=...; tools/r5_store_hazard.sh)
+_needs_experiments = pytest.mark.skipif(not _has_experiments(), reason="probe build of libmia_hip (-DMIA_EXPERIMENTS) only")
+
+
 def _dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -1167,6 +1180,7 @@ def test_stem_backward_fused_into_weight_gradient(norm, c0, hw, dtype):
         assert relerr(pb.all[2].bias.grad, blk[1].bias.grad) < 2e-4
 
 
+@_needs_experiments
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [(2, 37, 53), (1, 16, 16), (3, 64, 48), (5, 33, 17), (32, 128, 128), (2, 512, 384)])
 def test_conv_input_gradient_with_column_reduce_epilogue(case):
@@ -1229,6 +1243,7 @@ def test_conv_input_gradient_with_column_reduce_epilogue(case):
     assert relerr(outs[1][0], outs[0][0]) < 8e-3       # dy (bf16: a handful of values may round the other way)
 
 
+@_needs_experiments
 @pytest.mark.gpu
 def test_fused_backward_reduction_matches_unfused_model():
     """Model level: ops.FUSE_CR on / off on a bf16 UNet with 64-channel level-0 blocks -- logits identical, every parameter
@@ -1261,66 +1276,6 @@ def test_fused_backward_reduction_matches_unfused_model():
     assert torch.equal(res[False][0], res[True][0])
     for k, gk in res[True][1].items():
         assert relerr(gk, res[False][1][k]) < 2e-2, k
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("case", [(2, 256, 128, 24, 40), (1, 512, 256, 17, 23), (3, 256, 128, 9, 8), (1, 1024, 512, 16, 16)])
-def test_conv_t3_wide_matches_tile_kernel(case):
-    """Option conv_t3_wide: the stride-2 3x3 conv's input gradient (transposed mode) on 512-thread workgroups with 128-channel
-    blocks -- bit-identical to the 256-thread tile kernel (same per-element summation order), odd fine sizes included."""
-    import mia_hip
-    from mia_hip import CONV_T3S2, ops
-    dev = _dev()
-    n, cout, cin, hc, wc = case          # dy: [n, hc, wc, cout] -> dx: [n, 2hc(-1), 2wc(-1), cin]
-    g = torch.Generator().manual_seed(cout + hc)
-    dy = torch.randn(n, hc, wc, cout, generator=g).to(dev, torch.bfloat16)
-    wt = (torch.randn(cout, cin, 3, 3, generator=g) / 30).to(dev)
-    pc = ops.PackCache()
-    wb, npad, kpad = pc.get(wt, mia_hip.BF16, False)
-    old = mia_hip.get_option("conv_t3_wide")
-    try:
-        for fine in ((2 * hc, 2 * wc), (2 * hc - 1, 2 * wc - 1)):
-            outs = []
-            for v in (0, 1):
-                mia_hip.set_option("conv_t3_wide", v)
-                o, _, _ = ops.conv_mma(CONV_T3S2, dy, None, wb, npad, kpad, False, None, cin, fine)
-                outs.append(o)
-            assert torch.equal(outs[0], outs[1]), fine
-            want = F.conv_transpose2d(dy.float().cpu().permute(0, 3, 1, 2), wt.cpu().to(torch.bfloat16).float(), stride=2, padding=1,
-                                      output_padding=(fine[0] - (2 * hc - 1), fine[1] - (2 * wc - 1)))
-            assert relerr(nchw(outs[1]), want) < 1e-2
-    finally:
-        mia_hip.set_option("conv_t3_wide", old)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("case", [(2, 96, 0, 96, 40, 56), (1, 192, 0, 96, 24, 40), (1, 96, 96, 192, 17, 33), (2, 48, 0, 80, 20, 36),
-                                  (1, 32, 0, 32, 64, 64), (1, 160, 0, 224, 16, 48)])
-def test_wgrad_narrow_blocks_match_full_blocks(case):
-    """Option wgrad_narrow (cfg5's 96-channel level): the LDS-DMA weight gradient skips the empty 16-channel tiles of blocks with fewer
-    than 64 valid channels and re-deals the waves -- every computed entry is the same sum in the same order, so the gradient is
-    BIT-IDENTICAL to the full-block kernel, and it matches fp32-CPU math on the same bf16 operands."""
-    import mia_hip
-    from mia_hip import WGRAD_3S1, ops
-    dev = _dev()
-    n, c1, c2, cout, h, w = case
-    g = torch.Generator().manual_seed(c1 + cout + h)
-    x1 = torch.randn(n, h, w, c1, generator=g).to(dev, torch.bfloat16)
-    x2 = torch.randn(n, h, w, c2, generator=g).to(dev, torch.bfloat16) if c2 else None
-    dy = torch.randn(n, h, w, cout, generator=g).to(dev, torch.bfloat16)
-    shape = (cout, c1 + c2, 3, 3)
-    old = mia_hip.get_option("wgrad_narrow")
-    try:
-        outs = []
-        for v in (0, 1):
-            mia_hip.set_option("wgrad_narrow", v)
-            outs.append(ops.conv_wgrad(WGRAD_3S1, x1, x2, dy, shape, cout, c1 + c2))
-    finally:
-        mia_hip.set_option("wgrad_narrow", old)
-    assert torch.equal(outs[0], outs[1])
-    xc = torch.cat([t.float().cpu().permute(0, 3, 1, 2) for t in (x1, x2) if t is not None], 1)
-    want = torch.nn.grad.conv2d_weight(xc, shape, dy.float().cpu().permute(0, 3, 1, 2), padding=1)
-    assert relerr(outs[1], want) < 2e-4
 
 
 @pytest.mark.gpu
@@ -1632,48 +1587,6 @@ def test_f32_split_wide_dynamic_range_inside_one_tensor(split_everywhere):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [(2, 128, 64, 24, 40), (1, 256, 128, 17, 23), (3, 128, 64, 9, 8), (1, 1024, 512, 16, 16), (2, 512, 256, 33, 20),
-                                  (1, 128, 64, 1, 5), (2, 256, 128, 64, 64)])
-def test_stride2_input_gradient_on_the_pointwise_ring(case):
-    """Option conv_pw_t3 (csrc/conv_pw.hip MODE_T3S2): the stride-2 3x3 conv's input gradient as exact-tap GEMMs per output-parity
-    class on the LDS-DMA ring -- even and odd fine sizes, 64-channel outputs (two classes per column block, zero weight rows for the
-    positions a class skips), several pixel tiles and ragged last tiles -- against the tile kernel (fp32 summation order / one bf16
-    ulp) and fp32-CPU math, plain and accumulating (`mia_conv_mma_acc`: out += result, the skip gradient of unet.py:54-66)."""
-    import mia_hip
-    from mia_hip import CONV_T3S2, call, ops
-    from mia_hip.ops import _p, _stream
-    dev = _dev()
-    n, cout, cin, hc, wc = case          # dy: [n, hc, wc, cout] -> dx: [n, 2hc(-1), 2wc(-1), cin]
-    g = torch.Generator().manual_seed(cout + hc + wc)
-    dy = torch.randn(n, hc, wc, cout, generator=g).to(dev, torch.bfloat16)
-    wt = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cout * 2.25)).to(dev)
-    pc = ops.PackCache()
-    wb, npad, kpad = pc.get(wt, mia_hip.BF16, False)
-    old = mia_hip.get_option("conv_pw_t3")
-    try:
-        for fine in ((2 * hc, 2 * wc), (2 * hc - 1, 2 * wc - 1)):
-            want = F.conv_transpose2d(dy.float().cpu().permute(0, 3, 1, 2), wt.cpu().to(torch.bfloat16).float(), stride=2, padding=1,
-                                      output_padding=(fine[0] - (2 * hc - 1), fine[1] - (2 * wc - 1)))
-            prev = (torch.randn(n, fine[0], fine[1], cin, generator=g) * want.abs().mean().item()).to(dev, torch.bfloat16)
-            outs, accs = [], []
-            for v in (0, 1):
-                mia_hip.set_option("conv_pw_t3", v)
-                o, _, _ = ops.conv_mma(CONV_T3S2, dy, None, wb, npad, kpad, False, None, cin, fine)
-                outs.append(o)
-                acc = prev.clone()
-                call("mia_conv_mma_acc", CONV_T3S2, mia_hip.BF16, _p(dy), cout, _p(wb), npad, kpad, 0, _p(acc), cin, n, hc, wc, fine[0], fine[1], None, None, _stream())
-                accs.append(acc)
-            torch.cuda.synchronize()
-            assert relerr(nchw(outs[0]), want) < 1e-2 and relerr(nchw(outs[1]), want) < 1e-2, fine
-            assert relerr(outs[1], outs[0]) < 2 ** -7, fine                     # one bf16 ulp where the fp32 sums round apart
-            want_acc = want + prev.float().cpu().permute(0, 3, 1, 2)
-            assert relerr(nchw(accs[0]), want_acc) < 1.5e-2 and relerr(nchw(accs[1]), want_acc) < 1e-2, fine
-            assert bool(torch.isfinite(outs[1].float()).all())
-    finally:
-        mia_hip.set_option("conv_pw_t3", old)
-
-
-@pytest.mark.gpu
 def test_batched_weight_pack_matches_per_tensor_pack():
     """`mia_pack_weight_batch` (ops.PackPlan: one launch re-packs every weight of a model after the optimizer step) against the
     per-tensor `mia_pack_weight` on the same values: both orientations, 3x3 / 2x2 / 1x1 taps, channel counts that are not multiples
@@ -1703,55 +1616,3 @@ def test_batched_weight_pack_matches_per_tensor_pack():
                 assert got.data_ptr() != ref.data_ptr() and torch.equal(got, ref), (tuple(w.shape), orient, dt)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("case", [(2, 37, 53), (1, 16, 16), (3, 64, 48), (1, 9, 200), (2, 128, 128)])
-def test_conv64_winograd_matches_direct_kernel(case):
-    """Option conv64_wino (EXPERIMENT, csrc/conv64w.hip): the 64 -> 64 3x3 stride-1 bf16 conv as Winograd F(2x2, 3x3) -- forward with
-    bias + statistics, flipped taps (the input gradient), and normalise-on-load -- against the direct conv64 kernel and fp32-CPU math on the
-    same bf16 operands.  bf16-rounded transforms: tolerance 2.5x the direct kernel's, ragged tiles."""
-    import mia_hip
-    from mia_hip import CONV_G3S1, call, ops
-    from mia_hip.ops import _c_float, _c_i64, _p, _stream
-    dev = _dev()
-    n, h, w = case
-    c = 64
-    g = torch.Generator().manual_seed(n * h + w)
-    x = F.leaky_relu(torch.randn(n, h, w, c, generator=g), 0.01).to(dev, torch.bfloat16)
-    wt = (torch.randn(c, c, 3, 3, generator=g) / 24).to(dev)
-    bias = torch.randn(c, generator=g).to(dev)
-    coefs = torch.zeros(5, n, c)
-    coefs[2] = torch.randn(n, c, generator=g)
-    coefs[3] = torch.randn(n, c, generator=g) * 0.7
-    coefs = coefs.to(dev)
-    pc = ops.PackCache()
-    wp, npad, kpad = pc.get(wt, mia_hip.BF16, True)
-    wb, npb, kpb = pc.get(wt, mia_hip.BF16, False)
-    xc = x.float().cpu().permute(0, 3, 1, 2)
-    want = F.conv2d(xc, wt.cpu().to(torch.bfloat16).float(), bias.cpu(), padding=1)
-    want_dx = F.conv_transpose2d(xc, wt.cpu().to(torch.bfloat16).float(), padding=1)  # x plays dy: dgrad = flipped taps, transposed channels
-    old = mia_hip.get_option("conv64_wino")
-    res = {}
-    try:
-        for v in (0, 1):
-            mia_hip.set_option("conv64_wino", v)
-            y, _, st = ops.conv_mma(CONV_G3S1, x, None, wp, npad, kpad, False, bias, c, (h, w), want_stats=True)
-            dx, _, _ = ops.conv_mma(CONV_G3S1, x, None, wb, npb, kpb, True, None, c, (h, w))
-            if ops.nl_supported(torch.bfloat16, c, c, h, w, False):
-                ynl, _, stnl = ops.conv_mma(CONV_G3S1, x, None, wp, npad, kpad, False, bias, c, (h, w), want_stats=True, nl=(coefs, 0.01))
-            else:
-                ynl, stnl = None, None
-            res[v] = (y, st.sum(1), dx, ynl, None if stnl is None else stnl.sum(1))
-    finally:
-        mia_hip.set_option("conv64_wino", old)
-    d, wv = res[0], res[1]
-    assert relerr(nchw(d[0]), want) < 1e-2 and relerr(nchw(wv[0]), want) < 2.5e-2
-    assert relerr(nchw(d[2]), want_dx) < 1e-2 and relerr(nchw(wv[2]), want_dx) < 2.5e-2
-    if h > 8:
-        assert not torch.equal(wv[0], d[0])  # the Winograd kernel ran
-    assert torch.allclose(wv[1].cpu(), d[1].cpu(), rtol=2e-2, atol=2e-2 * d[1].abs().max().item())
-    if d[3] is not None:
-        z = torch.empty_like(x)
-        call("mia_norm_act_fwd", _p(x), _p(z), mia_hip.BF16, _p(coefs[2]), _p(coefs[3]), n, _c_i64(h * w), c, _c_float(0.01), None, _stream())
-        want_nl = F.conv2d(z.float().cpu().permute(0, 3, 1, 2), wt.cpu().to(torch.bfloat16).float(), bias.cpu(), padding=1)
-        assert relerr(nchw(d[3]), want_nl) < 1e-2 and relerr(nchw(wv[3]), want_nl) < 2.5e-2
-        assert torch.allclose(wv[4].cpu(), d[4].cpu(), rtol=2e-2, atol=2e-2 * d[4].abs().max().item())

@@ -6,10 +6,14 @@ cd /root/repo
 PKG=medical-image-analysis_amd
 if [ "$1" = build ]; then
   mkdir -p tools/ab
-  for pad in 0 2 4 8; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-gpu-rdc -DCR_PAD=$pad -c $PKG/csrc/conv64.hip -o tools/ab/conv64_pad$pad.o || exit 1
-    objs=$(ls $PKG/mia_hip/_obj/*.o | grep -v "/conv64.o")
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ab/libmia_crpad$pad.so $objs tools/ab/conv64_pad$pad.o || exit 1
+  # the column-reduce epilogue lives in probe builds only (-DMIA_EXPERIMENTS: conv64.hip, its entry points in conv_mma.hip / norm.hip)
+  for f in conv_mma norm; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-gpu-rdc -DMIA_EXPERIMENTS -c $PKG/csrc/$f.hip -o tools/ab/${f}_exp.o || exit 1
+  done
+  for pad in 0 2 4 8 16; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-gpu-rdc -DMIA_EXPERIMENTS -DCR_PAD=$pad -c $PKG/csrc/conv64.hip -o tools/ab/conv64_pad$pad.o || exit 1
+    objs=$(ls $PKG/mia_hip/_obj/*.o | grep -v "/conv64.o\|/conv_mma.o\|/norm.o")
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ab/libmia_crpad$pad.so $objs tools/ab/conv64_pad$pad.o tools/ab/conv_mma_exp.o tools/ab/norm_exp.o || exit 1
   done
   ls -la tools/ab/*.so
   exit 0
@@ -19,7 +23,7 @@ echo "# diag_cr4: bad tiles of 10 launches x 32768 tiles (64 -> 64 input gradien
 for pad in 0 2 4 8; do
   MIA_FUSE_CR=1 MIA_HIP_LIB=/root/repo/tools/ab/libmia_crpad$pad.so python tools/probe/diag_cr4.py 2>&1 | tail -1 | sed "s/^/pad $pad: /" >> $out
 done
-MIA_FUSE_CR=1 python tools/probe/diag_cr4.py 2>&1 | tail -1 | sed "s/^/pad 16 (shipping build): /" >> $out
+MIA_FUSE_CR=1 MIA_HIP_LIB=/root/repo/tools/ab/libmia_crpad16.so python tools/probe/diag_cr4.py 2>&1 | tail -1 | sed "s/^/pad 16 (the padding the epilogue carries): /" >> $out
 echo "# diag_cr3 on the unpadded build: which lanes / dwords of the first bad tiles" >> $out
 MIA_FUSE_CR=1 MIA_HIP_LIB=/root/repo/tools/ab/libmia_crpad0.so python tools/probe/diag_cr3.py 2>&1 | tail -25 >> $out
 cat $out
