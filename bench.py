@@ -404,35 +404,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Warm-up steps are fed the way the reference's loop feeds every step -- the batch starts in HOST memory and goes through
-    # image.to(device) / label.to(device) (al_trainer.py:1366-1368; here training.feed.HostFeed) -- the timed steps then run on the batch
-    # resident in HBM.  Round 5 found that this matters beyond fidelity: once a host -> device transfer has overlapped
-    # compute in a process, the board runs every matrix-bound kernel at a ~13 % higher shader clock for the rest of the process
-    # (same cycle counts, rocprofv3 --pmc; cfg3 step 42.4 -> 37.7 ms; profiles/r05_ab_boost_state.txt).  Training never runs outside
-    # that state (every step of al_train is host-fed); a benchmark whose batch never left HBM would.  MIA_BENCH_WARM=resident keeps the
-    # old behaviour for the A/B.
-    warm_host = os.environ.get("MIA_BENCH_WARM", "host") == "host"
-    host_warm_batch = {"image": img.clone(), "label": lab.clone()} if (warm_host and aug is None) else None
-    warm_feed = None
-    if warm_host and aug is not None:
-        from training.feed import HostFeed
-        warm_feed, warm_nat = HostFeed(dev), (aug_in[0].cpu(), aug_in[1].cpu())
-
-    def warm_step(i):
-        if host_warm_batch is not None:
-            return eng.train_step(host_warm_batch)
-        if warm_feed is not None:  # native-resolution batch from host memory -> on-GPU pipeline -> step (same rule as TrainEngine: plain .to() first)
-            staged = warm_feed.stage(*warm_nat) if i >= TrainEngine.FEED_AFTER else (warm_nat[0].to(dev), warm_nat[1].to(dev))
-            return eng.train_step(aug(*staged))
-        return one_step()
-
     n_warm = max(args.warmup, TrainEngine.GRAPH_WARMUP + 1) if args.graph else args.warmup  # graph mode: past the capture
-    for i in range(n_warm):  # (TrainEngine sends the first FEED_AFTER = 3 host batches through plain .to(), the later ones through HostFeed)
-        loss = warm_step(i)
+    for i in range(n_warm):
+        loss = one_step()
     # the engine's auto graph mode decides (and captures) within its first steps: let it settle before the timed region
     extra = 0
     while extra < 8 and ((eng.graph_mode and not eng._graphs) or (eng.graph_auto and not eng.graph_mode)):
-        loss = warm_step(n_warm + extra)
+        loss = one_step()
         extra += 1
     sync()
     replaying = bool(eng.graph_mode)  # --graph, or the engine's auto mode found the warm-up steps host-bound
@@ -496,6 +474,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_v = float(loss.item())
+    import math
+    if not math.isfinite(loss_v) or (elapsed_host is not None and not math.isfinite(float(loss3.item()))):
+        raise SystemExit("bench.py: the loss is not finite -- the timed steps did not train (a benchmark on NaN operands also runs at a "
+                         "higher clock: NaN payloads toggle fewer bits; round 5)")
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -622,8 +604,6 @@ def main():
                                       f"dropout {drop}, Dice+CE, Adam(wd 5e-4), clip 10 ({args.config})",
                           "global_batch": world * batch, "parallelism": f"dp{world}"},
                "final_loss": round(loss_v, 6), "roofline": roof}
-        out["config"]["warmup_feed"] = ("host memory -> HostFeed (pinned ring, side-stream H2D), like every step of the reference's loop; the timed "
-                                        "steps run on the HBM-resident batch") if warm_host else "HBM-resident batch (MIA_BENCH_WARM=resident)"
         if replaying:
             out["config"]["graph"] = ("train step replayed from one captured hipGraph" + ("" if args.graph else " (TrainEngine auto mode: the warm-up steps were host-bound)")
                                       + "; per-launch roofline probes cannot see into a replay")

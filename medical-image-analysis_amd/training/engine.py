@@ -363,7 +363,6 @@ class TrainEngine:
         self._graph_epoch = None  # ops.PARAM_EPOCH as the last capture / replay left it
         self._feed = None  # training.feed.HostFeed, created by the first batch that arrives in host memory
 
-    FEED_AFTER = 3    # host-memory batches go through HostFeed from this step on (see _train_step)
     GRAPH_WARMUP = 3  # eager steps before capture: lazy module loads, PackPlan creation (step 2), allocator warm-up
 
     def _capture(self, image: torch.Tensor, label: torch.Tensor) -> "_CapturedStep":
@@ -438,11 +437,9 @@ class TrainEngine:
             self.lr_scheduler.step(self.current_iter)
         dev = self.optimizer.flat_param.device
         image, label = sampled_batch["image"], sampled_batch["label"]
-        if dev.type == "cuda" and not image.is_cuda and not label.is_cuda and label.dtype == torch.int64 and self.current_iter >= self.FEED_AFTER:
+        if dev.type == "cuda" and not image.is_cuda and not label.is_cuda and label.dtype == torch.int64:
             # a batch in host memory (DataLoader output; the reference's image.to(device) / label.to(device), al_trainer.py:1366-1368):
-            # pinned staging ring, copies on a side stream, labels as bytes when they fit -- the host does not wait for the transfer.
-            # (From the FEED_AFTER-th step on: the first steps take the plain .to() path, so that the staging buffers are allocated
-            # after the model's activations -- the order in which the board reliably reached its higher-clock state, DESIGN round 5.)
+            # pinned staging ring, copies on a side stream, labels as bytes when they fit -- the host does not wait for the transfer
             if self._feed is None:
                 from training.feed import HostFeed
                 self._feed = HostFeed(dev)

@@ -81,8 +81,19 @@ class HostFeed:
             lib().mia_host_copy(ctypes.c_void_p(s.pin_lab64.data_ptr()), ctypes.c_void_p(label.data_ptr()), ctypes.c_int64(label.numel() * 8), 0)
             s.pin_lab = s.pin_lab64
         lab_dt = s.pin_lab.dtype
+        fresh = (s.dev_img is None or s.dev_img.shape != image.shape or s.dev_lab_raw is None or s.dev_lab_raw.shape != label.shape
+                 or s.dev_lab_raw.dtype != lab_dt)
         s.dev_img = _fit(s.dev_img, image.shape, torch.float32, device=self.device)
         s.dev_lab_raw = _fit(s.dev_lab_raw, label.shape, lab_dt, device=self.device)
+        if fresh:
+            # A block the caching allocator has just handed out may still be in use by launches that are IN FLIGHT on the launch
+            # stream (it re-uses memory stream-ordered: freed on the host, not yet on the device).  Writing it from the side stream
+            # before those launches have drained overwrote live activations of the previous step -- NaN from the second host-fed
+            # step on (round 5; the small bit-identity test did not hit it, cfg3 did).  The copy stream therefore waits for the
+            # launch stream once per new buffer.
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.copy_stream.wait_event(ev)
         if s.consumed is not None:
             self.copy_stream.wait_event(s.consumed)  # the step that used this slot's device buffers has finished with them
         with torch.cuda.stream(self.copy_stream):

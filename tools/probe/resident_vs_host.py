@@ -169,6 +169,16 @@ if which.startswith("f3:"):
     eng.train_step(res)
     meas("after PRE=%s EXTRA=%s fill=%s prealloc=%d:" % (pre, extra, ["none", "mia_host_copy(image)", "torch copy_(image)", "mia_host_copy(zeros)", "mia_host_copy(randn*1e3)", "torch copy_(zeros)"][fill], prealloc))
     sys.exit(0)
+if which.startswith("nan:"):
+    mode = which[4:]
+    losses = []
+    for i in range(40):
+        l = eng.train_step(host if (mode == "host" or (mode == "mixed" and i < 5)) else res)
+        losses.append(l)
+    torch.cuda.synchronize()
+    print(mode, " ".join("%.4f" % l.item() for l in losses))
+    print("params finite:", bool(torch.isfinite(eng.optimizer.flat_param).all()), "grad finite:", bool(torch.isfinite(eng.optimizer.flat_grad).all()))
+    sys.exit(0)
 if which.startswith("loss:"):
     trig = int(which[5:])
     import ctypes
