@@ -112,6 +112,14 @@ struct SplitF16 {
     for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_perm(w[d], w[d], 0x03020302u);
     return o;
   }
+  // (h, l) words -> (l, h): with the interleaved layout on BOTH sides, (h, l) x (H, L) gives h H + l L and (h, l) x (L, H) gives h L + l H --
+  // all four products from the fragment as it is plus ONE rotated copy (4 VALU per fragment; the (H, H) / (L, L) forms above cost 8)
+  static __device__ __forceinline__ u32x4 swap_hl(const u32x4& w) {
+    u32x4 o;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_alignbit(w[d], w[d], 16);
+    return o;
+  }
   static __device__ __forceinline__ f32x4 mfma(const u32x4& a, const u32x4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }

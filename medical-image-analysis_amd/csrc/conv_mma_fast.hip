@@ -196,16 +196,16 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
       else ldsB[at] = pb[i];
     }
   };
-  // one step of the matrix loop: acc[m][n] += A(m) x B(n) for the wave's MT x NT accumulators.  Split mode forms the (H, H) /
-  // (L, L) forms of a B fragment right before its MT MFMA pairs (8 v_perm per 2 * MT MFMAs; kept out of the double buffer:
-  // 32 more live registers would spill the 4 x 4 shape)
+  // one step of the matrix loop: acc[m][n] += A(m) x B(n) for the wave's MT x NT accumulators.  Split mode forms the (L, H) copy of
+  // a B fragment right before its MT MFMA pairs (4 v_alignbit per 2 * MT MFMAs; kept out of the double buffer: 16 more live registers
+  // per buffered fragment would spill the 4 x 4 shape)
   auto mma_step = [&](auto&& a_of, const u32x4* bfr) {
     if constexpr (SPLIT) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const u32x4 bh = SplitF16::dup_hi(bfr[n]), bl = SplitF16::dup_lo(bfr[n]);
+        const u32x4 bs = SplitF16::swap_hl(bfr[n]);  // (H, L) as staged, and (L, H)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][n] = SplitF16::mma(a_of(m), bh, bl, acc[m][n]);
+        for (int m = 0; m < MT; ++m) acc[m][n] = SplitF16::mma(a_of(m), bfr[n], bs, acc[m][n]);
       }
     } else {
 #pragma unroll

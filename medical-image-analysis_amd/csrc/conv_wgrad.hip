@@ -1734,7 +1734,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
           u32x4 w;
 #pragma unroll
           for (int j = 0; j < 4; ++j) w[j] = dw[(y * 16 + 4 * j + q) * PS + c * 16 + i16];
-          ah[c] = SplitF16::dup_hi(w); al[c] = SplitF16::dup_lo(w);
+          ah[c] = w; al[c] = SplitF16::swap_hl(w);  // (H, L) and (L, H) against the (h, l) x fragment: all four products
         }
 #pragma unroll
         for (int kh = 0; kh < KS; ++kh)
