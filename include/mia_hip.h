@@ -124,7 +124,13 @@ int mia_conv_mma_tiles(int mode, int hout, int wout, int* tiles_y, int* tiles_x,
 int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const void* in2, int c2, const void* wpack, int npad,
                  int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2, int o2,
                  float* stat_partials, int n, int hin, int win, int hout, int wout, const void* amax_in1, const void* amax_in2,
-                 const void* amax_w, void* amax_out1, void* amax_out2, void* stream);
+                 const void* amax_w, const void* wpack_split, void* amax_out1, void* amax_out2, void* stream);
+/* wpack_split (optional, with the maxima): the packed weights already split into (h | l << 16) fp16 words of w * 2^e (e from amax_w's
+ * slot) by mia_split_f16_batch -- same [tap][npad][kpad] layout, 4 bytes per weight; the split kernels then stage them as they are instead
+ * of splitting them once per tile.  Device table of `count` {const float* src; void* dst; int64_t n; const void* amax;} records
+ * (mia_split_desc_bytes() each; n a multiple of 4, 16-byte aligned buffers). */
+int mia_split_desc_bytes(void);
+int mia_split_f16_batch(const void* descs_dev, int count, void* stream);
 /* max |x| of an fp32 tensor of n elements, folded (atomic unsigned maximum of the fp32 bit pattern: order-independent, deterministic)
  * into *slot; reset != 0 zeroes the slot first (stream-ordered, by a kernel: hipMemsetAsync nodes on graph-pool memory were seen to
  * replay wrongly inside a captured step).  The batched form takes a device table of `count`
@@ -171,7 +177,7 @@ int mia_conv_mma_nl(int mode, int dtype, const void* y_in, int c1, const float* 
 int mia_conv_acc_supported(int mode, int dtype, int c1, int nout);
 int mia_conv_mma_acc(int mode, int dtype, const void* in1, int c1, const void* wpack, int npad, int kpad, int flip_taps,
                      void* out_inout, int nout, int n, int hin, int win, int hout, int wout, const void* amax_in, const void* amax_w,
-                     void* stream);
+                     const void* wpack_split, void* stream);
 
 
 /* Stem: Conv2d(1, C0, 3, padding=1) (first encoder block, unet.py:54-66 with input_channels=1): HBM-streaming VALU

@@ -31,6 +31,7 @@ struct ConvArgs {
   // each operand tensor as an fp32 bit pattern in device memory (mia_amax); split = all three known and the option on
   int split = 0;
   const unsigned* amax_in1 = nullptr; const unsigned* amax_in2 = nullptr; const unsigned* amax_w = nullptr;
+  int wsplit = 0;  // split mode: wp already holds (h | l) words of w * 2^eb (mia_split_f16_batch; eb from amax_w) -- staged as they are
   // optional by-product (fp32 tensors): max |out1| / max |out2| folded into these ZEROED slots by the epilogue, for the convs that
   // consume the outputs directly (ConvTranspose output -> decoder conv; a decoder conv's second input gradient -> ConvTranspose backward)
   unsigned* amax_out1 = nullptr; unsigned* amax_out2 = nullptr;

@@ -312,7 +312,8 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
                         int o2, float* stat_partials, int n, int hin, int win, int hout, int wout, void* stream,
                         const float* nl_scale, const float* nl_shift, float nl_slope, const void* cr_y = nullptr,
                         const float* const* cr_coef = nullptr, float cr_slope = 0.f, int acc_out = 0, const void* amax_in1 = nullptr,
-                        const void* amax_in2 = nullptr, const void* amax_w = nullptr, void* amax_out1 = nullptr, void* amax_out2 = nullptr) {
+                        const void* amax_in2 = nullptr, const void* amax_w = nullptr, void* amax_out1 = nullptr, void* amax_out2 = nullptr,
+                        const void* wpack_split = nullptr) {
   MIA_CHECK_ARG(mode >= 0 && mode <= MODE_G1, "mia_conv_mma: bad mode %d", mode);
   MIA_CHECK_ARG(dtype == MIA_F32 || dtype == MIA_BF16, "mia_conv_mma: bad dtype %d", dtype);
   MIA_CHECK_ARG(in1 && wpack && out1 && c1 > 0 && o1 > 0 && c2 >= 0 && o2 >= 0, "mia_conv_mma: null/empty operand");
@@ -375,6 +376,7 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
   // conv64_dma: 1 = the one-pass two-destination input gradient only (measured faster there), 2 = every 64 -> 64 launch
   if (acc_out) {  // out += result: the tile kernel's epilogue reads the previous values
     if (!fast) { mia_set_error("mia_conv_mma_acc: shape outside the accumulating kernel's contract"); return MIA_EUNSUPPORTED; }
+    if (a.split && wpack_split != nullptr) { a.wp = wpack_split; a.wsplit = 1; }
     rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
   }
 #ifdef MIA_EXPERIMENTS
@@ -403,6 +405,7 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
   else if (opt.conv_pw && (mode != MODE_G3S2 || opt.conv_pw_s2 >= 2 || (opt.conv_pw_s2 == 1 && c1 <= 256)) && conv_pw_eligible(mode, dtype, a))
     rc = conv_pw_launch(mode, a, opt.reserve_cus, st);
   else if (fast) {
+    if (a.split && wpack_split != nullptr) { a.wp = wpack_split; a.wsplit = 1; }
     if (dtype == MIA_F32) { a.amax_out1 = static_cast<unsigned*>(amax_out1); a.amax_out2 = static_cast<unsigned*>(amax_out2); amax_out1 = amax_out2 = nullptr; }
     rc = conv_mma_fast_launch(mode, dtype, a, mt, nt, grid_y, st);
   }
@@ -418,10 +421,11 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
 extern "C" int mia_conv_mma(int mode, int dtype, const void* in1, int c1, const void* in2, int c2, const void* wpack,
                             int npad, int kpad, int flip_taps, const float* bias, void* out1, int o1, void* out2,
                             int o2, float* stat_partials, int n, int hin, int win, int hout, int wout, const void* amax_in1,
-                            const void* amax_in2, const void* amax_w, void* amax_out1, void* amax_out2, void* stream) {
+                            const void* amax_in2, const void* amax_w, const void* wpack_split, void* amax_out1, void* amax_out2,
+                            void* stream) {
   return conv_mma_run(mode, dtype, in1, c1, in2, c2, wpack, npad, kpad, flip_taps, bias, out1, o1, out2, o2, stat_partials, n, hin,
                       win, hout, wout, stream, nullptr, nullptr, 0.f, nullptr, nullptr, 0.f, 0, amax_in1, amax_in2, amax_w, amax_out1,
-                      amax_out2);
+                      amax_out2, wpack_split);
 }
 
 // Normalise-on-load forward conv (the fused PlainBlock, SURVEY 8b export list "conv3x3_nhwc ... optional fused normalise +
@@ -474,8 +478,8 @@ extern "C" int mia_conv_acc_supported(int mode, int dtype, int c1, int nout) {
 
 extern "C" int mia_conv_mma_acc(int mode, int dtype, const void* in1, int c1, const void* wpack, int npad, int kpad, int flip_taps,
                                 void* out_inout, int nout, int n, int hin, int win, int hout, int wout, const void* amax_in,
-                                const void* amax_w, void* stream) {
+                                const void* amax_w, const void* wpack_split, void* stream) {
   MIA_CHECK_ARG(mode == MODE_T3S2 || mode == MODE_G3S1, "mia_conv_mma_acc: mode %d not served", mode);
   return conv_mma_run(mode, dtype, in1, c1, nullptr, 0, wpack, npad, kpad, flip_taps, nullptr, out_inout, nout, nullptr, 0, nullptr, n, hin,
-                      win, hout, wout, stream, nullptr, nullptr, 0.f, nullptr, nullptr, 0.f, 1, amax_in, nullptr, amax_w);
+                      win, hout, wout, stream, nullptr, nullptr, 0.f, nullptr, nullptr, 0.f, 1, amax_in, nullptr, amax_w, nullptr, nullptr, wpack_split);
 }

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int at = ((i * TPI + tsub) * 4 + g) * NPB + bn_;
-      if constexpr (SPLIT) ldsB[at] = SplitF16::unit(pb[i], sc_b);
+      if constexpr (SPLIT) ldsB[at] = a.wsplit ? pb[i] : SplitF16::unit(pb[i], sc_b);  // (uniform: the weights arrive split, or are split here)
       else ldsB[at] = pb[i];
     }
   };

@@ -564,3 +564,31 @@ extern "C" int mia_host_copy(void* dst, const void* src, int64_t bytes, int thre
   for (auto& t : th) t.join();
   return MIA_OK;
 }
+
+// ---- packed fp32 weights -> (h | l << 16) fp16 words of w * 2^e (common.h SplitF16), e from the tensor's maximum slot: the split-f16
+// convs then stage their weights as they are instead of splitting them once per tile (round 4 measured that at 7-10 % of a conv launch).
+struct MiaSplitDesc { const float* src; unsigned* dst; int64_t n; const unsigned* amax; };
+__device__ __forceinline__ void split_span(const MiaSplitDesc& d, int64_t first, int64_t stride) {
+  const float s = SplitF16::pow2(SplitF16::exp_of(*d.amax & 0x7FFFFFFFu));
+  const int64_t n4 = d.n / 4;  // (packed buffers are multiples of 64 x 16 elements, 16-byte aligned)
+  const u32x4* src = reinterpret_cast<const u32x4*>(d.src);
+  u32x4* dst = reinterpret_cast<u32x4*>(d.dst);
+  for (int64_t i = first; i < n4; i += stride) {
+    const u32x4 w = SplitF16::unit(src[i], s);
+    store_data_fence();
+    dst[i] = w;
+    store_data_pad();
+  }
+}
+__global__ __launch_bounds__(256) void split_f16_batch_kernel(const MiaSplitDesc* __restrict__ descs) {
+  const MiaSplitDesc d = descs[blockIdx.y];
+  if ((int64_t)blockIdx.x * 256 >= d.n / 4 && blockIdx.x > 0) return;
+  split_span(d, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+}
+extern "C" int mia_split_desc_bytes(void) { return (int)sizeof(MiaSplitDesc); }
+extern "C" int mia_split_f16_batch(const void* descs_dev, int count, void* stream) {
+  MIA_CHECK_ARG(descs_dev && count > 0 && count <= 65535, "mia_split_f16_batch: bad arguments");
+  hipLaunchKernelGGL(split_f16_batch_kernel, dim3(64, count), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const MiaSplitDesc*>(descs_dev));
+  MIA_LAUNCH_CHECK();
+  return MIA_OK;
+}

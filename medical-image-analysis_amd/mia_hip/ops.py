@@ -126,6 +126,20 @@ def _dup_view(z: torch.Tensor) -> torch.Tensor:
     return v
 
 
+def _split_descs(items, device):
+    """Device table for mia_split_f16_batch: items = [(packed fp32 buffer, int32 destination of the same shape, maximum slot)]."""
+    import ctypes as C
+
+    class SDesc(C.Structure):
+        _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64), ("amax", C.c_void_p)]
+
+    assert C.sizeof(SDesc) == lib().mia_split_desc_bytes()
+    arr = (SDesc * len(items))()
+    for i, (buf, dst, slot) in enumerate(items):
+        arr[i] = SDesc(buf.data_ptr(), dst.data_ptr(), buf.numel(), slot.data_ptr())
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
 def _split_ok(x: torch.Tensor, macs: int) -> bool:
     return x.dtype == torch.float32 and macs >= F32_SPLIT_MIN_MACS
 
@@ -168,6 +182,13 @@ class PackCache:
             slot = slot[0] if slot is not None else torch.empty(1, device=w.device, dtype=torch.int32)
             call("mia_amax", _p(wc), _c_i64(wc.numel()), _p(slot), 1, _stream())
             buf._mia_amax = (slot, buf._version)
+            # ... and the packed weights once more as (h | l) fp16 words of w * 2^e, so the split kernels do not split them per tile
+            sp = getattr(buf, "_mia_split", None)
+            if sp is None:
+                sp = torch.empty(buf.shape, device=w.device, dtype=torch.int32)
+                buf._mia_split = sp
+                buf._mia_split_desc = _split_descs([(buf, sp, slot)], w.device)
+            call("mia_split_f16_batch", _p(buf._mia_split_desc), 1, _stream())
         self._store[key] = (ver, buf, npad, kpad)
         return buf, npad, kpad
 
@@ -225,6 +246,12 @@ class PackPlan:
                 aarr[i] = ADesc(w.data_ptr(), w.numel())
             self.amax_descs = torch.frombuffer(bytearray(bytes(aarr)), dtype=torch.uint8).to(self.entries[0][0].device)
             self.amax_slots = torch.zeros(len(self.entries), device=self.entries[0][0].device, dtype=torch.int32)
+            self.split_bufs = [getattr(e[3], "_mia_split", None) for e in self.entries]
+            for i, e in enumerate(self.entries):
+                if self.split_bufs[i] is None:
+                    self.split_bufs[i] = torch.empty(e[3].shape, device=e[3].device, dtype=torch.int32)
+            self.split_descs = _split_descs([(e[3], self.split_bufs[i], self.amax_slots[i:i + 1]) for i, e in enumerate(self.entries)],
+                                            self.entries[0][0].device)
 
     def valid(self) -> bool:
         return all(w.data_ptr() == ptr for w, _, _, _, _, _, ptr in self.entries)
@@ -233,6 +260,7 @@ class PackPlan:
         call("mia_pack_weight_batch", _p(self.descs), len(self.entries), self.total_bricks, self.max_taps, self.dtype, _stream())
         if self.amax_descs is not None:
             call("mia_amax_batch", _p(self.amax_descs), len(self.entries), _p(self.amax_slots), _stream())
+            call("mia_split_f16_batch", _p(self.split_descs), len(self.entries), _stream())
         self.plant()
 
     def plant(self) -> None:
@@ -242,6 +270,7 @@ class PackPlan:
             pc._store[key] = ((w._version, w.data_ptr(), PARAM_EPOCH), buf, npad, kpad)
             if self.amax_descs is not None:
                 buf._mia_amax = (self.amax_slots[i:i + 1], buf._version)
+                buf._mia_split = self.split_bufs[i]
 
 
 _caches = {}
@@ -342,12 +371,13 @@ def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: tor
     if want_stats or cr is not None:
         stats = torch.empty((n, conv_tiles(mode, hout, wout), nout, 2), device=x1.device, dtype=torch.float32)
     # fp32: operand maxima for the split-f16 products (None -> the library runs its exact fp32 kernels)
-    am1 = am2 = amw = None
+    am1 = am2 = amw = wsp = None
     if cr is None and nl is None and _split_ok(x1, n * hout * wout * nout * (c1 + c2)):
         wh = getattr(wpack, "_mia_amax", None)
         if wh is not None:
             amw, am1 = wh[0], amax_slot(x1)
             am2 = None if x2 is None else amax_slot(x2)
+            wsp = getattr(wpack, "_mia_split", None)
     tag = PROBE.match(mode, c1, c2, nout, hin, win, bool(flip)) if (PROBE is not None and PROBE.enabled) else None
     probe = PROBE if tag else None
     if probe is not None:
@@ -367,7 +397,7 @@ def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: tor
         ao1 = _amax_new(out1) if (mode == CONV_T2S2 and x1.dtype == torch.float32) else None
         ao2 = _amax_new(out2) if (out2 is not None and x1.dtype == torch.float32) else None
         call("mia_conv_mma", mode, _dt(x1), _p(x1), c1, _p(x2), c2, _p(wpack), npad, kpad, int(flip), _p(bias), _p(out1), o1,
-             _p(out2), o2, _p(stats), n, hin, win, hout, wout, _p(am1), _p(am2), _p(amw), _p(ao1), _p(ao2), _stream())
+             _p(out2), o2, _p(stats), n, hin, win, hout, wout, _p(am1), _p(am2), _p(amw), _p(wsp), _p(ao1), _p(ao2), _stream())
     if probe is not None:
         e1.record()
         probe.pairs.append((e0, e1, tag, (mode, c1 + c2, nout, n, hout, wout)))
@@ -885,7 +915,8 @@ class PlainBlockFn(torch.autograd.Function):
                     # the other consumer of x1 (a skip tensor) has already written its gradient piece: add ours into it
                     amw = getattr(wb, "_mia_amax", None) if _split_ok(dy, n * ho * wo * cout * cin) else None
                     call("mia_conv_mma_acc", CONV_T3S2, dtype, _p(dy), cout, _p(wb), npad, kpad, 0, _p(other), cin, n, ho, wo,
-                         x1.shape[1], x1.shape[2], _p(None if amw is None else amax_slot(dy)), _p(None if amw is None else amw[0]), _stream())
+                         x1.shape[1], x1.shape[2], _p(None if amw is None else amax_slot(dy)), _p(None if amw is None else amw[0]),
+                         _p(None if amw is None else getattr(wb, "_mia_split", None)), _stream())
                     return (None, None, dw, dbias, dgamma, dbeta) + (None,) * 8
                 dx1, dx2, _ = conv_mma(CONV_T3S2, dy, None, wb, npad, kpad, False, None, cin, (x1.shape[1], x1.shape[2]),
                                        out_split=split)

@@ -36,7 +36,7 @@ def test_python_constants_match_header_defines():
 
 def test_argument_errors_are_reported_without_a_gpu():
     l = mia_hip.lib()
-    rc = l.mia_conv_mma(99, 0, None, 0, None, 0, None, 0, 0, 0, None, None, 0, None, 0, None, 1, 1, 1, 1, 1, None, None, None, None, None, None)
+    rc = l.mia_conv_mma(99, 0, None, 0, None, 0, None, 0, 0, 0, None, None, 0, None, 0, None, 1, 1, 1, 1, 1, None, None, None, None, None, None, None)
     assert rc < 0 and b"bad mode" in l.mia_last_error()
     with pytest.raises(mia_hip.MiaError):
         mia_hip.call("mia_grad_norm", None, ctypes.c_int64(0), ctypes.c_float(1.0), ctypes.c_float(1.0), None, None, None)

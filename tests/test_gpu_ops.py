@@ -1331,7 +1331,7 @@ def test_skip_gradient_accumulated_in_the_stride2_input_gradient(norm, ch, hw, d
         base = torch.randn(n, fine[0], fine[1], cin, generator=g).to(dev, dtype)
         plain, _, _ = ops.conv_mma(CONV_T3S2, dy, None, wb, npad, kpad, False, None, cin, fine)
         acc = base.clone()
-        call("mia_conv_mma_acc", CONV_T3S2, dt, _p(dy), cout, _p(wb), npad, kpad, 0, _p(acc), cin, n, hc, wc, fine[0], fine[1], None, None, _stream())
+        call("mia_conv_mma_acc", CONV_T3S2, dt, _p(dy), cout, _p(wb), npad, kpad, 0, _p(acc), cin, n, hc, wc, fine[0], fine[1], None, None, None, _stream())
         want = (base.float() + plain.float()).to(dtype)
         assert torch.equal(acc, want), fine
 

@@ -27,7 +27,7 @@ def run(xoff, yoff, iters=10):
     y = carve(yoff)
     stats = torch.empty((n, ops.conv_tiles(CONV_G3S1, h, w), c, 2), device=dev)
     f = lambda: call("mia_conv_mma", CONV_G3S1, mia_hip.BF16, _p(x), c, None, 0, _p(wp), npad, kpad, 0, _p(bias), _p(y), c, None, 0, _p(stats),
-                     n, h, w, h, w, None, None, None, None, None, _stream())
+                     n, h, w, h, w, None, None, None, None, None, None, _stream())
     for _ in range(3): f()
     torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -26,7 +26,7 @@ for cout, cin, hc in ((128, 64, 256), (256, 128, 128), (512, 256, 64), (1024, 51
                 if mode == "plain":
                     ops.conv_mma(CONV_T3S2, dy, None, wb, npad, kpad, False, None, cin, (2 * hc, 2 * hc))
                 else:
-                    call("mia_conv_mma_acc", CONV_T3S2, mia_hip.BF16, _p(dy), cout, _p(wb), npad, kpad, 0, _p(acc), cin, n, hc, hc, 2 * hc, 2 * hc, None, None, _stream())
+                    call("mia_conv_mma_acc", CONV_T3S2, mia_hip.BF16, _p(dy), cout, _p(wb), npad, kpad, 0, _p(acc), cin, n, hc, hc, 2 * hc, 2 * hc, None, None, None, _stream())
             for _ in range(3):
                 run()
             torch.cuda.synchronize()
