@@ -112,21 +112,26 @@ def main():
             ok = relerr(r1[0], r0[0]) < 1e-2 and (r1[1] is None or relerr(r1[1], r0[1]) < 1e-2)
             msg = f"two-destination={two} flip={flip}"
         elif kind == "f32_split":
-            # fp32 tensors, split-bf16 products (csrc/common.h SplitBf16) against the exact fp32 kernels: every mode of the tile kernel
-            # and every weight-gradient mode, channel counts on and off the 16-channel fast-path contract, one or two sources
+            # fp32 tensors, split-f16 products (csrc/common.h SplitF16, the default) against the exact fp32 kernels: every mode of the tile
+            # kernel and every weight-gradient mode, channel counts on and off the 16-channel fast-path contract, one or two sources, operand
+            # magnitudes drawn over eleven decades (the per-tensor power-of-two scaling must keep fp16's range out of the picture)
             F32 = mia_hip.F32
+            ops.F32_SPLIT_MIN_MACS = 0
+            sx, sd, sw = (10.0 ** rng.uniform(-7, 4) for _ in range(3))
             mode = rng.choice(["s1", "s1_dgrad", "s2", "s2_dgrad", "t2", "t2_dgrad", "wg_s1", "wg_s2", "wg_t2"])
             cin = rng.choice([16, 32, 48, 64, 96, 128, 160, 256])
             cout = rng.choice([16, 32, 48, 64, 96, 128, 192])
             two = mode in ("s1", "wg_s1") and rng.random() < 0.4
-            f = lambda *shape: torch.randn(*shape, device=dev)  # noqa: E731
+            f = lambda *shape: torch.randn(*shape, device=dev) * sx  # noqa: E731
             hh, ww = (2 * h - rng.randint(0, 1), 2 * w - rng.randint(0, 1)) if mode in ("s2", "s2_dgrad", "wg_s2") else (h, w)
             ho, wo = ((hh + 1) // 2, (ww + 1) // 2) if mode in ("s2", "s2_dgrad", "wg_s2") else (hh, ww)
-            wt = torch.randn(cout, cin * (2 if two else 1), 3, 3, device=dev) / (3 * (cin * (2 if two else 1)) ** 0.5)
-            wtt = torch.randn(cin, cout, 2, 2, device=dev) / (2 * cin ** 0.5)  # ConvTranspose2d(cin -> cout)
-            b = torch.randn(cout, device=dev)
+            wt = torch.randn(cout, cin * (2 if two else 1), 3, 3, device=dev) / (3 * (cin * (2 if two else 1)) ** 0.5) * sw
+            wtt = torch.randn(cin, cout, 2, 2, device=dev) / (2 * cin ** 0.5) * sw  # ConvTranspose2d(cin -> cout)
+            b = torch.randn(cout, device=dev) * (sx * sw)
             x1, x2 = f(n, hh, ww, cin), (f(n, hh, ww, cin) if two else None)
-            dy = f(n, ho, wo, cout)
+            dy = torch.randn(n, ho, wo, cout, device=dev) * sd
+            if two:
+                x2 = x2 * 10.0 ** rng.uniform(-3, 3)
             if mode == "s1":
                 fn = lambda: ops.conv_mma(CONV_G3S1, x1, x2, *ops.PackCache().get(wt, F32, True), False, b, cout, (hh, ww), want_stats=True)[0]  # noqa: E731
             elif mode == "s1_dgrad":
@@ -150,8 +155,8 @@ def main():
                 fn = lambda: ops.conv_wgrad(WGRAD_2S2, fine, None, x1, tuple(wtt.shape), cin, cout)  # noqa: E731
             r1, r0 = ab("f32_split", 1, fn)
             e = relerr(r1, r0)
-            ok = e < 6e-5 and bool(torch.isfinite(r1).all())
-            msg = f"{mode} cin={cin}{'x2' if two else ''} cout={cout} in {hh}x{ww} relerr {e:.1e}{' (identical: exact kernel ran)' if e == 0 else ''}"
+            ok = e < 4e-6 and bool(torch.isfinite(r1).all())  # two fp32-accurate evaluations of one sum
+            msg = f"{mode} cin={cin}{'x2' if two else ''} cout={cout} in {hh}x{ww} scales {sx:.0e}/{sw:.0e}/{sd:.0e} relerr {e:.1e}{' (identical: exact kernel ran)' if e == 0 else ''}"
         elif kind == "wgrad_t2":
             cin, cout = rng.choice([(128, 64), (256, 128), (384, 192), (512, 256)])
             x, dout = t(n, h, w, cin), t(n, 2 * h, 2 * w, cout)
