@@ -1,4 +1,7 @@
-"""Why does the host-fed loop of bench.py run faster than the resident one?  A / B / A / B on one engine (debug aid)."""
+"""Record of a wrong turn (round 5): the experiments that tried to find what made the host-fed loop of bench.py run 13 % FASTER
+than the resident one ("stage", "hoststeps", "part<N>", "q3:", "f3:", "t3:", ...), and the one that settled it ("nan:<res|host|mixed>": 40 steps,
+losses printed -- the first HostFeed overwrote live activations from its side stream, the parameters went NaN, and NaN operands clock higher).
+Kept as it was run; not a tool."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "medical-image-analysis_amd")]
