@@ -36,14 +36,17 @@ _CTYPES = {
 def parse_defines(path: str = HEADER) -> Dict[str, int]:
     """{name: value} for every integer `#define MIA_*` in include/mia_hip.h (the constants above must agree with it)."""
     out = {}
-    for m in re.finditer(r"^#define\s+(MIA_\w+)\s+(-?\d+)\b", open(path).read(), flags=re.M):
+    with open(path) as fh:
+        src = fh.read()
+    for m in re.finditer(r"^#define\s+(MIA_\w+)\s+(-?\d+)\b", src, flags=re.M):
         out[m.group(1)] = int(m.group(2))
     return out
 
 
 def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
     """{name: (restype, [argtypes])} for every prototype in include/mia_hip.h."""
-    txt = open(path).read()
+    with open(path) as fh:
+        txt = fh.read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     txt = "\n".join(l for l in txt.splitlines() if not l.strip().startswith("#"))
     protos = {}
