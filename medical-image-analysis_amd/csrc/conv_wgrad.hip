@@ -1639,19 +1639,24 @@ template <int MODE, bool NARROW = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
   using G = WGeo<MODE>;
   constexpr int KS = G::KS, S = G::S, PAD = G::PAD, TAPS = G::TAPS;
-  constexpr int TH = (S == 1) ? 4 : 2;
+  // N8 (narrow stride-1 3x3, round 5: al_train's 32-channel first level): 8-row tiles -- twice the MFMAs per barrier pair, a 10-row halo tile for
+  // 8 rows instead of 6 for 4 -- on a 48-dword pixel stride (32 channels + 16 pad: the same conflict-free bank pattern as 80) and staging
+  // lanes dealt 32 pixels x 8 units, so no lane idles on the 32 channels that do not exist.  61 KB of LDS: still two workgroups per CU.
+  constexpr bool N8 = NARROW && MODE == MODE_W3S1;
+  constexpr int TH = N8 ? 8 : ((S == 1) ? 4 : 2);
   constexpr int XH = (TH - 1) * S + KS, XW = 15 * S + KS;
-  constexpr int PS = 80;  // LDS pixel stride in dwords (64 channels + 16 pad): conflict-free b32 fragment reads
-  constexpr int X_IT = (XH * XW + 15) / 16, D_IT = TH * 16 / 16;  // 16 pixels x 16 four-channel units per iteration
-  __shared__ __attribute__((aligned(16))) float smem[(X_IT * 16 + TH * 16) * PS];
+  constexpr int PS = N8 ? 48 : 80;  // LDS pixel stride in dwords (64 channels + 16 pad): conflict-free b32 fragment reads
+  constexpr int UL = N8 ? 8 : 16, PPI = 256 / UL;  // four-channel units staged per pixel; pixels per staging iteration
+  constexpr int X_IT = (XH * XW + PPI - 1) / PPI, D_IT = TH * 16 / PPI;
+  __shared__ __attribute__((aligned(16))) float smem[(X_IT * PPI + TH * 16) * PS];
   float* xs = smem;
-  float* ds = smem + X_IT * 16 * PS;
+  float* ds = smem + X_IT * PPI * PS;
 
   constexpr int NC = NARROW ? 2 : 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = NARROW ? (wave & 1) : wave, ph = NARROW ? (wave >> 1) : 0;  // input-channel tile; half of the tile's pixel rows
   const int q = lane >> 4, i16 = lane & 15;
-  const int ch4 = tid & 15, p16 = tid >> 4;
+  const int ch4 = tid % UL, p16 = tid / UL;
   // 64-channel input blocks are cut per SOURCE (ceil(c1/64) + ceil(c2/64) of them), so a block never straddles the
   // two tensors of a concatenated input whatever c1 is; a source's last block may be partial (lanes beyond cs read
   // zeros and do not store)
@@ -1667,7 +1672,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
   int x_iy[X_IT], x_ix[X_IT];
 #pragma unroll
   for (int i = 0; i < X_IT; ++i) {
-    const int pix = p16 + 16 * i;
+    const int pix = p16 + PPI * i;
     x_iy[i] = pix < XH * XW ? pix / XW : -100000;
     x_ix[i] = pix - (pix / XW) * XW;
   }
@@ -1703,7 +1708,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < D_IT; ++i) {
-      const int pix = p16 + 16 * i;
+      const int pix = p16 + PPI * i;
       const int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
       const bool ok = gy < a.Hy && gx < a.Wy;
       const unsigned voff = (ok && n0 + ch4 * 4 < a.cdy) ? (unsigned)(((gy * a.Wy + gx) * a.cdy + n0 + ch4 * 4) * 4) : WSENT;
@@ -1716,9 +1721,9 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
   for (; tile < ntiles; tile += a.ksplit) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < X_IT; ++i) *reinterpret_cast<u32x4*>(xs + (p16 + 16 * i) * PS + ch4 * 4) = SPLIT ? SplitF16::unit(px[i], sc_x) : px[i];
+    for (int i = 0; i < X_IT; ++i) *reinterpret_cast<u32x4*>(xs + (p16 + PPI * i) * PS + ch4 * 4) = SPLIT ? SplitF16::unit(px[i], sc_x) : px[i];
 #pragma unroll
-    for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(ds + (p16 + 16 * i) * PS + ch4 * 4) = SPLIT ? SplitF16::unit(pd[i], sc_d) : pd[i];
+    for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(ds + (p16 + PPI * i) * PS + ch4 * 4) = SPLIT ? SplitF16::unit(pd[i], sc_d) : pd[i];
     __syncthreads();
     if (tile + a.ksplit < ntiles) fetch(tile + a.ksplit);
     constexpr int YR = NARROW ? TH / 2 : TH;
@@ -2030,6 +2035,7 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
   } else if (dtype == MIA_F32 && chan_ok && (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 4 < lim &&
              (size_t)hy * wy * cdy * 4 < lim) {
     const bool narrow = cdy <= 32 && c1 <= 32 && c2 <= 32;  // 32-channel layers: half-width blocks, all four waves busy
+    if (narrow && mode == MODE_W3S1) a.tiles_y = ceil_div(hy, 8);  // (8-row tiles: wgrad_f32_fast_kernel N8)
     if (split) {  // fp32 tensors, two-part split f16 products
       if (narrow) {
         if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, true, true>), fgrid, dim3(256), 0, st, a);

@@ -1394,7 +1394,9 @@ def split_everywhere():
 @pytest.mark.gpu
 @pytest.mark.parametrize("scales", [(1.0, 1.0, 1.0), (3e-7, 40.0, 2e-9), (5e4, 1e-3, 7e5)])
 @pytest.mark.parametrize("case", [(2, 64, 0, 64, 40, 56), (1, 128, 0, 256, 24, 40), (1, 64, 64, 64, 33, 47), (2, 32, 0, 32, 36, 52),
-                                  (1, 256, 0, 128, 17, 33), (2, 16, 0, 48, 20, 28), (1, 96, 96, 96, 24, 40)])
+                                  (1, 256, 0, 128, 17, 33), (2, 16, 0, 48, 20, 28), (1, 96, 96, 96, 24, 40),
+                                  # narrow layers (<= 32 channels everywhere: the 8-row-tile weight gradient), two sources, ragged heights
+                                  (2, 32, 32, 32, 20, 44), (1, 16, 16, 32, 19, 21), (3, 32, 0, 16, 9, 70)])
 def test_f32_split_conv_and_weight_gradient_have_fp32_accuracy(case, scales, split_everywhere):
     """Option f32_split (default): 3x3 forward (stride 1 and 2), both input gradients and both weight gradients in fp32 on split-f16
     products -- as close to fp64 math as the exact fp32 kernels (max-norm, relative: 2e-6 and within 2x the exact kernel's own
