@@ -407,6 +407,26 @@ def conv_mma(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], wpack: tor
 WGRAD_TARGET_BLOCKS = int(__import__('os').environ.get('MIA_WGRAD_BLOCKS', '0'))  # 0 = ask the library (one or two workgroups per CU)
 
 
+WGRAD_KSPLIT_MODEL = __import__('os').environ.get('MIA_WGRAD_KSPLIT_MODEL', '1') != '0'  # A/B knob
+
+
+def _ksplit_by_cost(base: int, slots: int, ntiles: int, slab_bytes: int, flops: float) -> int:
+    """Split-K count where base * ksplit cannot hit the machine's workgroup slots exactly (channel counts that are not powers of two:
+    cfg5's 96-multiples).  The workgroups run in rounds of `slots`, so a count just above a multiple of `slots` wastes most of a round --
+    384 channels: 36 column blocks x 8 slices = 288 of 512 slots, one round at 56 %; 768: 144 x 4 = 576 = two rounds at 56 % -- while every
+    extra slice writes and re-reads one more fp32 slab.  Minimise rounds(k) * slots / (base * k) * compute + k * slab traffic over
+    k = 1 .. 7 and the multiples of 8 (the XCD-aware launch order needs those)."""
+    t_compute = flops / 1.2e15            # the kernels' sustained rate on these shapes
+    cands = [k for k in range(1, 8) if k <= ntiles] + [k for k in range(8, min(ntiles, 1024) + 1, 8)]
+    best, best_t = 1, None
+    for k in cands:
+        rounds = -(-base * k // slots)
+        t = rounds * slots / (base * k) * t_compute + k * 2.0 * slab_bytes / 4.0e12
+        if best_t is None or t < best_t * 0.98:   # (a larger k must win by 2 %)
+            best, best_t = k, t
+    return best
+
+
 def conv_wgrad(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], dy: torch.Tensor, grad_shape, nn: int, kk: int,
                out: Optional[torch.Tensor] = None, nl=None) -> torch.Tensor:
     """Weight gradient in the parameter's native layout (fp32), written into `out` when given.  nl = (coefs, slope): x1 is the
@@ -429,6 +449,8 @@ def conv_wgrad(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], dy: torc
     ksplit = max(1, min(ntiles, -(-target // base), 1024))
     if 8 <= ksplit < ntiles:  # (one tile per slice already: a small problem, leave it)
         ksplit -= ksplit % 8
+    if dtype == BF16 and WGRAD_KSPLIT_MODEL and base * ksplit != target:
+        ksplit = _ksplit_by_cost(base, target, ntiles, taps * npad * kpad * 4, 2.0 * taps * nn * kk * n * hy * wy)
     slabs = torch.empty((ksplit, taps, npad, kpad), device=x1.device, dtype=torch.float32)
     if nl is not None:
         assert x2 is None

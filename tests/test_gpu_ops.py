@@ -1011,7 +1011,9 @@ def test_conv_and_wgrad_normalise_on_load_match_materialised_path(case):
     zc = z.float().cpu().permute(0, 3, 1, 2)
     want = F.conv2d(zc, wt.cpu().to(torch.bfloat16).float(), bias.cpu(), padding=1)
     assert relerr(nchw(got), want) < 1e-2
-    # weight gradient
+    # weight gradient (the split-K count pinned to the plain rule: the cost model of ops._ksplit_by_cost looks at the tile count, which differs
+    # between the kernels compared below, and bit-identity needs one summation order)
+    ops.WGRAD_KSPLIT_MODEL = False
     dw_ref = ops.conv_wgrad(WGRAD_3S1, z, None, dy, wt.shape, c, c)
     dw_nl = ops.conv_wgrad(WGRAD_3S1, y, None, dy, wt.shape, c, c, nl=(coefs, slope))
     want_dw = torch.nn.grad.conv2d_weight(zc, wt.shape, dy.float().cpu().permute(0, 3, 1, 2), padding=1)
@@ -1023,6 +1025,7 @@ def test_conv_and_wgrad_normalise_on_load_match_materialised_path(case):
         dw_2wg = ops.conv_wgrad(WGRAD_3S1, z, None, dy, wt.shape, c, c)
     finally:
         mia_hip.set_option("wgrad_dma", old)
+        ops.WGRAD_KSPLIT_MODEL = True
     assert torch.equal(dw_nl, dw_2wg)
 
 
