@@ -39,9 +39,10 @@ CONFIGS = {
 }
 PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, MI355X_MICROARCH.md
 # fp32 tensors with split-f16 products (library option f32_split, the default): every fp32 multiply-add is FOUR f16 products on the
-# matrix cores (csrc/common.h SplitF16), so the roof for fp32-equivalent FLOPs is the dense f16 peak (2500) / 4 -- pricing them
-# against the fp32-MFMA peak (157.3) gave fractions above 1
-PEAK_F32_SPLIT_TFLOPS = 2500.0 / 4
+# matrix cores (csrc/common.h SplitF16; THREE in the convs under the default value 2: h H + h L + l H on planes), so the roof for
+# fp32-equivalent FLOPs of the conv launches the line prices is the dense f16 peak (2500) / products -- pricing them against the
+# fp32-MFMA peak (157.3) gave fractions above 1
+PEAK_F32_SPLIT_TFLOPS = {1: 2500.0 / 4, 2: 2500.0 / 3}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -297,7 +298,7 @@ def main():
     batch = args.batch or batch
     dt = args.dtype or dt
     if dt == "f32" and mia_hip.get_option("f32_split"):
-        PEAK_MFMA_TFLOPS["f32"] = PEAK_F32_SPLIT_TFLOPS
+        PEAK_MFMA_TFLOPS["f32"] = PEAK_F32_SPLIT_TFLOPS[int(mia_hip.get_option("f32_split"))]
     args.norm = args.norm or ("batch" if args.config == "cfg4" else "instance")
     augment = (args.augment or ("on" if args.config == "cfg4" else "off")) == "on"
     torch.manual_seed(1337)  # identical weights on every rank
@@ -610,8 +611,9 @@ def main():
         if dt == "f32":  # fp32 tensors either way; 1 = conv / weight-gradient products from split-f16 operands (DESIGN: fp32 on the f16 matrix cores)
             out["config"]["f32_split"] = int(mia_hip.get_option("f32_split"))
             if out["config"]["f32_split"] and roof is not None:
-                roof["mfma_peak_note"] = ("fp32-equivalent TFLOP/s against 625 = dense f16 MFMA peak 2500 / 4 products per fp32 "
-                                          "multiply-add (split-f16 operands, csrc/common.h SplitF16)")
+                nprod = 3 if out["config"]["f32_split"] == 2 else 4
+                roof["mfma_peak_note"] = (f"fp32-equivalent TFLOP/s against {2500.0 / nprod:.0f} = dense f16 MFMA peak 2500 / {nprod} products per fp32 "
+                                          "multiply-add in the convs (split-f16 operands, csrc/common.h SplitF16)")
         if elapsed_host is not None:
             out["value_host_fed"] = round(world * batch * args.steps / elapsed_host, 2)
             out["ms_per_step_host_fed"] = round(1e3 * elapsed_host / args.steps, 3)

@@ -90,10 +90,11 @@ int mia_colsum(const void* x, int dtype, int64_t p, int c, float* workspace, flo
  *                                  two-workgroups-per-CU kernel
  *   stream_blocks (MIA_STREAM_BLOCKS, 32768)   target block count of the norm / activation streaming passes
  *   stem_mfma (MIA_STEM_MFMA, 1)   matrix-core stem kernel for fp32 images
- *   f32_split (MIA_F32_SPLIT, 1)      fp32 convs / weight gradients of the branch-free tile kernels on the f16 matrix cores: every
+ *   f32_split (MIA_F32_SPLIT, 2)      fp32 convs / weight gradients of the branch-free tile kernels on the f16 matrix cores: every
  *                                  operand element, scaled by a per-tensor power of two taken from the tensor's max |x| (the amax_*
- *                                  arguments below), enters as h + l (two fp16: 22-23 significand bits), four exact products, fp32
- *                                  accumulation, exact rescaling.  Accuracy of the exact fp32 MFMA kernels (not bit-identical to
+ *                                  arguments below), enters as h + l (two fp16: 22-23 significand bits), four exact products (value 1) or, in
+ *                                  the convs with >= 32 output channels under value 2, the three that matter (h H + h L + l H on
+ *                                  32 x 32 tiles; l L <= 2^-24 of the product), fp32 accumulation, exact rescaling.  Accuracy of the exact fp32 MFMA kernels (not bit-identical to
  *                                  them), ~2x on the fp32 training step.  Tensors stay fp32.  A call without the maxima, or value 0,
  *                                  runs the exact fp32 MFMA kernels.
  *   reserve_cus (MIA_RESERVE_CUS, 0)   CUs the persistent kernels leave free (0..64, rounded so that the grids stay

@@ -39,6 +39,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __builtin_bit_cast(float, ((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
@@ -99,6 +101,28 @@ struct SplitF16 {
       o[2 * p + 1] = __builtin_amdgcn_perm(lp, hp, 0x07060302u);  // h1 | l1 << 16
     }
     return o;
+  }
+  // planar form of the same split: 4 fp32 -> (h0 | h1 << 16, h2 | h3 << 16) and (l0 | l1 << 16, l2 | l3 << 16) -- the converts deliver exactly
+  // these pairs, the interleaved form spends four v_perm on top.  planes_of: interleaved words -> the two pairs.
+  static __device__ __forceinline__ void unit_planar(const u32x4& raw, float s, u32x2& hp, u32x2& lp) {
+    const f32x4 x = __builtin_bit_cast(f32x4, raw) * s;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f2 v = {x[2 * p], x[2 * p + 1]};
+      const h2 hh = __builtin_convertvector(v, h2);  // RNE
+      const h2 ll = __builtin_convertvector(v - __builtin_convertvector(hh, f2), h2);
+      hp[p] = __builtin_bit_cast(unsigned, hh); lp[p] = __builtin_bit_cast(unsigned, ll);
+    }
+  }
+  static __device__ __forceinline__ void planes_of(const u32x4& w, u32x2& hp, u32x2& lp) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      hp[p] = __builtin_amdgcn_perm(w[2 * p + 1], w[2 * p], 0x05040100u);
+      lp[p] = __builtin_amdgcn_perm(w[2 * p + 1], w[2 * p], 0x07060302u);
+    }
+  }
+  static __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
   static __device__ __forceinline__ u32x4 dup_hi(const u32x4& w) {  // (h, l) words -> (h, h)
     u32x4 o;

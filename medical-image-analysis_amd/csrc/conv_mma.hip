@@ -341,7 +341,7 @@ static int conv_mma_run(int mode, int dtype, const void* in1, int c1, const void
   a.nl_scale = nl_scale; a.nl_shift = nl_shift; a.nl_slope = nl_slope;
   a.acc_out = acc_out;
   // fp32: split f16 products when the caller knows every operand's maximum (otherwise, or with the option off, exact fp32 MFMAs)
-  a.split = (dtype == MIA_F32 && opt.f32_split && amax_in1 != nullptr && amax_w != nullptr && (c2 == 0 || amax_in2 != nullptr)) ? 1 : 0;
+  a.split = (dtype == MIA_F32 && opt.f32_split && amax_in1 != nullptr && amax_w != nullptr && (c2 == 0 || amax_in2 != nullptr)) ? opt.f32_split : 0;  // 1: four products on interleaved words, 2: three on planes
   a.amax_in1 = static_cast<const unsigned*>(amax_in1); a.amax_in2 = static_cast<const unsigned*>(amax_in2);
   a.amax_w = static_cast<const unsigned*>(amax_w);
   if (dtype != MIA_F32) amax_out1 = amax_out2 = nullptr;

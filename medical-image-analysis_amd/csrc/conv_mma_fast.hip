@@ -25,16 +25,25 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 // SPLIT (T = float only): fp32 tensors, products on the f16 matrix cores from two-part split operands (common.h SplitF16): commit()
 // turns every staged fp32 unit, scaled by its tensor's power of two (a.amax_in1 / amax_in2 / amax_w: device pointers to max |x| as fp32
 // bit patterns), into (h | l) words, an MFMA step is two 16x16x32 f16 instructions, the epilogue scales the accumulators back.
-template <typename T, int MODE, int MT, int NT, int WC = 1, bool SPLIT = false>
+// SPLIT = 2 (even MT and NT): THREE products on separate h / l planes -- x w = h H + h L + l H, the dropped l L is <= 2^-24 |x w|, the size
+// of the parts' own rounding.  A 16-channel chunk of one plane is exactly the K = 16 of v_mfma_f32_32x32x16_f16, so a wave's MT x NT
+// 16 x 16 tiles become (MT / 2) x (NT / 2) 32 x 32 tiles (two image rows -- m and m + MT / 2 -- x 16 pixels by 32 output channels) and a chunk costs
+// 3 x 32 matrix cycles per 32 x 32 outputs instead of 8 x 16: -25 %, with no VALU work in the loop (the interleaved form rotates every B
+// fragment).  LDS holds the same bytes: unit planes [h ch 0-7 | h ch 8-15 | l ch 0-7 | l ch 8-15] instead of four 4-channel word planes.
+template <typename T, int MODE, int MT, int NT, int WC = 1, int SPLIT = 0>
 __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_mma_fast_kernel(const ConvArgs a) {
   static_assert(!SPLIT || sizeof(T) == 4, "split mode is a mode of the fp32 kernel");
+  constexpr bool P = SPLIT == 2;  // planar three-product form
+  static_assert(!P || (MT % 2 == 0 && NT % 2 == 0 && WC == 1), "32 x 32 tiles");
+  constexpr int MB = P ? MT / 2 : 1, NB = P ? NT / 2 : 1;
   using G = Geo<MODE, MT>;
   constexpr int NTHR = 256 * WC, PL = 64 * WC;  // threads; pixel lanes (x 4 channel groups) of a staging iteration
   constexpr int TH = G::TH, BN = 16 * NT * WC, EPU = Elem<T>::EPU, KB = 4 * EPU, ES = (int)sizeof(T);
   constexpr int PITCH = G::PITCH, S = G::S, IW = G::IW, IH = G::IH;
   constexpr int A_IT = (IH * IW + PL - 1) / PL;  // PL pixels (x 4 channel groups) per staging iteration
   constexpr int NPIX_ALLOC = (S == 1) ? (A_IT * PL > G::NPIX ? A_IT * PL : G::NPIX) : G::NPIX + 1;  // S==2: +1 dummy slot
-  constexpr int NPA = ((NPIX_ALLOC + 13) / 16) * 16 + 2;
+  // (planar form: == 8 (mod 16), the two channel halves a staging quad writes land 32 banks apart)
+  constexpr int NPA = P ? ((NPIX_ALLOC + 7) / 16) * 16 + 8 : ((NPIX_ALLOC + 13) / 16) * 16 + 2;
   constexpr int NPB = BN + 2;
   constexpr int TPI = PL / BN;  // taps staged per iteration
   constexpr int B_IT = (G::MAXTAPS + TPI - 1) / TPI;
@@ -58,6 +67,11 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   const int q = lane >> 4, r16 = lane & 15;
   const int pr = pi16(r16);
   const int g = tid & 3, p4 = tid >> 2;
+  // planar form: MFMA row r32 of a 32 x 32 tile is pixel (image row r32 >> 4, column r32 & 15 with bits 2 and 3 exchanged: the
+  // accumulator rows a lane holds are then 8 consecutive pixels of each of the two rows, and the two lane halves write the epilogue's
+  // LDS image 8 pixels = 32 banks apart); kh = channel half of the chunk
+  const int r32 = lane & 31, kh = lane >> 5;
+  const int prow = r32 >> 4, ppx = (r32 & 3) | ((r32 & 4) << 1) | ((r32 & 8) >> 1);
 
   constexpr bool TMODE = (MODE == MODE_T3S2 || MODE == MODE_T2S2);
   // Block order.  Workgroups are dealt to the 8 XCDs round robin by linear id, and each XCD has its own L2: the blocks that
@@ -146,12 +160,19 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x16 accp[MB][NB];  // (planar form; acc[][] is unused there and vice versa)
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) accp[m][n][j] = 0.f;
   // the bias is loaded up front: at the top of the epilogue it would expose a full memory round trip per block
   const int nout = a.o1 + a.o2;
   float bv[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    int bi = n0 + (wc * NT + n) * 16 + pr;
+    int bi = P ? n0 + (n >> 1) * 32 + r32 : n0 + (wc * NT + n) * 16 + pr;  // (planar form: bv[2 * nb] is the lane's channel of block nb)
     bi = bi < nout ? bi : nout - 1;
     bv[n] = a.bias ? a.bias[bi] : 0.f;
   }
@@ -186,13 +207,24 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int at = g * NPA + (S == 2 ? a_lds[i] : p4 + PL * i);
-      if constexpr (SPLIT) ldsA[at] = SplitF16::unit(pa[i], sc_a);
+      if constexpr (P) {
+        u32x2 hp, lp;
+        SplitF16::unit_planar(pa[i], sc_a, hp, lp);
+        u32x2* d = reinterpret_cast<u32x2*>(ldsA + (g >> 1) * NPA + (at - g * NPA)) + (g & 1);
+        d[0] = hp; d[2 * 2 * NPA] = lp;  // the l planes sit two unit planes behind the h planes
+      } else if constexpr (SPLIT) ldsA[at] = SplitF16::unit(pa[i], sc_a);
       else ldsA[at] = pa[i];
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       const int at = ((i * TPI + tsub) * 4 + g) * NPB + bn_;
-      if constexpr (SPLIT) ldsB[at] = a.wsplit ? pb[i] : SplitF16::unit(pb[i], sc_b);  // (uniform: the weights arrive split, or are split here)
+      if constexpr (P) {
+        u32x2 hp, lp;
+        if (a.wsplit) SplitF16::planes_of(pb[i], hp, lp);  // (uniform: the weights arrive as (h | l) words, or are split here)
+        else SplitF16::unit_planar(pb[i], sc_b, hp, lp);
+        u32x2* d = reinterpret_cast<u32x2*>(ldsB + ((i * TPI + tsub) * 4 + (g >> 1)) * NPB + bn_) + (g & 1);
+        d[0] = hp; d[2 * 2 * NPB] = lp;
+      } else if constexpr (SPLIT) ldsB[at] = a.wsplit ? pb[i] : SplitF16::unit(pb[i], sc_b);  // (uniform: the weights arrive split, or are split here)
       else ldsB[at] = pb[i];
     }
   };
@@ -200,7 +232,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   // a B fragment right before its MT MFMA pairs (4 v_alignbit per 2 * MT MFMAs; kept out of the double buffer: 16 more live registers
   // per buffered fragment would spill the 4 x 4 shape)
   auto mma_step = [&](auto&& a_of, const u32x4* bfr) {
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT == 1) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const u32x4 bs = SplitF16::swap_hl(bfr[n]);  // (H, L) as staged, and (L, H)
@@ -225,7 +257,48 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
     commit();
     __syncthreads();
     if (c0 + KB < ctot) fetch(c0 + KB);
-    if constexpr (MODE == MODE_T3S2) {  // run-time tap count (depends on the output parity)
+    if constexpr (P) {
+      // per tap: the (h, l) fragments of the wave's MB pixel blocks and (H, L) of its NB channel blocks, 3 * MB * NB MFMAs; fragments
+      // double buffered in registers (tap t + 1's reads are issued in front of tap t's MFMAs)
+      u32x4 af[2][MB][2], bf[2][NB][2];
+      auto load_tap = [&](int tl, int toff, u32x4 (*afr)[2], u32x4 (*bfr)[2]) {
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) bfr[n][pl] = ldsB[(tl * 4 + pl * 2 + kh) * NPB + n * 32 + r32];
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) afr[m][pl] = ldsA[(pl * 2 + kh) * NPA + S * (wave * MT + m + MB * prow) * PITCH + toff + ppx];
+      };
+      auto mma_tap = [&](const u32x4 (*afr)[2], const u32x4 (*bfr)[2]) {
+#pragma unroll
+        for (int pr3 = 0; pr3 < 3; ++pr3)  // l H, h L, h H
+#pragma unroll
+          for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+              accp[m][n] = SplitF16::mfma32(afr[m][pr3 == 0 ? 1 : 0], bfr[n][pr3 == 1 ? 1 : 0], accp[m][n]);
+      };
+      if constexpr (MODE == MODE_T3S2) {  // run-time tap count (depends on the output parity)
+        for (int ta = 0; ta < nth; ++ta)
+          for (int tb = 0; tb < ntw; ++tb) {
+            load_tap(ta * ntw + tb, tap_off(ta, tb), af[0], bf[0]);
+            mma_tap(af[0], bf[0]);
+          }
+      } else {
+        constexpr int KSW = (MODE == MODE_G3S1 || MODE == MODE_G3S2) ? 3 : MODE == MODE_G2S2 ? 2 : 1;
+        constexpr int NTAPS = KSW * KSW;
+        load_tap(0, tap_off(0, 0), af[0], bf[0]);
+#pragma unroll
+        for (int tl = 0; tl < NTAPS; ++tl) {
+          const int cur = tl & 1;
+          if (tl + 1 < NTAPS) load_tap(tl + 1, tap_off((tl + 1) / KSW, (tl + 1) % KSW), af[cur ^ 1], bf[cur ^ 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_tap(af[cur], bf[cur]);
+        }
+      }
+    } else if constexpr (MODE == MODE_T3S2) {  // run-time tap count (depends on the output parity)
       for (int ta = 0; ta < nth; ++ta) {
         for (int tb = 0; tb < ntw; ++tb) {
           const int tl = ta * ntw + tb;
@@ -306,7 +379,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   float s1[NT], s2[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) { s1[n] = 0.f; s2[n] = 0.f; }
-  if constexpr (SPLIT) {
+  if constexpr (SPLIT == 1) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -315,7 +388,56 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
         for (int r = 0; r < 4; ++r) acc[m][n][r] = SplitF16::unscale(acc[m][n][r], e_out);
   }
   unsigned am1 = 0u, am2 = 0u;
-  if constexpr (sizeof(T) == 4) {
+  if constexpr (P) {
+    // a lane's 16 values of block (mb, nb): channel n0 + nb * 32 + r32, image rows mb + MB * (j >> 3) of the wave's MT, pixels (j & 7) + 8 * kh
+    float cm8[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) cm8[jj] = (ox0 + jj + 8 * kh < wd) ? 1.f : 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) accp[m][n][j] = SplitF16::unscale(accp[m][n][j], e_out) + bv[2 * n];
+    if (want_amax) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const int col = n0 + n * 32 + r32;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const bool rok = oy0 + wave * MT + m + MB * (j >> 3) < hd;
+            const float v = accp[m][n][j];  // (a copy: __builtin_bit_cast of the vector ELEMENT read element 0 for every j)
+            const unsigned b = (rok && cm8[j & 7] != 0.f && col < nout) ? (__builtin_bit_cast(unsigned, v) & 0x7FFFFFFFu) : 0u;
+            if (col < a.o1) am1 = b > am1 ? b : am1; else am2 = b > am2 ? b : am2;
+          }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float v = accp[m][n][j];
+          if (a.stats != nullptr) {
+            const float rm = (oy0 + wave * MT + m + MB * (j >> 3) < hd) ? 1.f : 0.f;
+            const float vm = full ? v : v * (rm * cm8[j & 7]);
+            s1[n] += vm; s2[n] += vm * v;
+          }
+          ldsO[((wave * MT + m + MB * (j >> 3)) * 16 + (j & 7) + 8 * kh) * OSTR + n * 32 + r32] = v;
+        }
+    if (a.stats != nullptr) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        float t1 = s1[n], t2 = s2[n];
+        t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+        if (kh == 0) { ldsR[(0 * 4 + wave) * BN + n * 32 + r32] = t1; ldsR[(1 * 4 + wave) * BN + n * 32 + r32] = t2; }
+      }
+    }
+  }
+  if constexpr (sizeof(T) == 4 && !P) {
     if (want_amax) {  // ONE uniform branch around the whole pass (inside the store loop below it became a branch per element).
       // Stored elements only: rows / pixels beyond the image and channels beyond nout do not count.
 #pragma unroll
@@ -334,7 +456,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
     }
   }
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
+  for (int m = 0; m < (P ? 0 : MT); ++m) {
     const float rm = (oy0 + wave * MT + m < hd) ? 1.f : 0.f;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -349,7 +471,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
       }
     }
   }
-  if (a.stats != nullptr) {
+  if (!P && a.stats != nullptr) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       float t1 = s1[n], t2 = s2[n];
@@ -446,7 +568,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   if (second_part) store_to(true);
 }
 
-template <typename T, int MODE, int MT, int NT, int WC = 1, bool SPLIT = false>
+template <typename T, int MODE, int MT, int NT, int WC = 1, int SPLIT = 0>
 static void flaunch(const ConvArgs& a, int grid_y, hipStream_t st) {
   int grid_x = a.N * a.tiles_x * a.tiles_y * a.nblk_n;
   if (a.xcd) {  // groups of (channel blocks x parity classes) per tile, tiles rounded up to a multiple of 8
@@ -458,10 +580,12 @@ static void flaunch(const ConvArgs& a, int grid_y, hipStream_t st) {
 template <typename T, int MODE, int MT>
 static void flaunch_nt(const ConvArgs& a, int nt, int grid_y, hipStream_t st) {
   if constexpr (sizeof(T) == 4) {
-    if (a.split) {  // fp32 tensors, two-part split f16 products
-      if (nt == 4) flaunch<T, MODE, MT, 4, 1, true>(a, grid_y, st);
-      else if (nt == 2) flaunch<T, MODE, MT, 2, 1, true>(a, grid_y, st);
-      else flaunch<T, MODE, MT, 1, 1, true>(a, grid_y, st);
+    if (a.split) {  // fp32 tensors, two-part split f16 products: three on planes (32 x 32 tiles) or four on interleaved words
+      if (a.split == 2 && nt == 4) flaunch<T, MODE, MT, 4, 1, 2>(a, grid_y, st);
+      else if (a.split == 2 && nt == 2) flaunch<T, MODE, MT, 2, 1, 2>(a, grid_y, st);
+      else if (nt == 4) flaunch<T, MODE, MT, 4, 1, 1>(a, grid_y, st);
+      else if (nt == 2) flaunch<T, MODE, MT, 2, 1, 1>(a, grid_y, st);
+      else flaunch<T, MODE, MT, 1, 1, 1>(a, grid_y, st);
       return;
     }
   }

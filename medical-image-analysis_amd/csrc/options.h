@@ -29,7 +29,7 @@ struct MiaOptions {
   int wgrad_t2;       // ConvTranspose 2x2 weight gradient (bf16, >= 128 coarse channels) on the 512-thread three-stage ring kernel   env MIA_WGRAD_T2      default 1
   int stream_blocks;  // target block count of the norm / activation streaming passes          env MIA_STREAM_BLOCKS default 32768
   int stem_mfma;      // matrix-core stem kernel for fp32 images                               env MIA_STEM_MFMA     default 1
-  int f32_split;      // fp32 convs / weight gradients of the branch-free tile kernels on the f16 matrix cores from two-part split operands scaled per tensor (common.h SplitF16: x * 2^e = h + l in fp16, 22-23 significand bits, fp32 accumulate) whenever the caller passes the operands' maxima; 0 = always the exact fp32 MFMA kernels   env MIA_F32_SPLIT   default 1
+  int f32_split;      // fp32 convs / weight gradients of the branch-free tile kernels on the f16 matrix cores from two-part split operands scaled per tensor (common.h SplitF16: x * 2^e = h + l in fp16, 22-23 significand bits, fp32 accumulate) whenever the caller passes the operands' maxima; 2 = the convs with 32 x 32 tiles (>= 32 output channels) take THREE products on separate h / l planes (h H + h L + l H; the dropped l L is below the parts' own rounding), 1 = four products on interleaved words everywhere, 0 = always the exact fp32 MFMA kernels   env MIA_F32_SPLIT   default 2
   int reserve_cus;    // CUs the persistent kernels leave free (grids of conv_bt / conv_pw / conv64 / conv64_dma, split-K target of the weight gradients): room for RCCL's ring kernels under data parallelism   env MIA_RESERVE_CUS   default 0
 };
 

@@ -25,7 +25,7 @@ Entry g_table[] = {
     {"conv_pw_s2", "MIA_CONV_PW_S2", 1, 0, 2, {1}},
     {"wgrad_t2", "MIA_WGRAD_T2", 1, 0, 1, {1}},
     {"reserve_cus", "MIA_RESERVE_CUS", 0, 0, 64, {0}},
-    {"f32_split", "MIA_F32_SPLIT", 1, 0, 1, {1}},
+    {"f32_split", "MIA_F32_SPLIT", 2, 0, 2, {2}},
 };
 constexpr int N_OPT = (int)(sizeof(g_table) / sizeof(g_table[0]));
 std::once_flag g_env_once;

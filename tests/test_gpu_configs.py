@@ -220,12 +220,13 @@ def test_cfg1_tiny_fp32_engine_step_vs_oracle():
     assert (got.argmax(1)[safe] == want.argmax(1)[safe]).all()
 
 
-@pytest.mark.parametrize("split,min_macs", [(0, None), (1, 0)])
+@pytest.mark.parametrize("split,min_macs", [(0, None), (1, 0), (2, 0)])
 @pytest.mark.parametrize("channels,size,n", [([16, 32, 64], 128, 4), ([32, 64, 128, 256, 512], 128, 2), ([64, 128, 256, 512, 1024], 128, 2)])
 def test_f32_exact_and_split_everywhere_train_steps_meet_the_fp32_gates(channels, size, n, split, min_macs):
     """The fp32 path's two extremes under the SAME gates (cfg1's, cfg4's and cfg2's networks, one train step against
     oracle/train_ref: logits / loss 1e-4, label maps exact off ties, gradients by `_check_grads_vs_exact`, clip norm, post-AdamW state):
-    option f32_split = 0 (every product an exact fp32 MFMA) and split-f16 products in EVERY tile-kernel launch (size gate lifted).
+    option f32_split = 0 (every product an exact fp32 MFMA) and split-f16 products in EVERY tile-kernel launch (size gate lifted; 1 = four
+    products on interleaved words everywhere, 2 = three products on planes in the convs that have 32 x 32 tiles).
     The default -- split products in the launches above the size gate -- is what every other fp32 test in this file runs."""
     import mia_hip
     from mia_hip import ops

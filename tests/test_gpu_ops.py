@@ -1431,7 +1431,7 @@ def test_f32_split_conv_and_weight_gradient_have_fp32_accuracy(case, scales, spl
             dyd = nhwc(dy, torch.float32, dev)
             wd = wt.to(dev)
             res = {}
-            for flag in (0, 1):
+            for flag in (0, 1, 2):
                 mia_hip.set_option("f32_split", flag)
                 pc = ops.PackCache()
                 wp, npad, kpad = pc.get(wd, mia_hip.F32, True)
@@ -1446,11 +1446,12 @@ def test_f32_split_conv_and_weight_gradient_have_fp32_accuracy(case, scales, spl
                 dx = nchw(dx1) if dx2 is None else torch.cat([nchw(dx1), nchw(dx2)], 1)
                 dw = ops.conv_wgrad(WGRAD_3S2 if stride == 2 else WGRAD_3S1, x1, x2, dyd, wt.shape, cout, cin).cpu()
                 res[flag] = (nchw(y), stats.sum(1).cpu(), dx, dw)
-            (y0, s0, dx0, dw0), (y1, s1, dx1_, dw1) = res[0], res[1]
-            for name, exact, got, want in (("y", y0, y1, yr), ("dx", dx0, dx1_, xr.grad), ("dw", dw0, dw1, wr.grad)):
-                _split_close(got, exact, want, (name, stride))
-            assert relerr(s1[..., 0], yr.detach().sum((2, 3))) < 1e-3
-            assert relerr(s1[..., 1], (yr.detach() ** 2).sum((2, 3))) < 1e-3
+            for flag in (1, 2):  # four products on interleaved words; three on planes (32 x 32 tiles, where the shape has them)
+                (y0, s0, dx0, dw0), (y1, s1, dx1_, dw1) = res[0], res[flag]
+                for name, exact, got, want in (("y", y0, y1, yr), ("dx", dx0, dx1_, xr.grad), ("dw", dw0, dw1, wr.grad)):
+                    _split_close(got, exact, want, (name, stride, flag))
+                assert relerr(s1[..., 0], yr.detach().sum((2, 3))) < 1e-3
+                assert relerr(s1[..., 1], (yr.detach() ** 2).sum((2, 3))) < 1e-3
     finally:
         mia_hip.set_option("f32_split", old)
 
@@ -1475,7 +1476,7 @@ def test_f32_split_transposed_conv_has_fp32_accuracy(case, split_everywhere):
     old = mia_hip.get_option("f32_split")
     res = {}
     try:
-        for flag in (0, 1):
+        for flag in (0, 1, 2):
             mia_hip.set_option("f32_split", flag)
             pc = ops.PackCache()
             wf, nf, kf = pc.get(wd, mia_hip.F32, False)
@@ -1486,8 +1487,9 @@ def test_f32_split_transposed_conv_has_fp32_accuracy(case, split_everywhere):
             res[flag] = (nchw(y), nchw(dx), dw)
     finally:
         mia_hip.set_option("f32_split", old)
-    for name, exact, got, want in zip(("y", "dx", "dw"), res[0], res[1], (yr, xr.grad, wr.grad)):
-        _split_close(got, exact, want, name)
+    for flag in (1, 2):
+        for name, exact, got, want in zip(("y", "dx", "dw"), res[0], res[flag], (yr, xr.grad, wr.grad)):
+            _split_close(got, exact, want, (name, flag))
 
 
 @pytest.mark.gpu
