@@ -42,9 +42,9 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   constexpr int PITCH = G::PITCH, S = G::S, IW = G::IW, IH = G::IH;
   constexpr int A_IT = (IH * IW + PL - 1) / PL;  // PL pixels (x 4 channel groups) per staging iteration
   constexpr int NPIX_ALLOC = (S == 1) ? (A_IT * PL > G::NPIX ? A_IT * PL : G::NPIX) : G::NPIX + 1;  // S==2: +1 dummy slot
-  // (planar form: == 8 (mod 16), the two channel halves a staging quad writes land 32 banks apart)
-  constexpr int NPA = P ? ((NPIX_ALLOC + 7) / 16) * 16 + 8 : ((NPIX_ALLOC + 13) / 16) * 16 + 2;
-  constexpr int NPB = BN + 2;
+  // (planar form: == 4 (mod 8) -- the two channel halves a staging quad writes with ds_write_b64 land 16 of the stores' 32 banks apart)
+  constexpr int NPA = P ? ((NPIX_ALLOC + 3) / 8) * 8 + 4 : ((NPIX_ALLOC + 13) / 16) * 16 + 2;
+  constexpr int NPB = P ? BN + 4 : BN + 2;
   constexpr int TPI = PL / BN;  // taps staged per iteration
   constexpr int B_IT = (G::MAXTAPS + TPI - 1) / TPI;
   constexpr int OSTR = BN + EPU;
@@ -67,11 +67,12 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   const int q = lane >> 4, r16 = lane & 15;
   const int pr = pi16(r16);
   const int g = tid & 3, p4 = tid >> 2;
-  // planar form: MFMA row r32 of a 32 x 32 tile is pixel (image row r32 >> 4, column r32 & 15 with bits 2 and 3 exchanged: the
-  // accumulator rows a lane holds are then 8 consecutive pixels of each of the two rows, and the two lane halves write the epilogue's
-  // LDS image 8 pixels = 32 banks apart); kh = channel half of the chunk
+  // planar form: MFMA row r32 of a 32 x 32 tile is pixel (image row r32 >> 4, column pi16(r32 & 15)): a ds_read_b128 is served in the
+  // lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32), i.e. eight lanes of each image row, and with the rows PITCH == 2 (mod 16)
+  // slots apart the odd / even split of pi16 keeps a group's sixteen 16-byte slots distinct (the 16 x 16 form's reason for pi16 too);
+  // kh = channel half of the chunk
   const int r32 = lane & 31, kh = lane >> 5;
-  const int prow = r32 >> 4, ppx = (r32 & 3) | ((r32 & 4) << 1) | ((r32 & 8) >> 1);
+  const int prow = r32 >> 4, ppx = pi16(r32 & 15);
 
   constexpr bool TMODE = (MODE == MODE_T3S2 || MODE == MODE_T2S2);
   // Block order.  Workgroups are dealt to the 8 XCDs round robin by linear id, and each XCD has its own L2: the blocks that
@@ -389,10 +390,15 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
   }
   unsigned am1 = 0u, am2 = 0u;
   if constexpr (P) {
-    // a lane's 16 values of block (mb, nb): channel n0 + nb * 32 + r32, image rows mb + MB * (j >> 3) of the wave's MT, pixels (j & 7) + 8 * kh
+    // a lane's 16 values of block (mb, nb): channel n0 + nb * 32 + r32, image rows mb + MB * (j >> 3) of the wave's MT, pixels
+    // px8[j & 7] = pi16 of the MFMA row (j & 3) + 8 * ((j >> 2) & 1) + 4 * kh
     float cm8[8];
+    int px8[8];
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) cm8[jj] = (ox0 + jj + 8 * kh < wd) ? 1.f : 0.f;
+    for (int jj = 0; jj < 8; ++jj) {
+      px8[jj] = pi16((jj & 3) + 8 * (jj >> 2) + 4 * kh);
+      cm8[jj] = (ox0 + px8[jj] < wd) ? 1.f : 0.f;
+    }
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(256 * WC, (MT >= 8 || WC == 2 ? 1 : 2)) void conv_m
             const float vm = full ? v : v * (rm * cm8[j & 7]);
             s1[n] += vm; s2[n] += vm * v;
           }
-          ldsO[((wave * MT + m + MB * (j >> 3)) * 16 + (j & 7) + 8 * kh) * OSTR + n * 32 + r32] = v;
+          ldsO[((wave * MT + m + MB * (j >> 3)) * 16 + px8[j & 7]) * OSTR + n * 32 + r32] = v;
         }
     if (a.stats != nullptr) {
 #pragma unroll
