@@ -211,6 +211,7 @@ class GradBucketReducer:
             self.counts[bi] += 1
         self.works = []
         self.handles = []
+        self.suspended = False  # hooks are no-ops (TrainEngine sets it while it RECORDS a backward into a hipGraph)
         self.trace = [] if os.environ.get("MIA_DP_TRACE") else None
         if self.world > 1 or self.force:
             for p, bi in zip(opt.params, opt.param_bucket):
@@ -218,8 +219,8 @@ class GradBucketReducer:
 
     def _make_hook(self, bi):
         def hook(_p):
-            if getattr(_p, "_mia_flat_owner", None) is not self.opt._token:
-                return  # stale reducer of an optimizer that no longer owns the parameter
+            if self.suspended or getattr(_p, "_mia_flat_owner", None) is not self.opt._token:
+                return  # recording into a graph; or the stale reducer of an optimizer that no longer owns the parameter
             self.pending[bi] += 1
             if self.pending[bi] == self.counts[bi]:
                 s, e = self.opt.buckets[bi]
@@ -252,6 +253,16 @@ class GradBucketReducer:
         self.works = []
 
     @property
+    def active(self) -> bool:
+        return self.world > 1 or self.force
+
+    def reduce_all(self):
+        """Every bucket, in index order, issued and joined now (graph mode: the captured backward has filled flat_grad and no hook
+        ran; every rank replays the same graphs, so every rank issues the same collectives in the same order)."""
+        self.start_step()
+        self.finish()
+
+    @property
     def grad_scale(self) -> float:
         return 1.0 / self.world
 
@@ -262,7 +273,7 @@ class _CaptureFailed(RuntimeError):
 
 class _CapturedStep:
     """A captured train step: static inputs, the device-resident per-step scalars, the graph, the static loss."""
-    __slots__ = ("img", "lab", "dyn", "graph", "loss")
+    __slots__ = ("img", "lab", "dyn", "graph", "graph_opt", "loss")
 
 
 class _ReservedCUs:
@@ -301,7 +312,11 @@ class TrainEngine:
         (`torch.cuda.CUDAGraph`) after `GRAPH_WARMUP` eager steps -- for small models whose step is launch-bound (cfg1: ~117
         launches for 1.1 ms of kernels).  Same kernels, same order, same arithmetic as the eager step: the values that change per
         iteration (poly LR, Adam bias corrections, Dropout2d Philox offsets) are read from device memory (`ops.StepDyn`).
-        Single-rank only (the RCCL reducer is not captured); one graph per input shape.  None = env MIA_ENGINE_GRAPH if set, else AUTO
+        Under data parallelism (or `force_reducer`) the step is TWO graphs split at the reducer's join -- forward + loss + backward |
+        the bucket all-reduces, issued eagerly in bucket order (RCCL is not captured; nothing overlaps backward, which is what a
+        host-bound step can afford) | clip + optimizer + re-pack; every rank must then be constructed with graph=True (auto mode is
+        single-rank: ranks deciding for themselves could issue their collectives in different orders), and a model whose forward
+        holds a collective (SyncBatchNorm) stays eager.  One graph (pair) per input shape.  None = env MIA_ENGINE_GRAPH if set, else AUTO
         (round 5): a single-rank engine on a HIP device switches to replay by itself when its first eager steps are HOST-bound -- the
         host needed at least 0.6 of the time the device spent between the step's first and last launch to issue them, in at least two
         steps (HIP events around the eager step, read back without blocking) -- and stays eager otherwise (cfg2 / cfg3 / cfg5 are device-bound; cfg1 and al_train-sized models are not: 3.4-4.1 -> 1.06 ms per step).
@@ -346,16 +361,18 @@ class TrainEngine:
         self.reducer = GradBucketReducer(self.optimizer, process_group, force=force_reducer)
         self.current_iter = 0
         self._one = None
-        can_graph = not (self.reducer.world > 1 or self.reducer.force or not next(model.parameters()).is_cuda)
+        sync_bn = any(getattr(m, "batch_sync", None) is not None for m in model.modules())  # (convert_sync_batchnorm: a collective inside forward)
+        can_graph = next(model.parameters()).is_cuda and not sync_bn
         self.graph_auto = False
         if graph is None:
             env = os.environ.get("MIA_ENGINE_GRAPH")
             if env is None or env == "auto":
-                graph, self.graph_auto = False, can_graph
+                graph, self.graph_auto = False, can_graph and not self.reducer.active
             else:
                 graph = env != "0"
         if graph and not can_graph:
-            raise ValueError("TrainEngine(graph=True) captures a single-rank step on a HIP device (the RCCL reducer is not captured)")
+            raise ValueError("TrainEngine(graph=True) captures the step of a model on a HIP device whose forward holds no collective "
+                             "(SyncBatchNorm under data parallelism is not captured)")
         self.graph_mode = bool(graph)
         self._auto_votes, self._auto_seen, self._auto_pending = 0, 0, []  # auto mode: host-bound steps, judged steps, (start, end, host ms) not yet read
         self._graphs: Dict[tuple, "_CapturedStep"] = {}
@@ -377,17 +394,26 @@ class TrainEngine:
         saved = (opt.step_count, set(opt.stepped))
         torch.cuda.synchronize()
         g.graph = torch.cuda.CUDAGraph()
+        g.graph_opt = None
+        split = self.reducer.active  # two graphs, cut where the gradient buckets are summed over the ranks
         ops._STEP_DYN = g.dyn
         ops.amax_arena_reset()  # the slots this capture uses come from chunks zeroed INSIDE it
+        self.reducer.suspended = True
         try:
             with torch.cuda.graph(g.graph, capture_error_mode="thread_local"):
                 output = self.model(g.img)
                 loss = self.loss_fn(output, g.lab)
                 opt.zero_grad()
                 loss.backward(self._one if self._one.shape == loss.shape else torch.ones_like(loss))
-                opt.step(max_grad_norm=self.grad_norm, grad_scale=self.reducer.grad_scale)
+                if not split:
+                    opt.step(max_grad_norm=self.grad_norm, grad_scale=self.reducer.grad_scale)
                 g.loss = loss.detach()
+            if split:
+                g.graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g.graph_opt, pool=g.graph.pool(), capture_error_mode="thread_local"):
+                    opt.step(max_grad_norm=self.grad_norm, grad_scale=self.reducer.grad_scale)
         finally:
+            self.reducer.suspended = False
             ops._STEP_DYN = None
             ops.amax_arena_reset()
             opt.step_count, opt.stepped = saved
@@ -418,6 +444,9 @@ class TrainEngine:
             # the captured forward holds no pack launch -- at capture time every packed copy was current -- so rebuild them here
             opt._pack_plan.repack()
         g.graph.replay()
+        if g.graph_opt is not None:
+            self.reducer.reduce_all()
+            g.graph_opt.replay()
         # the replay's optimizer rewrote the parameters and its captured re-pack rewrote the plan's copies: new epoch (a packed
         # copy made outside the plan must miss next time), plan copies marked current
         ops.bump_param_epoch()

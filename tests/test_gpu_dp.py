@@ -134,17 +134,21 @@ def _nccl_worker(port, q):
         from training.engine import TrainEngine
         x, y = _data()
         outs = []
-        for force in (True, False):
+        # (reducer forced, eager) / (no reducer, eager) / (reducer forced, step replayed from TWO graphs cut at the reducer's join:
+        # forward + backward | eager bucket all-reduces | clip + optimizer -- TrainEngine graph mode under data parallelism)
+        for force, graph in ((True, False), (False, False), (True, True)):
             torch.manual_seed(1337)
             m = UNet(2, 1, 3, [8, 16, 32], normalization="instance", dropout_prob=None).to(dev)
             eng = TrainEngine(m, DiceAndCELoss(dice_kwargs=dict(num_classes=2, do_bg=True)), "adam", {"weight_decay": 5e-4},
-                              start_lr=1e-2, num_iters=100, lr_warmup_iter=2, bucket_bytes=4096, force_reducer=force)
+                              start_lr=1e-2, num_iters=100, lr_warmup_iter=2, bucket_bytes=4096, force_reducer=force, graph=graph)
             assert (len(eng.reducer.handles) > 0) == force and len(eng.optimizer.buckets) > 2
             grads, losses = [], []
-            for _ in range(3):
+            for _ in range(8):
                 losses.append(eng.train_step({"image": x, "label": y}).item())
                 grads.append(eng.optimizer.flat_grad.detach().cpu().numpy().copy())
             torch.cuda.synchronize()
+            if graph:
+                assert eng.graph_mode and len(eng._graphs) == 1 and next(iter(eng._graphs.values())).graph_opt is not None
             outs.append((losses, grads, eng.optimizer.flat_param.detach().cpu().numpy().copy()))
         dist.destroy_process_group()
         q.put(("ok", outs))
@@ -163,8 +167,10 @@ def test_forced_reducer_on_one_rank_nccl_group_is_bit_identical():
     status, outs = q.get(timeout=300)
     p.join(timeout=60)
     assert status == "ok", outs
-    (l1, g1, p1), (l0, g0, p0) = outs
-    assert l1 == l0
-    for a, b in zip(g1, g0):
+    (l1, g1, p1), (l0, g0, p0), (l2, g2, p2) = outs
+    assert l1 == l0 and l2 == l0
+    for a, b, c in zip(g1, g0, g2):
         np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(c, b)
     np.testing.assert_array_equal(p1, p0)
+    np.testing.assert_array_equal(p2, p0)
