@@ -1635,8 +1635,11 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgArgs a) {
 // (one tile row) x 2 parts: lane group q takes pixels q, q + 4, q + 8, q + 12 (the exact kernel's conflict-free bank pattern),
 // the dy fragment is expanded to its (H, H) and (L, L) forms once per row and meets every tap's (h, l) x fragment in two MFMAs; the
 // accumulators are scaled back when the slab is written.
+// Full blocks (round 5): 512 threads -- eight waves = 4 input-channel tiles x 2 halves of the block's output channels, 72 accumulator
+// registers per wave instead of 144.  The 256-thread form needed 364 registers (hipcc parks accumulators in AGPRs), i.e. ONE wave per
+// SIMD and one workgroup per CU: staging and MFMA phases never overlapped (PMC: 45 % matrix-pipe busy); forced to 256 registers it spilled.
 template <int MODE, bool NARROW = false, bool SPLIT = false>
-__global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
+__global__ __launch_bounds__(NARROW ? 256 : 512, 2) void wgrad_f32_fast_kernel(const WgArgs a) {
   using G = WGeo<MODE>;
   constexpr int KS = G::KS, S = G::S, PAD = G::PAD, TAPS = G::TAPS;
   // N8 (narrow stride-1 3x3, round 5: al_train's 32-channel first level): 8-row tiles -- twice the MFMAs per barrier pair, a 10-row halo tile for
@@ -1646,15 +1649,17 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
   constexpr int TH = N8 ? 8 : ((S == 1) ? 4 : 2);
   constexpr int XH = (TH - 1) * S + KS, XW = 15 * S + KS;
   constexpr int PS = N8 ? 48 : 80;  // LDS pixel stride in dwords (64 channels + 16 pad): conflict-free b32 fragment reads
-  constexpr int UL = N8 ? 8 : 16, PPI = 256 / UL;  // four-channel units staged per pixel; pixels per staging iteration
+  constexpr int NTHR = NARROW ? 256 : 512;
+  constexpr int UL = N8 ? 8 : 16, PPI = NTHR / UL;  // four-channel units staged per pixel; pixels per staging iteration
   constexpr int X_IT = (XH * XW + PPI - 1) / PPI, D_IT = TH * 16 / PPI;
   __shared__ __attribute__((aligned(16))) float smem[(X_IT * PPI + TH * 16) * PS];
   float* xs = smem;
   float* ds = smem + X_IT * PPI * PS;
 
-  constexpr int NC = NARROW ? 2 : 4;
+  constexpr int NC = 2;  // output-channel tiles per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kq = NARROW ? (wave & 1) : wave, ph = NARROW ? (wave >> 1) : 0;  // input-channel tile; half of the tile's pixel rows
+  const int kq = NARROW ? (wave & 1) : (wave & 3), ph = NARROW ? (wave >> 1) : 0;  // input-channel tile; half of the tile's pixel rows
+  const int nh = NARROW ? 0 : 2 * (wave >> 2);  // first output-channel tile of this wave (full blocks: waves 4 .. 7 take tiles 2, 3)
   const int q = lane >> 4, i16 = lane & 15;
   const int ch4 = tid % UL, p16 = tid / UL;
   // 64-channel input blocks are cut per SOURCE (ceil(c1/64) + ceil(c2/64) of them), so a block never straddles the
@@ -1738,7 +1743,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
         for (int c = 0; c < NC; ++c) {
           u32x4 w;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) w[j] = dw[(y * 16 + 4 * j + q) * PS + c * 16 + i16];
+          for (int j = 0; j < 4; ++j) w[j] = dw[(y * 16 + 4 * j + q) * PS + (nh + c) * 16 + i16];
           ah[c] = w; al[c] = SplitF16::swap_hl(w);  // (H, L) and (L, H) against the (h, l) x fragment: all four products
         }
 #pragma unroll
@@ -1762,7 +1767,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
         const int xx = xq * 4 + q;
         float af[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) af[c] = ds[(y * 16 + xx) * PS + c * 16 + i16];
+        for (int c = 0; c < NC; ++c) af[c] = ds[(y * 16 + xx) * PS + (nh + c) * 16 + i16];
 #pragma unroll
         for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
@@ -1803,7 +1808,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_fast_kernel(const WgArgs a) {
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + c * 16 + 4 * q + r, k = k0 + kq * 16 + i16;
+        const int n = n0 + (nh + c) * 16 + 4 * q + r, k = k0 + kq * 16 + i16;
         if (kloc + kq * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = SPLIT ? SplitF16::unscale(acc[t][c][r], e_out) : acc[t][c][r];
       }
 }
@@ -2041,16 +2046,16 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
         if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, true, true>), fgrid, dim3(256), 0, st, a);
         else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S2, true, true>), fgrid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W2S2, true, true>), fgrid, dim3(256), 0, st, a);
-      } else if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, false, true>), fgrid, dim3(256), 0, st, a);
-      else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S2, false, true>), fgrid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W2S2, false, true>), fgrid, dim3(256), 0, st, a);
+      } else if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, false, true>), fgrid, dim3(512), 0, st, a);
+      else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S2, false, true>), fgrid, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W2S2, false, true>), fgrid, dim3(512), 0, st, a);
     } else if (narrow) {
       if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S1, true>), fgrid, dim3(256), 0, st, a);
       else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W3S2, true>), fgrid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((wgrad_f32_fast_kernel<MODE_W2S2, true>), fgrid, dim3(256), 0, st, a);
-    } else if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W3S1>, fgrid, dim3(256), 0, st, a);
-    else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W3S2>, fgrid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W2S2>, fgrid, dim3(256), 0, st, a);
+    } else if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W3S1>, fgrid, dim3(512), 0, st, a);
+    else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W3S2>, fgrid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_f32_fast_kernel<MODE_W2S2>, fgrid, dim3(512), 0, st, a);
   } else if (dtype == MIA_BF16) {
     if (mode == MODE_W3S1) hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W3S1>, grid, dim3(256), 0, st, a);
     else if (mode == MODE_W3S2) hipLaunchKernelGGL(wgrad_bf16_kernel<MODE_W3S2>, grid, dim3(256), 0, st, a);
