@@ -153,10 +153,11 @@ def main():
             else:
                 fine = f(n, 2 * hh, 2 * ww, cout)
                 fn = lambda: ops.conv_wgrad(WGRAD_2S2, fine, None, x1, tuple(wtt.shape), cin, cout)  # noqa: E731
-            r1, r0 = ab("f32_split", 1, fn)
+            sv = rng.choice([1, 2])  # four products on interleaved words / three on planes where the conv has 32 x 32 tiles
+            r1, r0 = ab("f32_split", sv, fn)
             e = relerr(r1, r0)
             ok = e < 4e-6 and bool(torch.isfinite(r1).all())  # two fp32-accurate evaluations of one sum
-            msg = f"{mode} cin={cin}{'x2' if two else ''} cout={cout} in {hh}x{ww} scales {sx:.0e}/{sw:.0e}/{sd:.0e} relerr {e:.1e}{' (identical: exact kernel ran)' if e == 0 else ''}"
+            msg = f"f32_split={sv} {mode} cin={cin}{'x2' if two else ''} cout={cout} in {hh}x{ww} scales {sx:.0e}/{sw:.0e}/{sd:.0e} relerr {e:.1e}{' (identical: exact kernel ran)' if e == 0 else ''}"
         elif kind == "wgrad_t2":
             cin, cout = rng.choice([(128, 64), (256, 128), (384, 192), (512, 256)])
             x, dout = t(n, h, w, cin), t(n, 2 * h, 2 * w, cout)
