@@ -16,3 +16,4 @@ for PMC in FETCH_SIZE WRITE_SIZE; do
 done
 python3 $R/tools/r5_pmc_block.py $cfg $C $S $B $DT
 rm -rf $R/gpurun_out/pmc5_${cfg}_FETCH_SIZE $R/gpurun_out/pmc5_${cfg}_WRITE_SIZE
+cp $R/profiles/r05_pmc_canonical_block_${cfg}.json $R/profiles/r05_pmc_canonical_block_${cfg}.csv $R/gpurun_out/   # (profiles/ on the GPU box is not merged back; gpurun_out/ is)
