@@ -207,6 +207,11 @@ int mia_stem_wgrad_fused(const void* x, int x_dtype, const void* dz, const void*
  * order into grad[nn][kk][taps] (= OIHW for Conv2d, [Cin][Cout][2][2] for ConvTranspose2d). */
 int mia_wgrad_target_blocks(int mode, int dtype); /* split-K workgroups to aim for (ksplit = target / (npad/64 * kpad/64)) */
 int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x);
+/* What the caller needs to size ksplit for THIS shape: the column blocks of one split-K slice, the workgroup count to aim for and the
+ * tile height (rows of 16 output pixels per split-K step) of the kernel mia_conv_wgrad will pick -- 64-wide channel blocks cut per
+ * source, or the 96-wide blocks of 3x3 stride-1 bf16 layers whose channel counts are multiples of 96 and not of 64 (768 threads, one
+ * block where the 64-wide form needs 2 x 2).  Supersedes the two queries above for callers that know the channel counts. */
+int mia_wgrad_plan(int mode, int dtype, int c1, int c2, int cdy, int npad, int hy, int* column_blocks, int* target_blocks, int* tile_h);
 int mia_conv_wgrad(int mode, int dtype, const void* x1, int c1, const void* x2, int c2, const void* dy, int cdy,
                    float* slabs, int ksplit, int npad, int kpad, int n, int hx, int wx, int hy, int wy, const void* amax_x1,
                    const void* amax_x2, const void* amax_dy, void* stream); /* amax_*: as for mia_conv_mma */

@@ -921,6 +921,205 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_dma_kernel(const WgArgs a) 
   // (slab entries this block does not compute -- padded n / k tiles -- are never read: mia_wgrad_reduce sums n < nn, k < kk only)
 }
 
+// ---------------------------------------------------------------- bf16, LDS-DMA ring, 96-wide blocks (stride-1 3x3; cfg5's level 0)
+// Channel counts that are multiples of 96 and not of 64 cost the 64-wide kernel 2 x 2 blocks per 96 x 96 of dW: 1.78x the MFMAs and the
+// x / dy tiles fetched L2 -> LDS four times -- and that fill, not the MFMAs, is what the launch waits for (skipping the empty MFMA tiles
+// measured +-0 in round 4; a register-staged 96-wide block measured slower in round 5).  This is the ring kernel on 96-wide images:
+//   * a tile is 4 output rows x 16 pixels: x image [6 rows][24 pixels][96 ch] = 27 KB, dy image [64 px][96 ch] = 12 KB, as 32-channel
+//     subtiles of 8 pixels x 64 B (THREE per 8-pixel group, same chunk swizzle as the 64-wide image); ring of three images = 117 KB,
+//     one 768-thread workgroup per CU;
+//   * a DMA piece is 1 KB = two consecutive subtiles: 27 + 12 = 39 pieces per tile dealt round-robin to the twelve waves (3 or 4 each);
+//     lane L of a piece is chunk slot L & 3 of pixel (L >> 2) & 7 of subtile 2 p + (L >> 5), the source chunk un-swizzled, out-of-image /
+//     out-of-channel lanes pointing past the descriptor (zero fill).  Per-lane offsets are tile-invariant (relative to the tile origin,
+//     which rides in the descriptor); what changes per tile is which rows / columns exist;
+//   * waves = 6 input-channel tiles x 2 halves of the six output-channel tiles: 27 accumulator tiles, 54 MFMAs per wave and tile;
+//   * per tile: issue tile t + 2 -> MFMAs of tile t -> s_waitcnt vmcnt(own pieces of t + 2) -> s_barrier (the 64-wide kernel's protocol).
+template <int DUMMY>
+__global__ __launch_bounds__(768) void wgrad_bf16_dma96_kernel(const WgArgs a) {
+  constexpr int KS = 3, TAPS = 9, TH = 4, CW = 96;
+  constexpr int XH = TH + 2, XROW = 3 * 3 * 512;  // 24 pixels = 3 groups of 8, x 3 subtiles of 512 B
+  constexpr int X_BYTES = XH * XROW, D_BYTES = TH * 2 * 3 * 512, STAGE = X_BYTES + D_BYTES, NSTAGE = 3;
+  constexpr int XPIECES = X_BYTES / 1024, PIECES = XPIECES + D_BYTES / 1024;  // 27 + 12
+  constexpr int NWAVE = 12, MAXOWN = (PIECES + NWAVE - 1) / NWAVE, NC = 3;
+  static_assert(X_BYTES % 1024 == 0 && D_BYTES % 1024 == 0, "whole pieces");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
+  auto swz = [](int row, int ch) { return 512 * ((row >> 3) * 3 + (ch >> 2)) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3)); };
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = lane >> 4, i16 = lane & 15, qp = i16 >> 2, pp = i16 & 3;
+  const int ktile = wave % 6, nh = (wave / 6) * NC;
+  const int kb1 = (a.c1 + CW - 1) / CW, nkb = kb1 + (a.c2 + CW - 1) / CW;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (a.opt & 16) {  // XCD-aware order (1-D grid)
+    const int ncol = nkb * ((a.cdy + CW - 1) / CW), slot = bx >> 3;
+    by = (slot / ncol) * 8 + (bx & 7);
+    bx = slot % ncol;
+    if (by >= a.ksplit) return;
+  }
+  const int kblk = bx % nkb, nblk = bx / nkb;
+  const bool second = kblk >= kb1;
+  const int cs = second ? a.c2 : a.c1, kloc = (second ? kblk - kb1 : kblk) * CW;
+  const int n0 = nblk * CW, k0 = (second ? a.c1 : 0) + kloc;
+  const bf16_t* xsrc = static_cast<const bf16_t*>(second ? a.x2 : a.x1);
+  const bf16_t* dy = static_cast<const bf16_t*>(a.dy);
+  const unsigned lds0 = (unsigned)(size_t)(lds_u8*)smem;
+
+  // tile-invariant lane constants of this wave's pieces: byte offset from the tile origin (WSENT: padding pixel / channel tail) and the
+  // (row, column) the lane's pixel has inside the tile, to be checked against the image per tile
+  unsigned voffc[MAXOWN];
+  int rcc[MAXOWN];  // row << 8 | column (one register per piece: the kernel sits at the 168 registers three waves per SIMD allow)
+  const int hl = lane >> 5, r8 = (lane >> 2) & 7, slot4 = lane & 3;
+#pragma unroll
+  for (int j = 0; j < MAXOWN; ++j) {
+    const int pc = wave + NWAVE * j;
+    voffc[j] = WSENT; rcc[j] = 0;
+    if (pc < XPIECES) {
+      const int t = 2 * pc + hl;                       // subtile of the x image
+      const int iy = t / 9, gx = (t % 9) / 3, sub = t % 3;
+      const int px = 8 * gx + r8, c = 4 * sub + (slot4 ^ ((px >> 2) & 3));
+      rcc[j] = iy << 8 | px;
+      if (px < 18 && kloc + c * 8 < cs) voffc[j] = (unsigned)(((iy * a.Wx + px) * cs + kloc + c * 8) * 2);
+    } else if (pc < PIECES) {
+      const int t = 2 * (pc - XPIECES) + hl;           // subtile of the dy image
+      const int g8 = t / 3, sub = t % 3;
+      const int P = 8 * g8 + r8, c = 4 * sub + (slot4 ^ ((P >> 2) & 3));
+      rcc[j] = (P >> 4) << 8 | (P & 15);
+      if (n0 + c * 8 < a.cdy) voffc[j] = (unsigned)((((P >> 4) * a.Wy + (P & 15)) * a.cdy + n0 + c * 8) * 2);
+    }
+  }
+  auto issue = [&](int img, int ty, int tx, unsigned stage_base) {
+    const int oy0 = ty * TH, ox0 = tx * 16;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    // descriptor bases at the tile origin (may lie one row / one pixel in front of the image: those lanes are masked, nothing is read through them)
+    const long long xorg = ((long long)(img * a.Hx + iy0) * a.Wx + ix0) * cs;
+    const long long dorg = ((long long)(img * a.Hy + oy0) * a.Wy + ox0) * a.cdy;
+    // (ranges: the last tile row reaches 17 / 15 pixels past its first column, which is more than an image row when the image is
+    // narrower than the tile -- the per-lane row / column masks, not the range, keep the loads inside the tensor)
+    const wi32x4 rx = wmake_rsrc_i(xsrc + xorg, (unsigned)((XH * a.Wx + 24) * cs * 2));
+    const wi32x4 rd = wmake_rsrc_i(dy + dorg, (unsigned)((TH * a.Wy + 16) * a.cdy * 2));
+    const unsigned m0base = stage_base + wave * 1024;  // piece pc of the tile image lives at byte 1024 pc
+#pragma unroll
+    for (int j = 0; j < MAXOWN; ++j) {
+      const int pc = wave + NWAVE * j;  // wave-uniform
+      if (pc < XPIECES) {
+        const bool ok = ((unsigned)(iy0 + (rcc[j] >> 8)) < (unsigned)a.Hx) & ((unsigned)(ix0 + (rcc[j] & 255)) < (unsigned)a.Wx);
+        lds_dma16(rx, ok ? voffc[j] : WSENT, m0base + NWAVE * 1024 * j);
+      } else if (pc < PIECES) {
+        const bool ok = (oy0 + (rcc[j] >> 8) < a.Hy) & (ox0 + (rcc[j] & 255) < a.Wy);
+        lds_dma16(rd, ok ? voffc[j] : WSENT, m0base + NWAVE * 1024 * j);
+      }
+    }
+  };
+  auto wait_own_in_flight = [&]() {  // all but the newest tile's own pieces have landed
+    if (wave < (PIECES % NWAVE)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXOWN) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXOWN - 1) : "memory");
+  };
+
+  f32x4 acc[TAPS][NC];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // lane-constant fragment bases (absolute LDS bytes of the CURRENT stage; stepped by one stage per tile)
+  const int g1 = grp >> 1, xb0 = 8 * (grp & 1) + qp, sub8 = 8 * (pp & 1);
+  unsigned dbase[NC][2], xbase[KS][2];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    dbase[c][0] = lds0 + X_BYTES + swz(g1 * 16 + xb0, 2 * (nh + c) + (pp >> 1)) + sub8;
+    dbase[c][1] = lds0 + X_BYTES + swz(g1 * 16 + xb0 + 4, 2 * (nh + c) + (pp >> 1)) + sub8;
+  }
+#pragma unroll
+  for (int kw = 0; kw < KS; ++kw) {
+    xbase[kw][0] = lds0 + g1 * XROW + swz(xb0 + kw, 2 * ktile + (pp >> 1)) + sub8;
+    xbase[kw][1] = lds0 + g1 * XROW + swz(xb0 + kw + 4, 2 * ktile + (pp >> 1)) + sub8;
+  }
+
+  const int ntiles = a.N * a.tiles_x * a.tiles_y;
+  int tile = by;
+  int t_tx, t_ty, t_img;  // digits of the NEXT tile to issue
+  { int tt = tile; t_tx = tt % a.tiles_x; tt /= a.tiles_x; t_ty = tt % a.tiles_y; t_img = tt / a.tiles_y; }
+  int d_tx, d_ty, d_img;
+  { int tt = a.ksplit; d_tx = tt % a.tiles_x; tt /= a.tiles_x; d_ty = tt % a.tiles_y; d_img = tt / a.tiles_y; }
+  auto advance = [&]() {
+    t_tx += d_tx; if (t_tx >= a.tiles_x) { t_tx -= a.tiles_x; t_ty += 1; }
+    t_ty += d_ty; if (t_ty >= a.tiles_y) { t_ty -= a.tiles_y; t_img += 1; }
+    t_img += d_img;
+  };
+  int issue_tile = tile;
+  unsigned issue_stage = 0;
+#pragma unroll 1
+  for (int s_ = 0; s_ < 2; ++s_) {  // prologue: two tiles in flight
+    if (issue_tile < ntiles) { issue(t_img, t_ty, t_tx, lds0 + issue_stage * STAGE); advance(); }
+    issue_tile += a.ksplit;
+    issue_stage = issue_stage == NSTAGE - 1 ? 0 : issue_stage + 1;
+  }
+  if (tile + a.ksplit < ntiles) wait_own_in_flight(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int stage = 0;
+  for (; tile < ntiles; tile += a.ksplit) {
+    const bool more = issue_tile < ntiles;
+    if (more) { issue(t_img, t_ty, t_tx, lds0 + issue_stage * STAGE); advance(); }
+    issue_tile += a.ksplit;
+    issue_stage = issue_stage == NSTAGE - 1 ? 0 : issue_stage + 1;
+
+    {
+      u32x4 af[NC], bf[3];  // (ONE set of dy fragments, reloaded between the two row blocks: a second set does not fit 168 registers)
+      auto load_a = [&](int kb, int c) -> u32x4 {  // 32 pixels = 4 groups of 8 x 3 subtiles = 6144 B per row block
+        const s16x4 lo = tr_read_at(dbase[c][0] + 6144 * kb);
+        const s16x4 hi = tr_read_at(dbase[c][1] + 6144 * kb);
+        return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      };
+      auto load_b = [&](int step) -> u32x4 {  // step = kb * 9 + tap
+        const int kb = step / TAPS, t = step % TAPS, kh = t / KS, kw = t % KS;
+        const s16x4 lo = tr_read_at(xbase[kw][0] + XROW * (2 * kb + kh));
+        const s16x4 hi = tr_read_at(xbase[kw][1] + XROW * (2 * kb + kh));
+        return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      };
+#pragma unroll
+      for (int c = 0; c < NC; ++c) af[c] = load_a(0, c);
+      bf[0] = load_b(0);
+      bf[1] = load_b(1);
+#pragma unroll
+      for (int step = 0; step < 2 * TAPS; ++step) {
+        const int kb = step / TAPS, t = step % TAPS;
+        if (step + 2 < 2 * TAPS) bf[(step + 2) % 3] = load_b(step + 2);
+        if (step == TAPS) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) af[c] = load_a(1, c);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[c]), __builtin_bit_cast(bf16x8, bf[step % 3]),
+                                                              acc[t][c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const int delta = stage == NSTAGE - 1 ? -(NSTAGE - 1) * STAGE : STAGE;
+    stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { dbase[c][0] += delta; dbase[c][1] += delta; }
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw) { xbase[kw][0] += delta; xbase[kw][1] += delta; }
+    if (more) wait_own_in_flight(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  float* slab = a.slabs + (size_t)by * TAPS * a.npad * a.kpad;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + (nh + c) * 16 + 4 * grp + r, k = k0 + ktile * 16 + i16;
+        if (kloc + ktile * 16 + i16 < cs && n < a.npad) slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+      }
+}
+
 // ---------------------------------------------------------------- bf16, 512-thread big block (stride-1 3x3, cdy % 128 == 0)
 // Round 3.  wgrad_bf16_dma_kernel moves 92 bytes L2 -> LDS per MFMA (an 18 KB x tile + an 8 KB dy tile per 288 MFMAs) and runs two
 // 256-thread workgroups per CU.  Here ONE 512-thread workgroup per CU owns a 128 n x 64 k x 9 taps block: waves 0-3 take output
@@ -1956,6 +2155,35 @@ extern "C" int mia_wgrad_debug_occupancy(int which) {
 }
 #endif
 
+// 96-wide blocks (wgrad_bf16_dma96_kernel): 3x3 stride 1, bf16, every channel count a multiple of 96 and at least one of them not a
+// multiple of 64 (cfg5's level 0: 96 -> 96 and (96 | 96) -> 96).
+#ifndef MIA_WGRAD_W96
+#define MIA_WGRAD_W96 1  /* 0: probe builds that A/B against the 64-wide blocks */
+#endif
+static bool wgrad_w96(const MiaOptions& o, int mode, int dtype, int c1, int c2, int cdy) {
+  if (!MIA_WGRAD_W96 || dtype != MIA_BF16 || mode != MODE_W3S1 || !o.wgrad_dma) return false;
+  if (c1 % 96 != 0 || c2 % 96 != 0 || cdy % 96 != 0) return false;
+  return c1 % 64 != 0 || cdy % 64 != 0 || (c2 != 0 && c2 % 64 != 0);
+}
+
+/* Column blocks of one split-K slice, the workgroup count to aim for and the tile height of the kernel mia_conv_wgrad will pick for THIS
+   shape (the caller sizes ksplit from them: ops.conv_wgrad). */
+extern "C" int mia_wgrad_plan(int mode, int dtype, int c1, int c2, int cdy, int npad, int hy, int* column_blocks, int* target_blocks,
+                              int* tile_h) {
+  const MiaOptions o = mia_options();
+  const int cus = o.reserve_cus > 0 ? ((256 - o.reserve_cus) & ~7) : 256;
+  if (wgrad_w96(o, mode, dtype, c1, c2, cdy)) {
+    if (column_blocks) *column_blocks = ceil_div(cdy, 96) * (ceil_div(c1, 96) + ceil_div(c2, 96));
+    if (target_blocks) *target_blocks = cus < 8 ? 8 : cus;  // one 768-thread workgroup per CU
+    if (tile_h) *tile_h = 4;
+    return MIA_OK;
+  }
+  if (column_blocks) *column_blocks = (npad / 64) * (ceil_div(c1, 64) + ceil_div(c2, 64));
+  if (target_blocks) *target_blocks = mia_wgrad_target_blocks(mode, dtype);
+  if (tile_h) *tile_h = wgrad_tile_h(o, mode, dtype, hy, true);
+  return MIA_OK;
+}
+
 extern "C" int mia_wgrad_geometry(int mode, int dtype, int hy, int wy, int* tiles_y, int* tiles_x) {
   const int th = wgrad_tile_h(mia_options(), mode, dtype, hy, true);  // the finest tiling any kernel of this mode uses (bounds ksplit)
   if (tiles_y) *tiles_y = ceil_div(hy, th);
@@ -2016,7 +2244,12 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
   const int th = wgrad_tile_h(o, mode, dtype, hy, fast);
   a.tiles_y = ceil_div(hy, th);
   a.tiles_x = ceil_div(wy, 16);
-  if (fast && th == 4 && mode == MODE_W3S1 && o.wgrad_bt && cdy % 128 == 0 && npad % 128 == 0) {
+  if (fast && wgrad_w96(o, mode, dtype, c1, c2, cdy)) {  // 96-wide ring blocks: one block per pixel tile where 64-wide ones need 2 x 2
+    const unsigned ncol = (unsigned)(ceil_div(cdy, 96) * (ceil_div(c1, 96) + ceil_div(c2, 96)));
+    const dim3 wgrid = (a.opt & 16) ? dim3(ncol * (unsigned)(ceil_div(ksplit, 8) * 8), 1) : dim3(ncol, ksplit);
+    a.tiles_y = ceil_div(hy, 4);
+    hipLaunchKernelGGL(wgrad_bf16_dma96_kernel<0>, wgrid, dim3(768), 0, st, a);
+  } else if (fast && th == 4 && mode == MODE_W3S1 && o.wgrad_bt && cdy % 128 == 0 && npad % 128 == 0) {
     // 512-thread workgroups on 128 n x 64 k blocks: half as many column blocks
     dim3 bgrid(fgrid.x / 2, fgrid.y);
     hipLaunchKernelGGL(wgrad_bf16_bt_kernel, bgrid, dim3(512), 0, st, a);

@@ -13,7 +13,7 @@ OBJ = os.path.join(HERE, "_obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
 # Kernels that issue LDS-DMA in inline asm and count `vmcnt` by hand: a register spill would add compiler-made scratch
 # traffic to the same counter and break the count, so the build fails unless their scratch size is 0.
-COUNTED_VMCNT = {"conv_bt.hip": ("conv_bt_kernel",), "conv_pw.hip": ("conv_pw_kernel",), "conv64_dma.hip": ("conv64_dma_kernel",), "conv_wgrad.hip": ("wgrad_bf16_dma_kernel", "wgrad_bf16_bt_kernel", "wgrad_bf16_bt_s2_kernel", "wgrad_bf16_bt_t2_kernel")}
+COUNTED_VMCNT = {"conv_bt.hip": ("conv_bt_kernel",), "conv_pw.hip": ("conv_pw_kernel",), "conv64_dma.hip": ("conv64_dma_kernel",), "conv_wgrad.hip": ("wgrad_bf16_dma_kernel", "wgrad_bf16_dma96_kernel", "wgrad_bf16_bt_kernel", "wgrad_bf16_bt_s2_kernel", "wgrad_bf16_bt_t2_kernel")}
 
 
 def sources():

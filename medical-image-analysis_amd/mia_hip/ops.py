@@ -437,15 +437,17 @@ def conv_wgrad(mode: int, x1: torch.Tensor, x2: Optional[torch.Tensor], dy: torc
     dtype = _dt(x1)
     taps = 4 if mode == WGRAD_2S2 else 9
     npad, kpad = _pad(nn, 64), _pad(kk, 64)
-    ty, tx = _c_int(), _c_int()
-    call("mia_wgrad_geometry", mode, dtype, hy, wy, ctypes.byref(ty), ctypes.byref(tx))
-    ntiles = n * ty.value * tx.value
+    # column blocks of one split-K slice, workgroups to aim for and the tile height of the kernel the library will pick for this shape
+    # (mia_wgrad_plan: 64-wide blocks cut per source, or 96-wide ones where every channel count is a multiple of 96 and not of 64)
+    pb, pt, ph = _c_int(), _c_int(), _c_int()
+    call("mia_wgrad_plan", mode, dtype, c1, c2, cdy, npad, hy, ctypes.byref(pb), ctypes.byref(pt), ctypes.byref(ph))
+    ntiles = n * -(-hy // ph.value) * -(-wy // 16)
     # column blocks of one split-K slice: the kernels cut the input channels per SOURCE (ceil(c1 / 64) + ceil(c2 / 64) blocks, which
     # is more than kpad / 64 when neither source is a multiple of 64: cfg5's 96 + 96), and the XCD-aware launch order needs a split
     # count that is a multiple of 8 (86, 57 or 29 slices dropped those launches to the plain 2-D order and overfilled the chip:
     # 688 workgroups for 512 slots on cfg5's 192 -> 96 gradient)
-    base = (npad // 64) * (-(-c1 // 64) + -(-c2 // 64))
-    target = WGRAD_TARGET_BLOCKS or lib().mia_wgrad_target_blocks(mode, dtype)
+    base = pb.value
+    target = WGRAD_TARGET_BLOCKS or pt.value
     ksplit = max(1, min(ntiles, -(-target // base), 1024))
     if 8 <= ksplit < ntiles:  # (one tile per slice already: a small problem, leave it)
         ksplit -= ksplit % 8

@@ -128,6 +128,35 @@ def test_conv3x3_fwd_dgrad_wgrad(case, stride, dtype):
     assert relerr(ops.colsum(dyd), dy.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 96, 0, 96, 24, 40), (1, 96, 96, 96, 19, 33), (1, 192, 0, 96, 12, 52), (3, 96, 0, 192, 9, 17), (1, 96, 96, 96, 4, 16),
+                                  (1, 288, 0, 96, 11, 21), (2, 96, 0, 96, 3, 5)])
+def test_weight_gradient_on_96_wide_blocks(case):
+    """`wgrad_bf16_dma96_kernel` (csrc/conv_wgrad.hip): 3x3 stride-1 bf16 layers whose channel counts are multiples of 96 and not of 64
+    (cfg5's level 0) run ONE 96 x 96 block per pixel tile on the LDS-DMA ring (768 threads, 192-byte-row images) where the 64-wide kernel
+    needs 2 x 2 blocks.  One and two sources, several blocks per dimension, ragged and tiny images (tiles hanging over every border);
+    bf16 inputs quantised on both sides, so the result differs from the fp32 reference by summation order only.  `mia_wgrad_plan` must
+    report the blocks / target / tile height the launch then uses."""
+    import ctypes
+    from mia_hip import ops, BF16, WGRAD_3S1
+    dev = _dev()
+    n, c1, c2, cout, h, w = case
+    cin = c1 + c2
+    g = torch.Generator().manual_seed(cin + cout + h)
+    dt = torch.bfloat16
+    x = q(torch.randn(n, cin, h, w, generator=g), dt)
+    dy = q(torch.randn(n, cout, h, w, generator=g), dt)
+    wt = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(x, wt, None, stride=1, padding=1).backward(dy)
+    x1 = nhwc(x[:, :c1], dt, dev)
+    x2 = nhwc(x[:, c1:], dt, dev) if c2 else None
+    dw = ops.conv_wgrad(WGRAD_3S1, x1, x2, nhwc(dy, dt, dev), wt.shape, cout, cin)
+    assert relerr(dw, wt.grad) < 2e-3
+    pb, pt, ph = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    ops.call("mia_wgrad_plan", WGRAD_3S1, BF16, c1, c2, cout, -(-cout // 64) * 64, h, ctypes.byref(pb), ctypes.byref(pt), ctypes.byref(ph))
+    assert (pb.value, pt.value, ph.value) == (-(-cout // 96) * (-(-c1 // 96) + -(-c2 // 96)), 256, 4)
+
+
 # Every distinct 3x3 conv of the benchmarked models at their own widths (VERDICT r1 weak #2: the golden UNets are 4..20
 # channels wide and never reach the branch-free kernels): [64..1024] (cfg2 / cfg3) on the 128x128-input pyramid, encoder
 # (one source; stride 2 = first block of the next level), decoder (two sources = skip | upsampled), plus cfg5's
