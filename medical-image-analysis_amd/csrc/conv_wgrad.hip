@@ -203,13 +203,18 @@ __device__ __forceinline__ wrsrc_t wmake_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
-template <int MODE, int TH>
-__global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
+// W8 (round 5): 512 threads -- eight waves = 4 input-channel tiles x 2 halves of the block's output channels, 72 accumulator registers per
+// wave.  The 256-thread form compiles to 436-464 registers (accumulators parked in AGPRs): ONE wave per SIMD, staging and MFMAs never
+// overlapping (0.37 PFLOP/s on cfg5's 96 -> 192 stride-2 and 192 -> 96 transposed gradients, the only launches that still use it).
+template <int MODE, int TH, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256) void wgrad_bf16_fast_kernel(const WgArgs a) {
   using G = WGeo<MODE>;
   constexpr int KS = G::KS, S = G::S, PAD = G::PAD, TAPS = G::TAPS;
   constexpr int XH = (TH - 1) * S + KS, XW = 15 * S + KS;
-  constexpr int X_IT = (XH * XW + 31) / 32, D_IT = TH * 16 / 32;  // 32 pixels x 8 chunks per iteration
-  constexpr int X_BYTES = X_IT * 32 * 128, D_BYTES = TH * 16 * 128;
+  constexpr int PPI = W8 ? 64 : 32;  // pixels x 8 chunks per staging iteration
+  constexpr int X_IT = (XH * XW + PPI - 1) / PPI, D_IT = (TH * 16 + PPI - 1) / PPI;
+  constexpr int X_BYTES = X_IT * PPI * 128, D_BYTES = D_IT * PPI * 128;
+  constexpr int NC = W8 ? 2 : 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[X_BYTES + D_BYTES];
   unsigned char* xs = smem;
   unsigned char* ds = smem + X_BYTES;
@@ -217,6 +222,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = lane >> 4, i16 = lane & 15, qp = i16 >> 2, pp = i16 & 3;
   const int ch8 = tid & 7, p8 = tid >> 3;
+  const int kq = W8 ? (wave & 3) : wave, nh = W8 ? 2 * (wave >> 2) : 0;  // input-channel tile; first output-channel tile of this wave
   // 64-channel input blocks are cut per SOURCE (ceil(c1/64) + ceil(c2/64) of them), so a block never straddles the
   // two tensors of a concatenated input whatever c1 is; a source's last block may be partial (lanes beyond cs read
   // zeros and do not store)
@@ -240,17 +246,17 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
   int x_iy[X_IT], x_ix[X_IT];
 #pragma unroll
   for (int i = 0; i < X_IT; ++i) {
-    const int pix = p8 + 32 * i;
+    const int pix = p8 + PPI * i;
     x_iy[i] = pix < XH * XW ? pix / XW : -100000;
     x_ix[i] = pix - (pix / XW) * XW;
   }
-  const int lds_x0 = swz_off(p8, ch8), lds_d0 = swz_off(p8, ch8);  // + 4096 per iteration (32 rows)
+  const int lds_x0 = swz_off(p8, ch8), lds_d0 = swz_off(p8, ch8);  // + 128 PPI per iteration (PPI rows)
 
-  f32x4 acc[TAPS][4];
+  f32x4 acc[TAPS][NC];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NC; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 px[X_IT], pd[D_IT];
   const int ntiles = a.N * a.tiles_x * a.tiles_y;
@@ -272,9 +278,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < D_IT; ++i) {
-      const int pix = p8 + 32 * i;
+      const int pix = p8 + PPI * i;
       const int gy = oy0 + (pix >> 4), gx = ox0 + (pix & 15);
-      const bool ok = gy < a.Hy && gx < a.Wy;
+      const bool ok = pix < TH * 16 && gy < a.Hy && gx < a.Wy;
       const unsigned voff = (ok && n0 + ch8 * 8 < a.cdy) ? (unsigned)(((gy * a.Wy + gx) * a.cdy + n0 + ch8 * 8) * 2) : WSENT;
       pd[i] = __builtin_amdgcn_raw_buffer_load_b128(rd, (int)voff, 0, 0);
     }
@@ -285,18 +291,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
   for (; tile < ntiles; tile += a.ksplit) {
     __syncthreads();  // previous tile's fragment reads are done
 #pragma unroll
-    for (int i = 0; i < X_IT; ++i) *reinterpret_cast<u32x4*>(xs + lds_x0 + 4096 * i) = px[i];
+    for (int i = 0; i < X_IT; ++i) *reinterpret_cast<u32x4*>(xs + lds_x0 + 128 * PPI * i) = px[i];
 #pragma unroll
-    for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(ds + lds_d0 + 4096 * i) = pd[i];
+    for (int i = 0; i < D_IT; ++i) *reinterpret_cast<u32x4*>(ds + lds_d0 + 128 * PPI * i) = pd[i];
     __syncthreads();
     if (tile + a.ksplit < ntiles) fetch(tile + a.ksplit);
 #pragma unroll(TH <= 8 ? TH / 2 : 2)
     for (int kb = 0; kb < TH / 2; ++kb) {
       const int yy = 2 * kb + (grp >> 1), xb = 8 * (grp & 1) + qp;
-      u32x4 af[4];
+      u32x4 af[NC];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int ch = 2 * c + (pp >> 1);
+      for (int c = 0; c < NC; ++c) {
+        const int ch = 2 * (nh + c) + (pp >> 1);
         const int r0 = yy * 16 + xb;
         const s16x4 lo = tr_read(ds, swz_off(r0, ch) + 8 * (pp & 1));
         const s16x4 hi = tr_read(ds, swz_off(r0 + 4, ch) + 8 * (pp & 1));
@@ -306,13 +312,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
       for (int kh = 0; kh < KS; ++kh) {
 #pragma unroll
         for (int kw = 0; kw < KS; ++kw) {
-          const int ch = 2 * wave + (pp >> 1);
+          const int ch = 2 * kq + (pp >> 1);
           const int r0 = (yy * S + kh) * XW + xb * S + kw;
           const s16x4 lo = tr_read(xs, swz_off(r0, ch) + 8 * (pp & 1));
           const s16x4 hi = tr_read(xs, swz_off(r0 + 4 * S, ch) + 8 * (pp & 1));
           const bf16x8 b = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
+          for (int c = 0; c < NC; ++c)
             acc[kh * KS + kw][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[c]), b,
                                                                              acc[kh * KS + kw][c], 0, 0, 0);
         }
@@ -323,11 +329,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_fast_kernel(const WgArgs a) {
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + c * 16 + 4 * grp + r, k = k0 + wave * 16 + i16;
-        if (kloc + wave * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
+        const int n = n0 + (nh + c) * 16 + 4 * grp + r, k = k0 + kq * 16 + i16;
+        if (kloc + kq * 16 + i16 < cs) slab[((size_t)t * a.npad + n) * a.kpad + k] = acc[t][c][r];
       }
 }
 
@@ -2268,8 +2274,8 @@ static int conv_wgrad_run(int mode, int dtype, const void* x1, int c1, const voi
   } else if (fast) {
     if (mode == MODE_W3S1 && th == 16) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 16>), fgrid, dim3(256), 0, st, a);
     else if (mode == MODE_W3S1) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S1, 8>), fgrid, dim3(256), 0, st, a);
-    else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S2, 4>), fgrid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W2S2, 4>), fgrid, dim3(256), 0, st, a);
+    else if (mode == MODE_W3S2) hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W3S2, 4, true>), fgrid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_bf16_fast_kernel<MODE_W2S2, 4>), fgrid, dim3(256), 0, st, a);  // (four taps: 172 registers, two waves per SIMD as it is; the 512-thread form measured 10 % slower)
   } else if (dtype == MIA_F32 && chan_ok && (size_t)hx * wx * (c1 > c2 ? c1 : c2) * 4 < lim &&
              (size_t)hy * wy * cdy * 4 < lim) {
     const bool narrow = cdy <= 32 && c1 <= 32 && c2 <= 32;  // 32-channel layers: half-width blocks, all four waves busy
