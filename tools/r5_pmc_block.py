@@ -13,7 +13,7 @@ ROLES = (("conv64_persist_kernel<true", "conv_nl"), ("conv64_persist_kernel<fals
          ("conv_mma_fast_kernel", "conv_or_dgrad"), ("norm_fwd_sum_kernel", "norm_finalize"), ("norm_finalize_kernel", "norm_finalize2"),
          ("norm_act_fwd_stream_kernel", "norm_act_fwd"), ("colreduce_vec_kernel", "bwd_colreduce"), ("norm_bwd_finalize_kernel", "bwd_finalize"),
          ("norm_bwd_sum_kernel", "bwd_sum"), ("norm_act_bwd_stream_kernel", "norm_act_bwd"), ("wgrad_bf16_2wg_kernel<8, true>", "wgrad_nl"),
-         ("wgrad_bf16_dma_kernel", "wgrad"), ("wgrad_bf16_bt_kernel", "wgrad"), ("wgrad_f32_fast_kernel", "wgrad"), ("wgrad_reduce", "wgrad_reduce"),
+         ("wgrad_bf16_dma96_kernel", "wgrad"), ("wgrad_bf16_dma_kernel", "wgrad"), ("wgrad_bf16_bt_kernel", "wgrad"), ("wgrad_f32_fast_kernel", "wgrad"), ("wgrad_reduce", "wgrad_reduce"),
          ("amax_kernel", "amax"))
 
 
