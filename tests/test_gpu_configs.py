@@ -241,15 +241,16 @@ def test_f32_exact_and_split_everywhere_train_steps_meet_the_fp32_gates(channels
         ops.F32_SPLIT_MIN_MACS = old_gate
 
 
-def test_full_width_bf16_train_step_vs_fp32_oracle():
+@pytest.mark.parametrize("channels,size", [([64, 128, 256, 512, 1024], 128), ([96, 192, 384, 768], 96)])
+def test_full_width_bf16_train_step_vs_fp32_oracle(channels, size):
     """The benchmark's dtype at the benchmark's widths vs the fp32 CPU oracle: logits, loss, label maps, every weight
     gradient (tolerances and their derivation: BF16_* above)."""
     dev = _dev()
     torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
-    channels, k1, norm = [64, 128, 256, 512, 1024], 3, "instance"
+    k1, norm = 3, "instance"  # (second case: cfg5's 96-multiples -- the 96-wide weight-gradient blocks and channel blocks of conv_bt inside a full step)
     m = _model(dev, channels, norm, k1, torch.bfloat16).train()
     state = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-    x, y = _batch(2, 128, seed=3)
+    x, y = _batch(2, size, seed=3)
     ref_logits, ref_loss, ref_grads, _, _ = _oracle_step(state, x, y, k1, norm, 1e-3)
     out = m(x.to(dev))
     loss = _loss_fn(k1)(out, y.to(dev))
@@ -271,14 +272,15 @@ def test_full_width_bf16_train_step_vs_fp32_oracle():
         rel = float((got - ref).norm() / ref.norm())
         cos = float((got * ref).sum() / (got.norm() * ref.norm()))
         report.append((name, rel, cos))
-        shallow = name.startswith(("decoder.seg_output", "decoder.levels.3.", "decoder.upsamples.3"))
+        last = len(channels) - 2
+        shallow = name.startswith(("decoder.seg_output", f"decoder.levels.{last}.", f"decoder.upsamples.{last}"))
         assert rel < (BF16_SHALLOW_REL_L2 if shallow else BF16_DEEP_REL_L2), (name, rel)
         assert cos > BF16_DEEP_COS, (name, cos)
     fg, fr = torch.cat(flat_got), torch.cat(flat_ref)
     flat_cos = float((fg * fr).sum() / (fg.norm() * fr.norm()))
     assert flat_cos > BF16_FLAT_COS, flat_cos
     worst = max(report, key=lambda t: t[1])
-    print(f"[bf16 64..1024 128x128x2] logit err {lerr:.2e} of range {rng:.2f}, loss {loss.item():.5f} vs {ref_loss:.5f}, "
+    print(f"[bf16 {channels[0]}..{channels[-1]} {size}x{size}x2] logit err {lerr:.2e} of range {rng:.2f}, loss {loss.item():.5f} vs {ref_loss:.5f}, "
           f"safe-margin pixels {float(safe.float().mean()):.3f}, worst rel-L2 {worst[1]:.3f} (cos {worst[2]:.3f}) at {worst[0]}, "
           f"flat cos {flat_cos:.4f}")
 
