@@ -233,28 +233,42 @@ static int head_fast_upp(int dtype, int c0, int k1, int64_t npix, int64_t sn, in
     }                                                                                                                 \
   } while (0)
 
+// the fused norm + head kernels also take twelve units per pixel (96 bf16 / 48 fp32 channels) on groups of sixteen lanes
+#define HEAD_DISPATCH_N(KERNEL, T, grid, ...)                                                                         \
+  do {                                                                                                                \
+    if (upp == 12) {                                                                                                  \
+      if (k1 == 2) hipLaunchKernelGGL((KERNEL<T, 2, 16, 12>), grid, dim3(256), 0, st, __VA_ARGS__);                   \
+      else if (k1 == 3) hipLaunchKernelGGL((KERNEL<T, 3, 16, 12>), grid, dim3(256), 0, st, __VA_ARGS__);              \
+      else hipLaunchKernelGGL((KERNEL<T, 4, 16, 12>), grid, dim3(256), 0, st, __VA_ARGS__);                           \
+    } else HEAD_DISPATCH(KERNEL, T, grid, __VA_ARGS__);                                                               \
+  } while (0)
+
 
 // ---------------------------------------------------------------- head fused with the last block's norm + LeakyReLU
 // The last decoder block's activated output z = lrelu(scale*y + shift) has exactly one consumer, the 1x1 head.  These
 // kernels recompute it from the raw conv output y on load (per-(image, channel) scale / shift in registers: a block
 // works inside one image), so z is never written or read: the forward apply pass and one activation round trip vanish.
-template <typename T, int K1, int UPP>
+// CU < UPP (round 5: 96 channels in bf16 = 12 units dealt to groups of 16 lanes): lanes CU .. UPP - 1 of a pixel group load nothing and
+// hold zero coefficients, so the group sums and every address (C0 = CU units) stay right; 25 % idle lanes on a memory-bound pass.
+template <typename T, int K1, int UPP, int CU = UPP>
 __global__ __launch_bounds__(256) void head_norm_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float slope,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             float* __restrict__ out, int hw, int slabs, int64_t osn,
                                                             int64_t osp, int64_t osk) {
-  constexpr int EPU = Elem<T>::EPU, C0 = UPP * EPU, LANES = 256 / UPP;
+  constexpr int EPU = Elem<T>::EPU, C0 = CU * EPU, LANES = 256 / UPP;
   const int u = threadIdx.x % UPP, pl = threadIdx.x / UPP;
+  const bool act = CU == UPP || u < CU;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
   const int per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
   float wr[K1][EPU], sc[EPU], sf[EPU];
 #pragma unroll
   for (int e = 0; e < EPU; ++e) {
-    sc[e] = scale[(size_t)n * C0 + u * EPU + e];
-    sf[e] = shift[(size_t)n * C0 + u * EPU + e];
+    sc[e] = act ? scale[(size_t)n * C0 + u * EPU + e] : 0.f;
+    sf[e] = act ? shift[(size_t)n * C0 + u * EPU + e] : 0.f;
 #pragma unroll
-    for (int k = 0; k < K1; ++k) wr[k][e] = w[k * C0 + u * EPU + e];
+    for (int k = 0; k < K1; ++k) wr[k][e] = act ? w[k * C0 + u * EPU + e] : 0.f;
   }
   float bu = 0.f;
 #pragma unroll
@@ -291,7 +305,7 @@ __global__ __launch_bounds__(256) void head_norm_fwd_kernel(const T* __restrict_
   for (int q0 = r0 + wave * 64; q0 < r0 + nbulk; q0 += 256) {
     u32x4 raw[UPP];
 #pragma unroll
-    for (int j = 0; j < UPP; ++j) raw[j] = *reinterpret_cast<const u32x4*>(yb + (size_t)(q0 + j * GP + gl) * C0);
+    for (int j = 0; j < UPP; ++j) raw[j] = act ? *reinterpret_cast<const u32x4*>(yb + (size_t)(q0 + j * GP + gl) * C0) : zero4;
 #pragma unroll
     for (int j = 0; j < UPP; ++j) {
       alignas(16) T v[EPU];
@@ -319,25 +333,27 @@ __global__ __launch_bounds__(256) void head_norm_fwd_kernel(const T* __restrict_
     for (int k = 0; k < K1; ++k) on[k * osk] = tb[k * 64 + lane];
     __builtin_amdgcn_wave_barrier();
   }
-  for (int p = r0 + nbulk + pl; p < r1; p += LANES) body(*reinterpret_cast<const u32x4*>(yb + (size_t)p * C0), p);
+  for (int p = r0 + nbulk + pl; p < r1; p += LANES) body(act ? *reinterpret_cast<const u32x4*>(yb + (size_t)p * C0) : zero4, p);
 }
 
 // part: [gridDim.x][K1][C0 + 1] like head_bwd_weight_fast_kernel, with x = lrelu(scale*y + shift) recomputed
-template <typename T, int K1, int UPP>
+template <typename T, int K1, int UPP, int CU = UPP>  // (CU < UPP: see head_norm_fwd_kernel)
 __global__ __launch_bounds__(256) void head_norm_wgrad_kernel(const float* __restrict__ dl, const T* __restrict__ y,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               float slope, float* __restrict__ part, int hw, int slabs,
                                                               int64_t gsn, int64_t gsp, int64_t gsk) {
-  constexpr int EPU = Elem<T>::EPU, C0 = UPP * EPU, LANES = 256 / UPP, SHS = C0 + 1;
+  constexpr int EPU = Elem<T>::EPU, C0 = CU * EPU, LANES = 256 / UPP, SHS = C0 + 1;
   __shared__ float shd[LANES * SHS];
   const int u = threadIdx.x % UPP, pl = threadIdx.x / UPP;
+  const bool act = CU == UPP || u < CU;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const int n = blockIdx.x / slabs, s = blockIdx.x % slabs;
   const int per = (hw + slabs - 1) / slabs, r0 = s * per, r1 = r0 + per < hw ? r0 + per : hw;
   float sc[EPU], sf[EPU], acc[K1][EPU], bacc[K1];
 #pragma unroll
   for (int e = 0; e < EPU; ++e) {
-    sc[e] = scale[(size_t)n * C0 + u * EPU + e];
-    sf[e] = shift[(size_t)n * C0 + u * EPU + e];
+    sc[e] = act ? scale[(size_t)n * C0 + u * EPU + e] : 0.f;
+    sf[e] = act ? shift[(size_t)n * C0 + u * EPU + e] : 0.f;
   }
 #pragma unroll
   for (int k = 0; k < K1; ++k) {
@@ -365,7 +381,7 @@ __global__ __launch_bounds__(256) void head_norm_wgrad_kernel(const float* __res
     u32x4 raw[4];
     float gv[4][K1];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) raw[j] = *reinterpret_cast<const u32x4*>(yb + (size_t)(p + j * LANES) * C0);
+    for (int j = 0; j < 4; ++j) raw[j] = act ? *reinterpret_cast<const u32x4*>(yb + (size_t)(p + j * LANES) * C0) : zero4;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -377,13 +393,14 @@ __global__ __launch_bounds__(256) void head_norm_wgrad_kernel(const float* __res
     float gv[K1];
 #pragma unroll
     for (int k = 0; k < K1; ++k) gv[k] = gb[(int64_t)p * gsp + k * gsk];
-    body(*reinterpret_cast<const u32x4*>(yb + (size_t)p * C0), gv);
+    body(act ? *reinterpret_cast<const u32x4*>(yb + (size_t)p * C0) : zero4, gv);
   }
 #pragma unroll
   for (int k = 0; k < K1; ++k) {
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < EPU; ++e) shd[pl * SHS + u * EPU + e] = acc[k][e];
+    for (int e = 0; e < EPU; ++e)
+      if (act) shd[pl * SHS + u * EPU + e] = acc[k][e];
     if (u == 0) shd[pl * SHS + C0] = bacc[k];
     __syncthreads();
     if (threadIdx.x <= C0) {
@@ -639,7 +656,7 @@ extern "C" int mia_head_norm_eligible(int dtype, int n, int64_t hw, int c0, int 
   const int epu = dtype == MIA_BF16 ? 8 : 4;
   if ((dtype != MIA_BF16 && dtype != MIA_F32) || c0 % epu != 0) return 0;
   const int upp = c0 / epu;
-  if ((upp != 4 && upp != 8 && upp != 16) || k1 < 2 || k1 > 4) return 0;
+  if ((upp != 4 && upp != 8 && upp != 12 && upp != 16) || k1 < 2 || k1 > 4) return 0;
   if (hw >= ((int64_t)1 << 31) || n > HEAD_BWD_BLOCKS) return 0;
   return upp;
 }
@@ -659,8 +676,8 @@ extern "C" int mia_head_norm_fwd(const void* y, int dtype, const float* scale, c
   MIA_CHECK_ARG(upp > 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "mia_head_norm_fwd: shape not eligible (c0=%d k1=%d)", c0, k1);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int slabs = head_norm_slabs(n, hw);
-  if (dtype == MIA_BF16) HEAD_DISPATCH(head_norm_fwd_kernel, bf16_t, dim3(n * slabs), static_cast<const bf16_t*>(y), scale, shift, slope, w, b, logits, (int)hw, slabs, osn, osp, osk);
-  else HEAD_DISPATCH(head_norm_fwd_kernel, float, dim3(n * slabs), static_cast<const float*>(y), scale, shift, slope, w, b, logits, (int)hw, slabs, osn, osp, osk);
+  if (dtype == MIA_BF16) HEAD_DISPATCH_N(head_norm_fwd_kernel, bf16_t, dim3(n * slabs), static_cast<const bf16_t*>(y), scale, shift, slope, w, b, logits, (int)hw, slabs, osn, osp, osk);
+  else HEAD_DISPATCH_N(head_norm_fwd_kernel, float, dim3(n * slabs), static_cast<const float*>(y), scale, shift, slope, w, b, logits, (int)hw, slabs, osn, osp, osk);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
 }
@@ -674,8 +691,8 @@ extern "C" int mia_head_norm_wgrad(const float* dlogits, const void* y, int dtyp
   MIA_CHECK_ARG(upp > 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "mia_head_norm_wgrad: shape not eligible (c0=%d k1=%d)", c0, k1);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int slabs = head_norm_slabs(n, hw);
-  if (dtype == MIA_BF16) HEAD_DISPATCH(head_norm_wgrad_kernel, bf16_t, dim3(n * slabs), dlogits, static_cast<const bf16_t*>(y), scale, shift, slope, workspace, (int)hw, slabs, gsn, gsp, gsk);
-  else HEAD_DISPATCH(head_norm_wgrad_kernel, float, dim3(n * slabs), dlogits, static_cast<const float*>(y), scale, shift, slope, workspace, (int)hw, slabs, gsn, gsp, gsk);
+  if (dtype == MIA_BF16) HEAD_DISPATCH_N(head_norm_wgrad_kernel, bf16_t, dim3(n * slabs), dlogits, static_cast<const bf16_t*>(y), scale, shift, slope, workspace, (int)hw, slabs, gsn, gsp, gsk);
+  else HEAD_DISPATCH_N(head_norm_wgrad_kernel, float, dim3(n * slabs), dlogits, static_cast<const float*>(y), scale, shift, slope, workspace, (int)hw, slabs, gsn, gsp, gsk);
   hipLaunchKernelGGL(head_bwd_final_kernel, dim3(ceil_div(k1 * (c0 + 1), 16)), dim3(256), 0, st, workspace, n * slabs, k1, c0, dw, db, accumulate);
   MIA_LAUNCH_CHECK();
   return MIA_OK;
