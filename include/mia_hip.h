@@ -318,7 +318,7 @@ int mia_dice_ce_bwd(const float* logits, const long long* labels, const float* c
 /* Head fused with the last decoder block (unet.py:176 behind blocks.py:98-100): the block's activation
  * z = lrelu(scale*y + shift) has one consumer, the 1x1 head, so it is never materialised -- the head recomputes it from the
  * raw conv output y on load, and the block's norm backward recomputes dz = W^T dlogits instead of reading it.
- * mia_head_norm_eligible: 0 or the units per pixel; contract c0 in {4,8,16} 16-byte units, 2 <= k1 <= 4. */
+ * mia_head_norm_eligible: 0 or the units per pixel; contract c0 in {4,8,12,16} 16-byte units (12 = 96 bf16 channels, on sixteen-lane groups), 2 <= k1 <= 4. */
 int mia_head_norm_eligible(int dtype, int n, int64_t hw, int c0, int k1);
 int mia_head_norm_fwd(const void* y, int dtype, const float* scale, const float* shift, float slope, const float* w,
                       const float* b, float* logits, int n, int64_t hw, int c0, int k1, int64_t osn, int64_t osk, int64_t osp,
